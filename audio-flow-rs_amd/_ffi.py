@@ -1,0 +1,139 @@
+"""ctypes binding of libaudioflow_dsp.so (the C ABI in include/audioflow_dsp.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).
+There is no fallback: if the shared object is missing, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaudioflow_dsp.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+AF_OK = 0
+AF_ERR_INVALID_ARG = 1
+AF_ERR_BUFFER_TOO_SMALL = 2
+AF_ERR_NO_DEVICE = 3
+AF_ERR_HIP = 4
+AF_ERR_OUT_OF_MEMORY = 5
+AF_ERR_UNSUPPORTED = 6
+
+AF_PCM_F32 = 0
+AF_PCM_I16 = 1
+
+
+class FeaturesConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint32), ("channels", C.c_uint32), ("n_fft", C.c_uint32),
+                ("hop", C.c_uint32), ("n_mels", C.c_uint32), ("f_min", C.c_float),
+                ("f_max", C.c_float), ("sample_format", C.c_uint32), ("device", C.c_int32)]
+
+
+class VadConfig(C.Structure):
+    _fields_ = [("threshold_db", C.c_float), ("smoothing_factor", C.c_float),
+                ("silence_timeout_frames", C.c_size_t), ("min_speech_frames", C.c_size_t)]
+
+
+_vp = C.c_void_p
+_sz = C.c_size_t
+_szp = C.POINTER(C.c_size_t)
+_u32 = C.c_uint32
+_st = C.c_int32
+
+# name -> (restype, argtypes); mirrors include/audioflow_dsp.h one to one
+SIGNATURES = {
+    "af_last_error": (C.c_char_p, []),
+    "af_version": (C.c_char_p, []),
+    "af_device_count": (C.c_int, []),
+    # to_mono
+    "af_to_mono_out_len": (_sz, [_sz, C.c_uint16]),
+    "af_to_mono": (_st, [_vp, _sz, C.c_uint16, _vp, _sz, _szp]),
+    "af_to_mono_device": (_st, [_vp, _sz, C.c_uint16, _vp, _vp]),
+    # quantiser / base64
+    "af_quantize_pcm16": (_st, [_vp, _sz, _vp]),
+    "af_quantize_pcm16_device": (_st, [_vp, _sz, _vp, _vp]),
+    "af_base64_len": (_sz, [_sz]),
+    "af_pcm16_base64": (_st, [_vp, _sz, _vp, _sz, _szp]),
+    "af_pcm16_base64_device": (_st, [_vp, _sz, _vp, _vp]),
+    # VAD
+    "af_vad_energy": (_st, [_vp, _sz, _sz, _vp]),
+    "af_vad_energy_device": (_st, [_vp, _sz, _sz, _vp, _vp]),
+    "af_vad_default_config": (None, [C.POINTER(VadConfig)]),
+    "af_vad_create": (_st, [C.POINTER(VadConfig), C.POINTER(_vp)]),
+    "af_vad_destroy": (None, [_vp]),
+    "af_vad_detect": (_st, [_vp, _vp, _sz, C.POINTER(C.c_int)]),
+    "af_vad_detect_frames": (_st, [_vp, _vp, _sz, _sz, _vp]),
+    "af_vad_reset": (None, [_vp]),
+    "af_vad_state": (C.c_int, [_vp]),
+    "af_vad_energy_db": (C.c_float, [_vp]),
+    "af_vad_speech_frame_count": (_sz, [_vp]),
+    # AudioResampler
+    "af_resampler_create": (_st, [_u32, _u32, C.POINTER(_vp)]),
+    "af_resampler_create_48k_to_16k": (_st, [C.POINTER(_vp)]),
+    "af_resampler_destroy": (None, [_vp]),
+    "af_resampler_input_rate": (_u32, [_vp]),
+    "af_resampler_output_rate": (_u32, [_vp]),
+    "af_resampler_needs_resampling": (C.c_int, [_vp]),
+    "af_resampler_out_len": (_sz, [_vp, _sz]),
+    "af_resampler_process": (_st, [_vp, _vp, _sz, _vp, _sz, _szp]),
+    "af_resampler_flush": (_st, [_vp, _vp, _sz, _szp]),
+    "af_resampler_reset": (None, [_vp]),
+    "af_resample_out_len": (_sz, [_u32, _u32, _sz]),
+    "af_resample_batch": (_st, [_u32, _u32, _vp, _sz, _sz, _vp, _sz]),
+    "af_resample_batch_device": (_st, [_u32, _u32, _vp, _sz, _sz, _vp, _vp]),
+    "af_resample_taps": (_st, [_u32, _u32, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32),
+                               C.POINTER(_u32)]),
+    # BatchResampler
+    "af_batch_resampler_create": (_st, [_u32, _u32, C.POINTER(_vp)]),
+    "af_batch_resampler_destroy": (None, [_vp]),
+    "af_batch_resampler_out_len": (_sz, [_vp, _sz]),
+    "af_batch_resampler_buffered": (_sz, [_vp]),
+    "af_batch_resampler_process": (_st, [_vp, _vp, _sz, _vp, _sz, _szp]),
+    "af_batch_resampler_flush": (_st, [_vp, _vp, _sz, _szp]),
+    # FIR
+    "af_fir_create": (_st, [_vp, _sz, C.POINTER(_vp)]),
+    "af_fir_destroy": (None, [_vp]),
+    "af_fir_process": (_st, [_vp, _vp, _sz, _vp]),
+    "af_fir_reset": (None, [_vp]),
+    "af_fir_batch": (_st, [_vp, _sz, _vp, _sz, _sz, _vp]),
+    "af_fir_batch_device": (_st, [_vp, _sz, _vp, _sz, _sz, _vp, _vp]),
+    # FeaturePipeline
+    "af_features_default_config": (None, [C.POINTER(FeaturesConfig)]),
+    "af_features_create": (_st, [C.POINTER(FeaturesConfig), C.POINTER(_vp)]),
+    "af_features_destroy": (None, [_vp]),
+    "af_features_n_frames": (_sz, [_vp, _sz]),
+    "af_features_set_batch": (_st, [_vp, _vp, _sz, _szp]),
+    "af_features_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp]),
+    "af_features_run_device": (_st, [_vp, _vp, _vp, _vp]),
+    "af_features_run": (_st, [_vp, _vp, _vp, _sz]),
+    "af_features_mel_weights": (_st, [_vp, _vp, _sz]),
+    "af_features_kernel_name": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load(path: str | None = None) -> C.CDLL:
+    """Load libaudioflow_dsp.so and attach the declared signatures.
+
+    Importing torch first (when it is going to be used for device memory) makes
+    the dynamic loader reuse torch's already-loaded libamdhip64.so.7, so both
+    sides share one HIP runtime and device pointers can cross the boundary.
+    """
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError(
+            f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError => header/library mismatch
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if path is None:
+        _lib = lib
+    return lib

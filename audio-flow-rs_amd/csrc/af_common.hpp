@@ -1,0 +1,77 @@
+// af_common.hpp -- shared host-side helpers for libaudioflow_dsp.so
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/audioflow_dsp.h"
+
+namespace af {
+
+// thread-local message behind af_last_error()
+std::string& last_error_slot();
+af_status fail(af_status code, const char* fmt, ...);
+
+// Makes sure a gfx950 device is usable; never aborts.
+af_status ensure_device(int device /* -1 = current */);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define AF_HIP(expr)                                                              \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess)                                                     \
+            return ::af::fail(_e == hipErrorOutOfMemory ? AF_ERR_OUT_OF_MEMORY    \
+                                                        : AF_ERR_HIP,             \
+                              "%s failed: %s (%s:%d)", #expr,                     \
+                              hipGetErrorString(_e), __FILE__, __LINE__);         \
+    } while (0)
+
+#define AF_REQUIRE(cond, ...)                                                     \
+    do {                                                                          \
+        if (!(cond)) return ::af::fail(AF_ERR_INVALID_ARG, __VA_ARGS__);          \
+    } while (0)
+
+#define AF_TRY(expr)                                                              \
+    do {                                                                          \
+        af_status _s = (expr);                                                    \
+        if (_s != AF_OK) return _s;                                               \
+    } while (0)
+
+// RAII device buffer (host-side bookkeeping only)
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // grow-only reserve
+    af_status reserve(size_t n)
+    {
+        if (n <= bytes) return AF_OK;
+        release();
+        hipError_t e = hipMalloc(&p, n ? n : 1);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(AF_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", n,
+                        hipGetErrorString(e));
+        }
+        bytes = n;
+        return AF_OK;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace af

@@ -1,0 +1,67 @@
+// core.hip -- error reporting and device bring-up for libaudioflow_dsp.so
+#include <mutex>
+
+#include "af_common.hpp"
+
+namespace af {
+
+std::string& last_error_slot()
+{
+    static thread_local std::string slot;
+    return slot;
+}
+
+af_status fail(af_status code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error_slot() = buf;
+    return code;
+}
+
+af_status ensure_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(AF_ERR_NO_DEVICE,
+                    "no HIP device available (%s); libaudioflow_dsp has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    if (device >= 0) {
+        if (device >= n) return fail(AF_ERR_INVALID_ARG, "device %d out of range (have %d)", device, n);
+        AF_HIP(hipSetDevice(device));
+    }
+    int cur = 0;
+    AF_HIP(hipGetDevice(&cur));
+    hipDeviceProp_t prop;
+    AF_HIP(hipGetDeviceProperties(&prop, cur));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(AF_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", cur,
+                    prop.gcnArchName);
+    return AF_OK;
+}
+
+}  // namespace af
+
+extern "C" {
+
+const char* af_last_error(void) { return af::last_error_slot().c_str(); }
+
+const char* af_version(void) { return "audioflow-dsp-mi355x 0.1.0 (gfx950)"; }
+
+int af_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,353 @@
+// features_api.hip -- host side of FeaturePipeline (include/audioflow_dsp.h):
+// builds the constant tables (window, twiddles, banded mel plan), the per-batch
+// clip tables, and launches the fused kernel of features_kernel.hip.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "features.hpp"
+
+using namespace af;
+using namespace af::feat;
+
+struct af_features {
+    af_features_config cfg{};
+    int device = 0;
+    int n_cus = 256;
+    std::vector<float> W;            // [n_mels][513] f32, as used on the device
+    Plan plan{};
+    DevBuf d_const;                  // wintab | twtab | wfrag | plan
+    const float* d_wintab = nullptr;
+    const float2* d_twtab = nullptr;
+    const float* d_wfrag = nullptr;
+    const Plan* d_plan = nullptr;
+    // batch description
+    DevBuf d_tables;                 // pcm_off | out_off | unit_off, (n_clips+1) each
+    size_t n_clips = 0;
+    int64_t total_pcm_frames = 0;
+    int64_t total_frames = 0;
+    int64_t total_units = 0;
+    bool offsets_aligned = false;
+    // staging for the host-buffer entry point
+    DevBuf d_pcm, d_mel;
+};
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+double hz_to_mel(double hz) { return 2595.0 * std::log10(1.0 + hz / 700.0); }
+double mel_to_hz(double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); }
+
+// docs/OPS.md "Mel": HTK scale, triangular, no area normalisation
+void build_mel(const af_features_config& c, double f_max, std::vector<float>& W)
+{
+    const int nm = (int)c.n_mels;
+    std::vector<double> edges(nm + 2);
+    const double m_lo = hz_to_mel(c.f_min), m_hi = hz_to_mel(f_max);
+    for (int i = 0; i < nm + 2; ++i)
+        edges[i] = mel_to_hz(m_lo + (m_hi - m_lo) * (double)i / (double)(nm + 1));
+    W.assign((size_t)nm * kBins, 0.0f);
+    for (int m = 0; m < nm; ++m) {
+        const double lo = edges[m], ce = edges[m + 1], hi = edges[m + 2];
+        for (int k = 0; k < kBins; ++k) {
+            const double f = (double)k * (double)c.sample_rate / (double)kNfft;
+            const double up = (f - lo) / (ce - lo), dn = (hi - f) / (hi - ce);
+            const double v = up < dn ? up : dn;
+            W[(size_t)m * kBins + k] = v > 0.0 ? (float)v : 0.0f;
+        }
+    }
+}
+
+// Turn W into MFMA A fragments: per 16-filter tile only the band of bins with
+// a non-zero weight, in K-steps of 4 bins, split contiguously over 4 waves.
+af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
+                     std::vector<float>& wfrag)
+{
+    std::memset(&plan, 0, sizeof(plan));
+    const int n_tiles = (n_mels + 15) / 16;
+    if (n_tiles > kMaxTiles) return fail(AF_ERR_UNSUPPORTED, "n_mels %d > %d", n_mels, 16 * kMaxTiles);
+    plan.n_mels = n_mels;
+    plan.n_tiles = n_tiles;
+
+    std::vector<int> t_bin0(n_tiles), t_steps(n_tiles), t_step0(n_tiles);
+    int total = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+        int lo = kBins, hi = -1;
+        for (int i = 0; i < 16; ++i) {
+            const int m = 16 * t + i;
+            if (m >= n_mels) break;
+            for (int k = 0; k < kBins; ++k)
+                if (W[(size_t)m * kBins + k] != 0.0f) {
+                    if (k < lo) lo = k;
+                    if (k > hi) hi = k;
+                }
+        }
+        if (hi < lo) { lo = 0; hi = 0; }           // all-zero tile: one harmless step
+        int steps = (hi - lo + 1 + 3) / 4;
+        int bin0 = lo;
+        if (bin0 + 4 * steps > kBins) bin0 = kBins - 4 * steps;  // never read past bin 512
+        if (bin0 < 0) return fail(AF_ERR_UNSUPPORTED, "mel tile wider than the spectrum");
+        t_bin0[t] = bin0;
+        t_steps[t] = steps;
+        t_step0[t] = total;
+        total += steps;
+    }
+    plan.n_steps = total;
+    wfrag.assign((size_t)total * 64, 0.0f);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int s = 0; s < t_steps[t]; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = 16 * t + (lane & 15);
+                const int k = t_bin0[t] + 4 * s + (lane >> 4);
+                wfrag[(size_t)(t_step0[t] + s) * 64 + lane] =
+                    (m < n_mels) ? W[(size_t)m * kBins + k] : 0.0f;
+            }
+
+    // contiguous split of the step list over the waves
+    int slot = 0;
+    int tile = 0, used_in_tile = 0;
+    for (int t = 0; t < n_tiles; ++t) { plan.tile_slot0[t] = -1; plan.tile_nslots[t] = 0; }
+    int remaining = total;
+    for (int w = 0; w < kWaves; ++w) {
+        int quota = (remaining + (kWaves - w) - 1) / (kWaves - w);
+        remaining -= quota;
+        int g = 0;
+        while (quota > 0 && tile < n_tiles) {
+            const int avail = t_steps[tile] - used_in_tile;
+            const int take = avail < quota ? avail : quota;
+            if (g >= kMaxSeg || slot >= kMaxSlots)
+                return fail(AF_ERR_UNSUPPORTED, "mel plan needs more than %d segments per wave",
+                            kMaxSeg);
+            plan.seg_slot[w][g] = slot;
+            plan.seg_bin0[w][g] = t_bin0[tile] + 4 * used_in_tile;
+            plan.seg_step0[w][g] = t_step0[tile] + used_in_tile;
+            plan.seg_nsteps[w][g] = take;
+            if (plan.tile_slot0[tile] < 0) plan.tile_slot0[tile] = slot;
+            plan.tile_nslots[tile] += 1;
+            ++slot;
+            ++g;
+            used_in_tile += take;
+            quota -= take;
+            if (used_in_tile == t_steps[tile]) { ++tile; used_in_tile = 0; }
+        }
+        plan.wave_nseg[w] = g;
+    }
+    plan.n_slots = slot;
+    return AF_OK;
+}
+
+size_t bytes_per_frame(const af_features_config& c)
+{
+    return (size_t)c.channels * (c.sample_format == AF_PCM_I16 ? 2 : 4);
+}
+
+af_status upload_tables(af_features* p, const std::vector<int64_t>& pcm_off)
+{
+    const size_t n = p->n_clips;
+    std::vector<int64_t> tab(3 * (n + 1));
+    int64_t* out_off = tab.data() + (n + 1);
+    int64_t* unit_off = tab.data() + 2 * (n + 1);
+    std::memcpy(tab.data(), pcm_off.data(), (n + 1) * sizeof(int64_t));
+    out_off[0] = 0;
+    unit_off[0] = 0;
+    const size_t bpf = bytes_per_frame(p->cfg);
+    bool aligned = (p->cfg.hop * bpf) % 16 == 0;
+    for (size_t c = 0; c < n; ++c) {
+        const int64_t len = pcm_off[c + 1] - pcm_off[c];
+        if (len < 0) return fail(AF_ERR_INVALID_ARG, "clip offsets must be non-decreasing");
+        const int64_t nf = (int64_t)af_features_n_frames(p, (size_t)len);
+        out_off[c + 1] = out_off[c] + nf;
+        unit_off[c + 1] = unit_off[c] + (nf + kFramesPerIter - 1) / kFramesPerIter;
+        if ((pcm_off[c] * (int64_t)bpf) % 16 != 0) aligned = false;
+    }
+    p->total_pcm_frames = pcm_off[n];
+    p->total_frames = out_off[n];
+    p->total_units = unit_off[n];
+    p->offsets_aligned = aligned;
+    AF_TRY(p->d_tables.reserve(tab.size() * sizeof(int64_t)));
+    AF_HIP(hipMemcpy(p->d_tables.p, tab.data(), tab.size() * sizeof(int64_t),
+                     hipMemcpyHostToDevice));
+    return AF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void af_features_default_config(af_features_config* cfg)
+{
+    if (!cfg) return;
+    cfg->sample_rate = 48000;
+    cfg->channels = 2;
+    cfg->n_fft = kNfft;
+    cfg->hop = 256;
+    cfg->n_mels = 80;
+    cfg->f_min = 0.0f;
+    cfg->f_max = 0.0f;
+    cfg->sample_format = AF_PCM_F32;
+    cfg->device = -1;
+}
+
+af_status af_features_create(const af_features_config* cfg, af_features** out)
+{
+    AF_REQUIRE(cfg && out, "af_features_create: null argument");
+    *out = nullptr;
+    AF_REQUIRE(cfg->n_fft == (uint32_t)kNfft, "n_fft must be %d (got %u)", kNfft, cfg->n_fft);
+    AF_REQUIRE(cfg->channels == 1 || cfg->channels == 2, "channels must be 1 or 2 (got %u)",
+               cfg->channels);
+    AF_REQUIRE(cfg->hop >= 64 && cfg->hop <= 1024 && cfg->hop % 4 == 0,
+               "hop must be a multiple of 4 in [64, 1024] (got %u)", cfg->hop);
+    AF_REQUIRE(cfg->n_mels >= 1 && cfg->n_mels <= 16u * kMaxTiles, "n_mels must be in [1, %d]",
+               16 * kMaxTiles);
+    AF_REQUIRE(cfg->sample_rate > 0, "sample_rate must be positive");
+    AF_REQUIRE(cfg->sample_format == AF_PCM_F32 || cfg->sample_format == AF_PCM_I16,
+               "unknown sample_format %u", cfg->sample_format);
+    const double f_max = cfg->f_max > 0.0f ? (double)cfg->f_max : 0.5 * (double)cfg->sample_rate;
+    AF_REQUIRE((double)cfg->f_min >= 0.0 && (double)cfg->f_min < f_max, "need 0 <= f_min < f_max");
+
+    AF_TRY(ensure_device(cfg->device));
+    af_features* p = new (std::nothrow) af_features();
+    if (!p) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
+    p->cfg = *cfg;
+    if (hipGetDevice(&p->device) != hipSuccess) p->device = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->n_cus = prop.multiProcessorCount;
+
+    build_mel(*cfg, f_max, p->W);
+    std::vector<float> wfrag;
+    af_status st = build_plan(p->W, (int)cfg->n_mels, p->plan, wfrag);
+    if (st != AF_OK) { delete p; return st; }
+
+    // constant block: wintab[1024] | twtab[32*32] float2 | wfrag | plan
+    std::vector<float> wintab(kNfft);
+    for (int i = 0; i < kNfft; ++i) {
+        const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)kNfft);
+        wintab[i] = 0.5f * (float)w;   // the 1/2 of the two-real-signals split, exact
+    }
+    std::vector<float> twtab(2 * 32 * 32);
+    for (int k1 = 0; k1 < 32; ++k1)
+        for (int n2 = 0; n2 < 32; ++n2) {
+            const double a = 2.0 * kPi * (double)(k1 * n2) / (double)kNfft;
+            twtab[2 * (k1 * 32 + n2)] = (float)std::cos(a);
+            twtab[2 * (k1 * 32 + n2) + 1] = (float)std::sin(a);
+        }
+    const size_t off_tw = wintab.size() * sizeof(float);
+    const size_t off_wf = off_tw + twtab.size() * sizeof(float);
+    const size_t off_plan = (off_wf + wfrag.size() * sizeof(float) + 15) & ~(size_t)15;
+    const size_t total = off_plan + sizeof(Plan);
+    std::vector<char> blob(total, 0);
+    std::memcpy(blob.data(), wintab.data(), off_tw);
+    std::memcpy(blob.data() + off_tw, twtab.data(), twtab.size() * sizeof(float));
+    std::memcpy(blob.data() + off_wf, wfrag.data(), wfrag.size() * sizeof(float));
+    std::memcpy(blob.data() + off_plan, &p->plan, sizeof(Plan));
+    st = p->d_const.reserve(total);
+    if (st == AF_OK && hipMemcpy(p->d_const.p, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess)
+        st = fail(AF_ERR_HIP, "uploading feature tables failed");
+    if (st != AF_OK) { delete p; return st; }
+    char* base = p->d_const.as<char>();
+    p->d_wintab = reinterpret_cast<const float*>(base);
+    p->d_twtab = reinterpret_cast<const float2*>(base + off_tw);
+    p->d_wfrag = reinterpret_cast<const float*>(base + off_wf);
+    p->d_plan = reinterpret_cast<const Plan*>(base + off_plan);
+    *out = p;
+    return AF_OK;
+}
+
+void af_features_destroy(af_features* p) { delete p; }
+
+size_t af_features_n_frames(const af_features* p, size_t n_pcm_frames)
+{
+    if (!p || n_pcm_frames < p->cfg.n_fft) return 0;
+    return 1 + (n_pcm_frames - p->cfg.n_fft) / p->cfg.hop;
+}
+
+af_status af_features_set_batch(af_features* p, const int64_t* clip_offsets, size_t n_clips,
+                                size_t* total_frames_out)
+{
+    AF_REQUIRE(p && (clip_offsets || n_clips == 0), "af_features_set_batch: null argument");
+    AF_REQUIRE(n_clips < (size_t)1 << 30, "too many clips");
+    std::vector<int64_t> off(n_clips + 1, 0);
+    for (size_t c = 0; c <= n_clips && clip_offsets; ++c) off[c] = clip_offsets[c];
+    AF_REQUIRE(off[0] >= 0, "clip offsets must be non-negative");
+    p->n_clips = n_clips;
+    AF_TRY(upload_tables(p, off));
+    if (total_frames_out) *total_frames_out = (size_t)p->total_frames;
+    return AF_OK;
+}
+
+af_status af_features_set_batch_uniform(af_features* p, size_t n_clips, size_t frames_per_clip,
+                                        size_t* total_frames_out)
+{
+    AF_REQUIRE(p, "af_features_set_batch_uniform: null handle");
+    AF_REQUIRE(n_clips < (size_t)1 << 30, "too many clips");
+    std::vector<int64_t> off(n_clips + 1);
+    for (size_t c = 0; c <= n_clips; ++c) off[c] = (int64_t)(c * frames_per_clip);
+    p->n_clips = n_clips;
+    AF_TRY(upload_tables(p, off));
+    if (total_frames_out) *total_frames_out = (size_t)p->total_frames;
+    return AF_OK;
+}
+
+af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel_dev, void* stream)
+{
+    AF_REQUIRE(p, "af_features_run_device: null handle");
+    if (p->total_units == 0) return AF_OK;
+    AF_REQUIRE(pcm_dev && mel_dev, "af_features_run_device: null buffer");
+    Params prm{};
+    prm.pcm = pcm_dev;
+    prm.mel = mel_dev;
+    prm.wintab = p->d_wintab;
+    prm.twtab = p->d_twtab;
+    prm.wfrag = p->d_wfrag;
+    prm.plan = p->d_plan;
+    const int64_t* tab = p->d_tables.as<int64_t>();
+    prm.pcm_off = tab;
+    prm.out_off = tab + (p->n_clips + 1);
+    prm.unit_off = tab + 2 * (p->n_clips + 1);
+    prm.total_units = p->total_units;
+    prm.n_clips = (int)p->n_clips;
+    prm.hop = (int)p->cfg.hop;
+    prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
+    const size_t smem = features_smem_bytes(prm.hop, p->plan.n_slots);
+    AF_REQUIRE(smem <= 160 * 1024, "hop %d needs %zu bytes of LDS", prm.hop, smem);
+    // persistent grid: as many workgroups as stay resident (LDS-limited, at most 2 per CU)
+    int per_cu = (int)((160 * 1024) / smem);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)p->n_cus * per_cu;
+    if (grid > p->total_units) grid = p->total_units;
+    return launch_features(prm, (int)p->cfg.channels, p->cfg.sample_format == AF_PCM_I16,
+                           (int)grid, smem, as_stream(stream));
+}
+
+af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t mel_cap)
+{
+    AF_REQUIRE(p, "af_features_run: null handle");
+    const size_t n_out = (size_t)p->total_frames * p->cfg.n_mels;
+    if (mel_cap < n_out)
+        return fail(AF_ERR_BUFFER_TOO_SMALL, "mel buffer holds %zu floats, need %zu", mel_cap, n_out);
+    if (n_out == 0) return AF_OK;
+    AF_REQUIRE(pcm && mel, "af_features_run: null buffer");
+    const size_t in_bytes = (size_t)p->total_pcm_frames * bytes_per_frame(p->cfg);
+    AF_TRY(p->d_pcm.reserve(in_bytes));
+    AF_TRY(p->d_mel.reserve(n_out * sizeof(float)));
+    AF_HIP(hipMemcpy(p->d_pcm.p, pcm, in_bytes, hipMemcpyHostToDevice));
+    AF_TRY(af_features_run_device(p, p->d_pcm.p, p->d_mel.as<float>(), nullptr));
+    AF_HIP(hipMemcpy(mel, p->d_mel.p, n_out * sizeof(float), hipMemcpyDeviceToHost));
+    return AF_OK;
+}
+
+af_status af_features_mel_weights(const af_features* p, float* W, size_t cap)
+{
+    AF_REQUIRE(p && W, "af_features_mel_weights: null argument");
+    if (cap < p->W.size())
+        return fail(AF_ERR_BUFFER_TOO_SMALL, "need %zu floats", p->W.size());
+    std::memcpy(W, p->W.data(), p->W.size() * sizeof(float));
+    return AF_OK;
+}
+
+const char* af_features_kernel_name(void) { return "af_features_kernel"; }
+
+}  // extern "C"

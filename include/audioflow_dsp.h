@@ -1,0 +1,224 @@
+/*
+ * audioflow_dsp.h -- C ABI of libaudioflow_dsp.so, the MI355X (gfx950) DSP
+ * hot path behind audio-flow's audio module.
+ *
+ * This is the drop-in boundary: plain `extern "C"`, pointers + sizes, opaque
+ * handles, int status codes.  No C++/torch types cross it.  Every entry point
+ * names the reference interface (forfd8960/audio-flow-rs, paths relative to
+ * src-tauri/src/) it replaces or, for ops the reference only plans
+ * (specs/0001-spec.md:266, specs/0002-design.md:1519-1523), the build-defined
+ * op in docs/OPS.md -- marked [R] (reference-pinned) or [B] (build-defined).
+ *
+ * Conventions
+ *  - status: 0 = AF_OK, non-zero = error; af_last_error() returns the
+ *    thread-local message of the last failing call (the Rust shim maps it to
+ *    AudioError::ResamplingFailed(msg), error.rs:109-110).
+ *  - nothing aborts or throws across the ABI.
+ *  - handles are NOT thread-safe (they mirror `&mut self`,
+ *    modules/audio/resampler.rs:71); distinct handles may be used concurrently.
+ *  - "*_device" entry points take device pointers and a hipStream_t (as
+ *    void*), enqueue work and return without synchronising; the host-buffer
+ *    entry points copy in, run, copy out and synchronise.
+ *  - there is NO CPU fallback: every compute call needs a gfx950 device and
+ *    fails with AF_ERR_NO_DEVICE / AF_ERR_HIP otherwise.
+ */
+#ifndef AUDIOFLOW_DSP_H
+#define AUDIOFLOW_DSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t af_status;
+enum {
+    AF_OK = 0,
+    AF_ERR_INVALID_ARG = 1,     /* null pointer, zero rate, unsupported shape */
+    AF_ERR_BUFFER_TOO_SMALL = 2,
+    AF_ERR_NO_DEVICE = 3,       /* no gfx950 device visible */
+    AF_ERR_HIP = 4,             /* a HIP runtime call failed (message has it) */
+    AF_ERR_OUT_OF_MEMORY = 5,
+    AF_ERR_UNSUPPORTED = 6
+};
+
+/* sample formats of interleaved PCM handed to the batch entry points */
+enum { AF_PCM_F32 = 0, AF_PCM_I16 = 1 };
+
+const char* af_last_error(void);
+const char* af_version(void);
+/* number of visible HIP devices (0 if none; never fails) */
+int         af_device_count(void);
+
+/* ------------------------------------------------------------------ [R] */
+/* AudioFrame::to_mono, modules/audio/capture.rs:30-42.
+ * n_samples interleaved f32 samples, `channels` per frame; a trailing partial
+ * frame is summed and still divided by `channels` (Rust `chunks`).
+ * channels==1 copies.  Output length = ceil(n_samples/channels). */
+size_t    af_to_mono_out_len(size_t n_samples, uint16_t channels);
+af_status af_to_mono(const float* in, size_t n_samples, uint16_t channels,
+                     float* out, size_t out_cap, size_t* n_out);
+af_status af_to_mono_device(const float* in_dev, size_t n_samples, uint16_t channels,
+                            float* out_dev, void* stream);
+
+/* WebSocketClient::send_audio / MessageBuilder::audio_message quantiser,
+ * modules/network/websocket.rs:246-251 and :340-345:
+ * (x.clamp(-1,1) * 32767.0) as i16, little-endian. */
+af_status af_quantize_pcm16(const float* in, size_t n, int16_t* out);
+af_status af_quantize_pcm16_device(const float* in_dev, size_t n, int16_t* out_dev,
+                                   void* stream);
+/* websocket.rs:254 STANDARD.encode of the LE i16 bytes: quantise + base64 on
+ * the device, `out` receives af_base64_len(2*n) chars (no NUL). */
+size_t    af_base64_len(size_t n_bytes);
+af_status af_pcm16_base64(const float* in, size_t n, char* out, size_t out_cap,
+                          size_t* n_out);
+af_status af_pcm16_base64_device(const float* in_dev, size_t n, char* out_dev,
+                                 void* stream);
+
+/* VoiceActivityDetector::calculate_energy, modules/audio/vad.rs:157-168,
+ * batched: energy[i] = sum(x[i*frame_len .. +frame_len]^2) / frame_len for
+ * n_frames consecutive frames (f32, wavefront-shuffle reduction). */
+af_status af_vad_energy(const float* in, size_t n_frames, size_t frame_len,
+                        float* energy_out);
+af_status af_vad_energy_device(const float* in_dev, size_t n_frames, size_t frame_len,
+                               float* energy_dev, void* stream);
+
+/* VoiceActivityDetector, vad.rs:21-43 (config), :80 new, :97 detect,
+ * :179 reset.  detect() runs the energy reduction on the device and the
+ * EMA / dBFS / 3-state machine (vad.rs:102-151) on the host. */
+typedef struct af_vad af_vad;
+typedef struct {
+    float  threshold_db;            /* vad.rs:37, default -50 */
+    float  smoothing_factor;        /* vad.rs:38, default 0.3 */
+    size_t silence_timeout_frames;  /* vad.rs:39, default 15 */
+    size_t min_speech_frames;       /* vad.rs:40, default 3 */
+} af_vad_config;
+enum { AF_VAD_SILENCE = 0, AF_VAD_SPEECH = 1, AF_VAD_ENDING = 2 };
+void      af_vad_default_config(af_vad_config* cfg);
+af_status af_vad_create(const af_vad_config* cfg, af_vad** out);
+void      af_vad_destroy(af_vad* v);
+/* one frame (vad.rs:97); *state_out receives AF_VAD_* */
+af_status af_vad_detect(af_vad* v, const float* frame, size_t n, int* state_out);
+/* n_frames consecutive frames of frame_len samples; states_out[n_frames] */
+af_status af_vad_detect_frames(af_vad* v, const float* in, size_t n_frames,
+                               size_t frame_len, int* states_out);
+void      af_vad_reset(af_vad* v);                       /* vad.rs:179 */
+int       af_vad_state(const af_vad* v);                 /* vad.rs:187 */
+float     af_vad_energy_db(const af_vad* v);             /* vad.rs:192 */
+size_t    af_vad_speech_frame_count(const af_vad* v);    /* vad.rs:202 */
+
+/* AudioResampler, modules/audio/resampler.rs:23-109.
+ * new(input_rate, output_rate) :32; equal rates => exact passthrough
+ * (:72-75, pinned by test :185-190) [R].  Unequal rates: the reference wraps
+ * rubato's cubic FastFixedIn (never executed by any test; SURVEY section 8
+ * A2); here it is the polyphase windowed-sinc resampler of docs/OPS.md [B]
+ * (the spec's stated intent, specs/0001-spec.md:266).
+ * process() is streaming like the reference's (state carried in the handle):
+ * it returns every output whose input support has arrived. */
+typedef struct af_resampler af_resampler;
+af_status af_resampler_create(uint32_t input_rate, uint32_t output_rate,
+                              af_resampler** out);                 /* :32 */
+af_status af_resampler_create_48k_to_16k(af_resampler** out);      /* :60 */
+void      af_resampler_destroy(af_resampler* r);
+uint32_t  af_resampler_input_rate(const af_resampler* r);          /* :96 */
+uint32_t  af_resampler_output_rate(const af_resampler* r);         /* :101 */
+int       af_resampler_needs_resampling(const af_resampler* r);    /* :106 */
+/* upper bound of what the next process(n_in) can return */
+size_t    af_resampler_out_len(const af_resampler* r, size_t n_in);
+af_status af_resampler_process(af_resampler* r, const float* in, size_t n_in,
+                               float* out, size_t out_cap, size_t* n_out); /* :71 */
+/* [B] emit the tail (zero extension) so the stream totals ceil(n*L/M) */
+af_status af_resampler_flush(af_resampler* r, float* out, size_t out_cap,
+                             size_t* n_out);
+void      af_resampler_reset(af_resampler* r);
+
+/* One-shot batch resample [B] (BASELINE config 3): n_clips mono clips of
+ * n_in samples each, contiguous; out gets n_clips * af_resample_out_len(). */
+size_t    af_resample_out_len(uint32_t input_rate, uint32_t output_rate, size_t n_in);
+af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate,
+                            const float* in, size_t n_clips, size_t n_in,
+                            float* out, size_t out_cap);
+af_status af_resample_batch_device(uint32_t input_rate, uint32_t output_rate,
+                                   const float* in_dev, size_t n_clips, size_t n_in,
+                                   float* out_dev, void* stream);
+/* prototype filter taps h[L*T] as used by the device (f32), for inspection */
+af_status af_resample_taps(uint32_t input_rate, uint32_t output_rate,
+                           float* taps, size_t cap, uint32_t* L, uint32_t* M, uint32_t* T);
+
+/* BatchResampler, resampler.rs:114-167: 128-frame chunker over an
+ * AudioResampler; process() :132 consumes whole chunks and carries the
+ * remainder; flush() :150 zero-pads the carried remainder to one chunk.
+ * Equal rates: the reference's loop does not terminate (chunk_size 0,
+ * :34-39,:138); here it is passthrough (documented deviation). */
+typedef struct af_batch_resampler af_batch_resampler;
+af_status af_batch_resampler_create(uint32_t input_rate, uint32_t output_rate,
+                                    af_batch_resampler** out);     /* :121 */
+void      af_batch_resampler_destroy(af_batch_resampler* r);
+size_t    af_batch_resampler_out_len(const af_batch_resampler* r, size_t n_in);
+size_t    af_batch_resampler_buffered(const af_batch_resampler* r);
+af_status af_batch_resampler_process(af_batch_resampler* r, const float* in, size_t n_in,
+                                     float* out, size_t out_cap, size_t* n_out); /* :132 */
+af_status af_batch_resampler_flush(af_batch_resampler* r, float* out, size_t out_cap,
+                                   size_t* n_out);                 /* :150 */
+
+/* ------------------------------------------------------------------ [B] */
+/* FirFilter (docs/OPS.md "FIR"): causal direct form, y[n] = sum h[k] x[n-k],
+ * same length as the input; the handle carries K-1 samples of history so
+ * consecutive process() calls equal one call on the concatenation. */
+typedef struct af_fir af_fir;
+af_status af_fir_create(const float* taps, size_t n_taps, af_fir** out);
+void      af_fir_destroy(af_fir* f);
+af_status af_fir_process(af_fir* f, const float* in, size_t n, float* out);
+void      af_fir_reset(af_fir* f);
+/* stateless batch: n_clips clips of n samples, zero initial state per clip */
+af_status af_fir_batch(const float* taps, size_t n_taps, const float* in,
+                       size_t n_clips, size_t n, float* out);
+af_status af_fir_batch_device(const float* taps_dev, size_t n_taps, const float* in_dev,
+                              size_t n_clips, size_t n, float* out_dev, void* stream);
+
+/* FeaturePipeline (docs/OPS.md "STFT", "Mel"): interleaved PCM ->
+ * to_mono (capture.rs:30-42 semantics) -> periodic-Hann STFT (n_fft 1024,
+ * center=false) -> |X|^2 -> HTK mel filterbank, fused in one kernel; the
+ * power spectrum never reaches HBM. */
+typedef struct af_features af_features;
+typedef struct {
+    uint32_t sample_rate;    /* Hz, of the PCM handed in */
+    uint32_t channels;       /* 1 or 2 (interleaved) */
+    uint32_t n_fft;          /* 1024 */
+    uint32_t hop;            /* 64..1024, multiple of 4 */
+    uint32_t n_mels;         /* 1..128 */
+    float    f_min;          /* Hz */
+    float    f_max;          /* Hz; 0 => sample_rate/2 */
+    uint32_t sample_format;  /* AF_PCM_F32 or AF_PCM_I16 */
+    int32_t  device;         /* HIP device ordinal, -1 = current */
+} af_features_config;
+void      af_features_default_config(af_features_config* cfg); /* 48 kHz stereo, 1024/256, 80 mels */
+af_status af_features_create(const af_features_config* cfg, af_features** out);
+void      af_features_destroy(af_features* p);
+/* 1 + floor((n_pcm_frames - n_fft)/hop), 0 if shorter than n_fft */
+size_t    af_features_n_frames(const af_features* p, size_t n_pcm_frames);
+/* Describe the batch once (uploads small per-clip tables):
+ * clip c occupies PCM frames [clip_offsets[c], clip_offsets[c+1]) of the
+ * buffer (n_clips+1 monotone offsets, in frames).  Output rows are the
+ * clips' spectrogram frames back to back, [frame][n_mels] f32.
+ * *total_frames_out receives the total number of output frames. */
+af_status af_features_set_batch(af_features* p, const int64_t* clip_offsets,
+                                size_t n_clips, size_t* total_frames_out);
+af_status af_features_set_batch_uniform(af_features* p, size_t n_clips,
+                                        size_t frames_per_clip,
+                                        size_t* total_frames_out);
+/* enqueue the fused kernel on `stream` for the batch set above */
+af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel_dev,
+                                 void* stream);
+/* host buffers: H2D, run, D2H, synchronise */
+af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t mel_cap);
+/* the filterbank the device uses: W[n_mels][n_fft/2+1] f32 */
+af_status af_features_mel_weights(const af_features* p, float* W, size_t cap);
+/* name and launch geometry of the fused kernel, for profiling harnesses */
+const char* af_features_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOFLOW_DSP_H */
