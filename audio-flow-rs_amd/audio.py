@@ -1,0 +1,495 @@
+"""Host-side mirror of the reference's audio module over the C ABI.
+
+Every class keeps the reference's method names and semantics and cites the
+lines it mirrors (paths relative to forfd8960/audio-flow-rs ``src-tauri/src/``).
+numpy arrays stand in for ``Vec<f32>``; failures raise :class:`AudioError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import threading
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .errors import AudioError
+
+
+def library() -> C.CDLL:
+    """The loaded C-ABI library (raises OSError if it has not been built)."""
+    return _ffi.load()
+
+
+def _check(status: int) -> None:
+    if status != _ffi.AF_OK:
+        msg = library().af_last_error().decode("utf-8", "replace")
+        raise AudioError.resampling_failed(msg, status)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def device_count() -> int:
+    return int(library().af_device_count())
+
+
+# --------------------------------------------------------------------------
+# free functions (device kernels behind one call)
+def to_mono(samples, channels: int) -> np.ndarray:
+    """capture.rs:30-42 on the device."""
+    x = _f32(samples)
+    lib = library()
+    if channels <= 0:
+        raise AudioError.resampling_failed("to_mono: channels must be > 0", _ffi.AF_ERR_INVALID_ARG)
+    out = np.empty(lib.af_to_mono_out_len(x.size, channels), np.float32)
+    n = C.c_size_t()
+    _check(lib.af_to_mono(_ptr(x), x.size, channels, _ptr(out), out.size, C.byref(n)))
+    return out[: n.value]
+
+
+def quantize_pcm16(samples) -> np.ndarray:
+    """network/websocket.rs:246-251: f32 -> i16 (clamp, *32767, truncate)."""
+    x = _f32(samples)
+    out = np.empty(x.size, np.int16)
+    _check(library().af_quantize_pcm16(_ptr(x), x.size, _ptr(out)))
+    return out
+
+
+def vad_energy(frames, frame_len: int) -> np.ndarray:
+    """vad.rs:157-168 for consecutive frames of ``frame_len`` samples."""
+    x = _f32(frames)
+    n_frames = x.size // frame_len if frame_len else 0
+    out = np.empty(n_frames, np.float32)
+    _check(library().af_vad_energy(_ptr(x), n_frames, frame_len, _ptr(out)))
+    return out
+
+
+def resample_batch(clips, input_rate: int, output_rate: int) -> np.ndarray:
+    """One-shot polyphase resample of equal-length mono clips ``[n_clips, n_in]``."""
+    x = np.ascontiguousarray(clips, np.float32)
+    if x.ndim == 1:
+        x = x[None, :]
+    lib = library()
+    n_out = lib.af_resample_out_len(input_rate, output_rate, x.shape[1])
+    out = np.empty((x.shape[0], n_out), np.float32)
+    _check(lib.af_resample_batch(input_rate, output_rate, _ptr(x), x.shape[0], x.shape[1],
+                                 _ptr(out), out.size))
+    return out
+
+
+def fir_batch(clips, taps) -> np.ndarray:
+    x = np.ascontiguousarray(clips, np.float32)
+    if x.ndim == 1:
+        x = x[None, :]
+    h = _f32(taps)
+    out = np.empty_like(x)
+    _check(library().af_fir_batch(_ptr(h), h.size, _ptr(x), x.shape[0], x.shape[1], _ptr(out)))
+    return out
+
+
+# --------------------------------------------------------------------------
+@dataclass
+class AudioFrame:
+    """capture.rs:13-28: interleaved f32 PCM in [-1, 1], frame-major."""
+    samples: np.ndarray
+    sample_rate: int
+    channels: int
+    timestamp_ns: int = 0
+
+    def __post_init__(self):
+        self.samples = _f32(self.samples)
+
+    @classmethod
+    def new(cls, samples, sample_rate: int, channels: int, timestamp_ns: int = 0) -> "AudioFrame":
+        return cls(samples, sample_rate, channels, timestamp_ns)          # capture.rs:25
+
+    def to_mono(self) -> "AudioFrame":
+        """capture.rs:30-42."""
+        if self.channels == 1:
+            return AudioFrame(self.samples.copy(), self.sample_rate, 1, self.timestamp_ns)
+        return AudioFrame(to_mono(self.samples, self.channels), self.sample_rate, 1,
+                          self.timestamp_ns)
+
+    def clone(self) -> "AudioFrame":
+        return AudioFrame(self.samples.copy(), self.sample_rate, self.channels, self.timestamp_ns)
+
+
+class RingBuffer:
+    """capture.rs:84-161: mutex-guarded f32 ring with ``capacity - 1`` usable
+    slots.  Pure host bookkeeping (it feeds the device path), restated with the
+    reference's integer arithmetic."""
+
+    def __init__(self, capacity_samples: int):
+        self.capacity = int(capacity_samples)                       # capture.rs:93-100
+        self._buf = np.zeros(self.capacity, np.float32)
+        self._w = 0
+        self._r = 0
+        self._lock = threading.Lock()
+
+    def _used(self) -> int:
+        if self.capacity == 0:
+            return 0
+        return (self._w - self._r + self.capacity) % self.capacity
+
+    def write(self, data) -> int:
+        """capture.rs:103-122"""
+        x = _f32(data)
+        with self._lock:
+            if self.capacity == 0:
+                return 0
+            available = max(self.capacity - self._used(), 0)
+            to_write = min(x.size, max(available - 1, 0))
+            idx = (self._w + np.arange(to_write)) % self.capacity
+            self._buf[idx] = x[:to_write]
+            if to_write > 0:
+                self._w = (self._w + to_write) % self.capacity
+            return to_write
+
+    def read(self, size: int) -> Optional[np.ndarray]:
+        """capture.rs:125-145 (``None`` when empty)"""
+        with self._lock:
+            available = self._used()
+            if available == 0:
+                return None
+            to_read = min(size, available)
+            idx = (self._r + np.arange(to_read)) % self.capacity
+            out = self._buf[idx].copy()
+            self._r = (self._r + to_read) % self.capacity
+            return out
+
+    def available(self) -> int:
+        return self._used()                                          # capture.rs:148-152
+
+    def clear(self) -> None:
+        with self._lock:                                             # capture.rs:155-160
+            self._w = self._r = 0
+            self._buf[:] = 0.0
+
+
+# --------------------------------------------------------------------------
+class AudioResampler:
+    """resampler.rs:23-109.  ``process`` is streaming, like the rubato-backed
+    original: it returns the outputs whose input support has arrived."""
+
+    def __init__(self, input_rate: int, output_rate: int):
+        self._lib = library()
+        h = C.c_void_p()
+        _check(self._lib.af_resampler_create(int(input_rate), int(output_rate), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def new(cls, input_rate: int, output_rate: int) -> "AudioResampler":
+        return cls(input_rate, output_rate)                          # resampler.rs:32
+
+    @classmethod
+    def create_48k_to_16k(cls) -> "AudioResampler":
+        return cls(48000, 16000)                                     # resampler.rs:60
+
+    @classmethod
+    def default(cls) -> "AudioResampler":
+        return cls(48000, 16000)                                     # resampler.rs:169-178
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_resampler_destroy(h)
+
+    def process(self, input) -> np.ndarray:
+        """resampler.rs:71-93"""
+        x = _f32(input)
+        cap = self._lib.af_resampler_out_len(self._h, x.size)
+        out = np.empty(max(cap, 1), np.float32)
+        n = C.c_size_t()
+        _check(self._lib.af_resampler_process(self._h, _ptr(x), x.size, _ptr(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def flush(self) -> np.ndarray:
+        """[B] zero-extend the stream: totals ceil(n_in * L / M) outputs."""
+        cap = self._lib.af_resampler_out_len(self._h, 0)
+        out = np.empty(max(cap, 1), np.float32)
+        n = C.c_size_t()
+        _check(self._lib.af_resampler_flush(self._h, _ptr(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def reset(self) -> None:
+        self._lib.af_resampler_reset(self._h)
+
+    def input_rate(self) -> int:
+        return int(self._lib.af_resampler_input_rate(self._h))       # resampler.rs:96
+
+    def output_rate(self) -> int:
+        return int(self._lib.af_resampler_output_rate(self._h))      # resampler.rs:101
+
+    def needs_resampling(self) -> bool:
+        return bool(self._lib.af_resampler_needs_resampling(self._h))  # resampler.rs:106
+
+
+class BatchResampler:
+    """resampler.rs:114-167: 128-frame chunker with carry and zero-padded flush."""
+
+    def __init__(self, input_rate: int, output_rate: int):
+        self._lib = library()
+        h = C.c_void_p()
+        _check(self._lib.af_batch_resampler_create(int(input_rate), int(output_rate), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def new(cls, input_rate: int, output_rate: int) -> "BatchResampler":
+        return cls(input_rate, output_rate)                          # resampler.rs:121
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_batch_resampler_destroy(h)
+
+    def buffered(self) -> int:
+        return int(self._lib.af_batch_resampler_buffered(self._h))
+
+    def process(self, input) -> np.ndarray:
+        """resampler.rs:132-147"""
+        x = _f32(input)
+        cap = self._lib.af_batch_resampler_out_len(self._h, x.size)
+        out = np.empty(max(cap, 1), np.float32)
+        n = C.c_size_t()
+        _check(self._lib.af_batch_resampler_process(self._h, _ptr(x), x.size, _ptr(out), cap,
+                                                    C.byref(n)))
+        return out[: n.value].copy()
+
+    def flush(self) -> np.ndarray:
+        """resampler.rs:150-166"""
+        cap = self._lib.af_batch_resampler_out_len(self._h, 0)
+        out = np.empty(max(cap, 1), np.float32)
+        n = C.c_size_t()
+        _check(self._lib.af_batch_resampler_flush(self._h, _ptr(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+
+# --------------------------------------------------------------------------
+class VadLevel(enum.Enum):
+    """vad.rs:8-17"""
+    Aggressive = 0
+    Balanced = 1
+    Relaxed = 2
+
+
+class VadState(enum.IntEnum):
+    """vad.rs:46-54"""
+    Silence = 0
+    Speech = 1
+    Ending = 2
+
+
+@dataclass
+class VadConfig:
+    """vad.rs:21-43 (defaults :34-43)"""
+    threshold_db: float = -50.0
+    smoothing_factor: float = 0.3
+    silence_timeout_frames: int = 15
+    min_speech_frames: int = 3
+
+
+class VoiceActivityDetector:
+    """vad.rs:60-205.  Energy on the device, state machine in the library."""
+
+    def __init__(self, config: Optional[VadConfig] = None):
+        self._lib = library()
+        cfg = config or VadConfig()
+        c = _ffi.VadConfig(cfg.threshold_db, cfg.smoothing_factor, cfg.silence_timeout_frames,
+                           cfg.min_speech_frames)
+        h = C.c_void_p()
+        _check(self._lib.af_vad_create(C.byref(c), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def new(cls, config: VadConfig) -> "VoiceActivityDetector":
+        return cls(config)                                            # vad.rs:80
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_vad_destroy(h)
+
+    def detect(self, frame) -> VadState:
+        """vad.rs:97-154"""
+        x = _f32(frame)
+        st = C.c_int()
+        _check(self._lib.af_vad_detect(self._h, _ptr(x), x.size, C.byref(st)))
+        return VadState(st.value)
+
+    def detect_frames(self, samples, frame_len: int) -> List[VadState]:
+        x = _f32(samples)
+        n_frames = x.size // frame_len if frame_len else 0
+        out = np.zeros(max(n_frames, 1), np.int32)
+        _check(self._lib.af_vad_detect_frames(self._h, _ptr(x), n_frames, frame_len, _ptr(out)))
+        return [VadState(int(v)) for v in out[:n_frames]]
+
+    def reset(self) -> None:
+        self._lib.af_vad_reset(self._h)                               # vad.rs:179
+
+    def state(self) -> VadState:
+        return VadState(self._lib.af_vad_state(self._h))              # vad.rs:187
+
+    def energy_db(self) -> float:
+        return float(self._lib.af_vad_energy_db(self._h))             # vad.rs:192
+
+    def is_speaking(self) -> bool:
+        return self.state() == VadState.Speech                        # vad.rs:197
+
+    def speech_frame_count(self) -> int:
+        return int(self._lib.af_vad_speech_frame_count(self._h))      # vad.rs:202
+
+
+# --------------------------------------------------------------------------
+class MessageBuilder:
+    """network/websocket.rs:333-363 (audio part): quantise + base64 on the device."""
+
+    @staticmethod
+    def audio_base64(audio_data) -> str:
+        x = _f32(audio_data)
+        lib = library()
+        cap = lib.af_base64_len(2 * x.size)
+        buf = np.zeros(max(cap, 1), np.uint8)
+        n = C.c_size_t()
+        _check(lib.af_pcm16_base64(_ptr(x), x.size, _ptr(buf), cap, C.byref(n)))
+        return buf[: n.value].tobytes().decode("ascii")
+
+    @staticmethod
+    def audio_message(audio_data) -> str:
+        """websocket.rs:338-352 (serde_json::json! sorts keys alphabetically)."""
+        b64 = MessageBuilder.audio_base64(audio_data)
+        return '{"audio_base_64":"%s","message_type":"input_audio_chunk"}' % b64
+
+    @staticmethod
+    def configure_message(model_id: str, language_code: str) -> str:
+        """websocket.rs:355-362"""
+        import json
+        return json.dumps({"encoding": "pcm_16000", "language_code": language_code,
+                           "message_type": "configure", "model_id": model_id},
+                          separators=(",", ":"))
+
+
+# --------------------------------------------------------------------------
+class FirFilter:
+    """docs/OPS.md "FIR" [B]; streaming like AudioResampler.process."""
+
+    def __init__(self, taps):
+        self._lib = library()
+        h = _f32(taps)
+        p = C.c_void_p()
+        _check(self._lib.af_fir_create(_ptr(h), h.size, C.byref(p)))
+        self._h = p
+        self.n_taps = h.size
+
+    @classmethod
+    def new(cls, taps) -> "FirFilter":
+        return cls(taps)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_fir_destroy(h)
+
+    def process(self, input) -> np.ndarray:
+        x = _f32(input)
+        out = np.empty(x.size, np.float32)
+        _check(self._lib.af_fir_process(self._h, _ptr(x), x.size, _ptr(out)))
+        return out
+
+    def reset(self) -> None:
+        self._lib.af_fir_reset(self._h)
+
+
+@dataclass
+class MelSpectrogram:
+    """One clip's ``[n_frames, n_mels]`` mel power spectrogram."""
+    data: np.ndarray
+    sample_rate: int
+    hop: int
+
+
+class FeaturePipeline:
+    """docs/OPS.md "STFT"/"Mel" [B]: to_mono -> Hann STFT -> |X|^2 -> mel, fused."""
+
+    def __init__(self, sample_rate: int = 48000, channels: int = 2, n_fft: int = 1024,
+                 hop: int = 256, n_mels: int = 80, f_min: float = 0.0, f_max: float = 0.0,
+                 sample_format: int = _ffi.AF_PCM_F32, device: int = -1):
+        self._lib = library()
+        self.cfg = _ffi.FeaturesConfig(sample_rate, channels, n_fft, hop, n_mels, f_min, f_max,
+                                       sample_format, device)
+        h = C.c_void_p()
+        _check(self._lib.af_features_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h
+        self.total_frames = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_features_destroy(h)
+
+    # -- geometry
+    def n_frames(self, n_pcm_frames: int) -> int:
+        return int(self._lib.af_features_n_frames(self._h, n_pcm_frames))
+
+    def mel_weights(self) -> np.ndarray:
+        W = np.empty((self.cfg.n_mels, self.cfg.n_fft // 2 + 1), np.float32)
+        _check(self._lib.af_features_mel_weights(self._h, _ptr(W), W.size))
+        return W
+
+    # -- batch description
+    def set_batch(self, clip_frame_offsets: Sequence[int]) -> int:
+        off = np.ascontiguousarray(clip_frame_offsets, np.int64)
+        tot = C.c_size_t()
+        _check(self._lib.af_features_set_batch(self._h, _ptr(off), off.size - 1, C.byref(tot)))
+        self.total_frames = tot.value
+        return self.total_frames
+
+    def set_batch_uniform(self, n_clips: int, frames_per_clip: int) -> int:
+        tot = C.c_size_t()
+        _check(self._lib.af_features_set_batch_uniform(self._h, n_clips, frames_per_clip,
+                                                       C.byref(tot)))
+        self.total_frames = tot.value
+        return self.total_frames
+
+    # -- execution
+    def run_device(self, pcm_ptr: int, mel_ptr: int, stream: int = 0) -> None:
+        """Enqueue on ``stream`` (a hipStream_t as int); device pointers as ints."""
+        _check(self._lib.af_features_run_device(self._h, C.c_void_p(pcm_ptr), C.c_void_p(mel_ptr),
+                                                C.c_void_p(stream)))
+
+    def run(self, pcm: np.ndarray) -> np.ndarray:
+        """Host buffers: ``pcm`` is the batch's interleaved PCM back to back."""
+        dt = np.int16 if self.cfg.sample_format == _ffi.AF_PCM_I16 else np.float32
+        x = np.ascontiguousarray(pcm, dt).reshape(-1)
+        mel = np.empty((self.total_frames, self.cfg.n_mels), np.float32)
+        _check(self._lib.af_features_run(self._h, _ptr(x), _ptr(mel), mel.size))
+        return mel
+
+    def process_batch(self, frames: Sequence[AudioFrame]) -> List[MelSpectrogram]:
+        """``FeaturePipeline::process_batch(&[AudioFrame]) -> Vec<MelSpectrogram>``."""
+        ch = self.cfg.channels
+        for f in frames:
+            if f.channels != ch or f.sample_rate != self.cfg.sample_rate:
+                raise AudioError.resampling_failed(
+                    f"frame is {f.sample_rate} Hz x{f.channels}, pipeline expects "
+                    f"{self.cfg.sample_rate} Hz x{ch}", _ffi.AF_ERR_INVALID_ARG)
+        offs = np.zeros(len(frames) + 1, np.int64)
+        for i, f in enumerate(frames):
+            offs[i + 1] = offs[i] + f.samples.size // ch
+        self.set_batch(offs)
+        pcm = (np.concatenate([f.samples[: (f.samples.size // ch) * ch] for f in frames])
+               if frames else np.zeros(0, np.float32))
+        mel = self.run(pcm)
+        out, row = [], 0
+        for i in range(len(frames)):
+            nf = self.n_frames(int(offs[i + 1] - offs[i]))
+            out.append(MelSpectrogram(mel[row:row + nf], self.cfg.sample_rate, self.cfg.hop))
+            row += nf
+        return out

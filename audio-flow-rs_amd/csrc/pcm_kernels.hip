@@ -1,0 +1,311 @@
+// pcm_kernels.hip -- the reference's small PCM ops as HBM-bound gfx950 kernels:
+//   to_mono        modules/audio/capture.rs:30-42
+//   PCM16 quantise modules/network/websocket.rs:246-251 (+ :254 base64)
+//   VAD energy     modules/audio/vad.rs:157-168
+// All are pure streaming kernels: 16-byte loads/stores per lane, grid-stride
+// over at most 2048 workgroups, no LDS except the wave reduction of the energy.
+#include <vector>
+
+#include "af_common.hpp"
+
+namespace af {
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(size_t work_items)
+{
+    size_t g = (work_items + kBlock - 1) / kBlock;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---- to_mono ---------------------------------------------------------------
+// stereo fast path: one float4 (two frames) per lane per step
+__global__ void to_mono2_kernel(const float* __restrict__ in, size_t n_pairs /* = n_frames/2 */,
+                                float* __restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        float2 o;
+        o.x = (v.x + v.y) / 2.0f;          // capture.rs:37-38: sum, then / channels
+        o.y = (v.z + v.w) / 2.0f;
+        reinterpret_cast<float2*>(out)[i] = o;
+    }
+}
+
+// general channel count, including the trailing partial frame (`chunks`)
+__global__ void to_mono_kernel(const float* __restrict__ in, size_t n_samples, unsigned channels,
+                               size_t first_frame, size_t n_out, float* __restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t f = first_frame + (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < n_out;
+         f += stride) {
+        const size_t b = f * channels;
+        const size_t e = b + channels < n_samples ? b + channels : n_samples;
+        float sum = 0.0f;
+        for (size_t j = b; j < e; ++j) sum = sum + in[j];   // left fold, f32
+        out[f] = sum / (float)channels;
+    }
+}
+
+// ---- PCM16 quantiser ---------------------------------------------------------
+__device__ __forceinline__ int quant1(float x)
+{
+    // websocket.rs:248: (x.clamp(-1.0, 1.0) * 32767.0) as i16
+    if (x != x) return 0;                   // NaN survives clamp, `as i16` gives 0
+    x = x < -1.0f ? -1.0f : x;
+    x = x > 1.0f ? 1.0f : x;
+    return (int)(x * 32767.0f);             // f32 product, truncation toward zero
+}
+
+__global__ void quantize_kernel(const float* __restrict__ in, size_t n, int16_t* __restrict__ out,
+                                int vec_ok)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = vec_ok ? n / 4 : 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        const unsigned a = (unsigned)quant1(v.x) & 0xffffu, b = (unsigned)quant1(v.y) & 0xffffu;
+        const unsigned c = (unsigned)quant1(v.z) & 0xffffu, d = (unsigned)quant1(v.w) & 0xffffu;
+        uint2 o;
+        o.x = a | (b << 16);                // little-endian, websocket.rs:249
+        o.y = c | (d << 16);
+        reinterpret_cast<uint2*>(out)[i] = o;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (int16_t)quant1(in[i]);
+}
+
+// ---- quantise + base64 ---------------------------------------------------------
+__device__ __forceinline__ unsigned b64c(unsigned v)
+{
+    // RFC 4648 alphabet without a table: A-Z a-z 0-9 + /
+    v &= 63u;
+    return v < 26 ? 'A' + v : v < 52 ? 'a' + (v - 26) : v < 62 ? '0' + (v - 52) : v == 62 ? '+' : '/';
+}
+
+// one lane = 6 samples = 12 bytes -> 16 characters (one 16-byte store)
+__global__ void pcm16_base64_kernel(const float* __restrict__ in, size_t n,
+                                    char* __restrict__ out, int vec_store_ok)
+{
+    const size_t n_groups = (n + 5) / 6;
+    const size_t n_bytes = 2 * n;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
+        unsigned char by[12];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const size_t i = g * 6 + j;
+            const int q = i < n ? quant1(in[i]) : 0;
+            by[2 * j] = (unsigned char)(q & 0xff);
+            by[2 * j + 1] = (unsigned char)((q >> 8) & 0xff);
+        }
+        unsigned char ch[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned v = ((unsigned)by[3 * t] << 16) | ((unsigned)by[3 * t + 1] << 8) | by[3 * t + 2];
+            ch[4 * t] = (unsigned char)b64c(v >> 18);
+            ch[4 * t + 1] = (unsigned char)b64c(v >> 12);
+            ch[4 * t + 2] = (unsigned char)b64c(v >> 6);
+            ch[4 * t + 3] = (unsigned char)b64c(v);
+        }
+        const size_t byte0 = g * 12;
+        if (byte0 + 12 <= n_bytes) {
+            if (vec_store_ok) {
+                uint4 o;
+                o.x = ch[0] | (ch[1] << 8) | (ch[2] << 16) | ((unsigned)ch[3] << 24);
+                o.y = ch[4] | (ch[5] << 8) | (ch[6] << 16) | ((unsigned)ch[7] << 24);
+                o.z = ch[8] | (ch[9] << 8) | (ch[10] << 16) | ((unsigned)ch[11] << 24);
+                o.w = ch[12] | (ch[13] << 8) | (ch[14] << 16) | ((unsigned)ch[15] << 24);
+                reinterpret_cast<uint4*>(out)[g] = o;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) out[g * 16 + t] = (char)ch[t];
+            }
+        } else {
+            // last, partial group: whole 3-byte triples, then '=' padding
+            const size_t rem = n_bytes - byte0;          // 2,4,6,8,10
+            const size_t full = rem / 3, tail = rem % 3;
+            for (size_t t = 0; t < full * 4; ++t) out[g * 16 + t] = (char)ch[t];
+            if (tail) {
+                char* o = out + g * 16 + full * 4;
+                o[0] = (char)ch[full * 4];
+                o[1] = (char)ch[full * 4 + 1];       // low bits already zero (bytes beyond are 0)
+                o[2] = tail == 2 ? (char)ch[full * 4 + 2] : '=';
+                o[3] = '=';
+            }
+        }
+    }
+}
+
+// ---- VAD energy ----------------------------------------------------------------
+// one wave64 per frame: lanes stride the frame, wavefront-shuffle tree sum.
+__global__ void vad_energy_kernel(const float* __restrict__ in, size_t n_frames, size_t frame_len,
+                                  float* __restrict__ energy)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t f = wave; f < n_frames; f += n_waves) {
+        const float* x = in + f * frame_len;
+        float s = 0.0f;
+        for (size_t i = lane; i < frame_len; i += 64) {
+            const float v = x[i];
+            s += v * v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) energy[f] = frame_len ? s / (float)frame_len : 0.0f;   // vad.rs:158,167
+    }
+}
+
+}  // namespace
+}  // namespace af
+
+using namespace af;
+
+extern "C" {
+
+size_t af_to_mono_out_len(size_t n_samples, uint16_t channels)
+{
+    if (channels == 0) return 0;
+    if (channels == 1) return n_samples;
+    return (n_samples + channels - 1) / channels;
+}
+
+af_status af_to_mono_device(const float* in_dev, size_t n_samples, uint16_t channels,
+                            float* out_dev, void* stream)
+{
+    AF_REQUIRE(channels > 0, "to_mono: channels must be > 0");
+    if (n_samples == 0) return AF_OK;
+    AF_REQUIRE(in_dev && out_dev, "to_mono: null buffer");
+    hipStream_t s = as_stream(stream);
+    const size_t n_out = af_to_mono_out_len(n_samples, channels);
+    if (channels == 1) {                                   // capture.rs:31-33
+        AF_HIP(hipMemcpyAsync(out_dev, in_dev, n_samples * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return AF_OK;
+    }
+    size_t done = 0;
+    if (channels == 2 && reinterpret_cast<uintptr_t>(in_dev) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(out_dev) % 8 == 0) {
+        const size_t n_pairs = (n_samples / 2) / 2;        // whole frames, two per lane
+        if (n_pairs) {
+            hipLaunchKernelGGL(to_mono2_kernel, dim3(grid_for(n_pairs)), dim3(kBlock), 0, s, in_dev,
+                               n_pairs, out_dev);
+            done = n_pairs * 2;
+        }
+    }
+    if (done < n_out)
+        hipLaunchKernelGGL(to_mono_kernel, dim3(grid_for(n_out - done)), dim3(kBlock), 0, s, in_dev,
+                           n_samples, (unsigned)channels, done, n_out, out_dev);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+af_status af_to_mono(const float* in, size_t n_samples, uint16_t channels, float* out, size_t out_cap,
+                     size_t* n_out)
+{
+    AF_REQUIRE(channels > 0, "to_mono: channels must be > 0");
+    const size_t no = af_to_mono_out_len(n_samples, channels);
+    if (n_out) *n_out = no;
+    if (out_cap < no) return fail(AF_ERR_BUFFER_TOO_SMALL, "to_mono: need %zu floats", no);
+    if (no == 0) return AF_OK;
+    AF_REQUIRE(in && out, "to_mono: null buffer");
+    AF_TRY(ensure_device(-1));
+    DevBuf din, dout;
+    AF_TRY(din.reserve(n_samples * sizeof(float)));
+    AF_TRY(dout.reserve(no * sizeof(float)));
+    AF_HIP(hipMemcpy(din.p, in, n_samples * sizeof(float), hipMemcpyHostToDevice));
+    AF_TRY(af_to_mono_device(din.as<float>(), n_samples, channels, dout.as<float>(), nullptr));
+    AF_HIP(hipMemcpy(out, dout.p, no * sizeof(float), hipMemcpyDeviceToHost));
+    return AF_OK;
+}
+
+af_status af_quantize_pcm16_device(const float* in_dev, size_t n, int16_t* out_dev, void* stream)
+{
+    if (n == 0) return AF_OK;
+    AF_REQUIRE(in_dev && out_dev, "quantize: null buffer");
+    const int vec_ok = reinterpret_cast<uintptr_t>(in_dev) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(out_dev) % 8 == 0;
+    hipLaunchKernelGGL(quantize_kernel, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, as_stream(stream),
+                       in_dev, n, out_dev, vec_ok);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+af_status af_quantize_pcm16(const float* in, size_t n, int16_t* out)
+{
+    if (n == 0) return AF_OK;
+    AF_REQUIRE(in && out, "quantize: null buffer");
+    AF_TRY(ensure_device(-1));
+    DevBuf din, dout;
+    AF_TRY(din.reserve(n * sizeof(float)));
+    AF_TRY(dout.reserve(n * sizeof(int16_t)));
+    AF_HIP(hipMemcpy(din.p, in, n * sizeof(float), hipMemcpyHostToDevice));
+    AF_TRY(af_quantize_pcm16_device(din.as<float>(), n, dout.as<int16_t>(), nullptr));
+    AF_HIP(hipMemcpy(out, dout.p, n * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return AF_OK;
+}
+
+size_t af_base64_len(size_t n_bytes) { return 4 * ((n_bytes + 2) / 3); }
+
+af_status af_pcm16_base64_device(const float* in_dev, size_t n, char* out_dev, void* stream)
+{
+    if (n == 0) return AF_OK;
+    AF_REQUIRE(in_dev && out_dev, "pcm16_base64: null buffer");
+    const int vec_ok = reinterpret_cast<uintptr_t>(out_dev) % 16 == 0;
+    hipLaunchKernelGGL(pcm16_base64_kernel, dim3(grid_for((n + 5) / 6)), dim3(kBlock), 0,
+                       as_stream(stream), in_dev, n, out_dev, vec_ok);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+af_status af_pcm16_base64(const float* in, size_t n, char* out, size_t out_cap, size_t* n_out)
+{
+    const size_t len = af_base64_len(2 * n);
+    if (n_out) *n_out = len;
+    if (out_cap < len) return fail(AF_ERR_BUFFER_TOO_SMALL, "pcm16_base64: need %zu chars", len);
+    if (n == 0) return AF_OK;
+    AF_REQUIRE(in && out, "pcm16_base64: null buffer");
+    AF_TRY(ensure_device(-1));
+    DevBuf din, dout;
+    AF_TRY(din.reserve(n * sizeof(float)));
+    AF_TRY(dout.reserve(len + 16));
+    AF_HIP(hipMemcpy(din.p, in, n * sizeof(float), hipMemcpyHostToDevice));
+    AF_TRY(af_pcm16_base64_device(din.as<float>(), n, dout.as<char>(), nullptr));
+    AF_HIP(hipMemcpy(out, dout.p, len, hipMemcpyDeviceToHost));
+    return AF_OK;
+}
+
+af_status af_vad_energy_device(const float* in_dev, size_t n_frames, size_t frame_len,
+                               float* energy_dev, void* stream)
+{
+    if (n_frames == 0) return AF_OK;
+    AF_REQUIRE(energy_dev && (in_dev || frame_len == 0), "vad_energy: null buffer");
+    size_t g = (n_frames * 64 + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(vad_energy_kernel, dim3((int)g), dim3(kBlock), 0, as_stream(stream), in_dev,
+                       n_frames, frame_len, energy_dev);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+af_status af_vad_energy(const float* in, size_t n_frames, size_t frame_len, float* energy_out)
+{
+    if (n_frames == 0) return AF_OK;
+    AF_REQUIRE(energy_out && (in || frame_len == 0), "vad_energy: null buffer");
+    AF_TRY(ensure_device(-1));
+    DevBuf din, dout;
+    const size_t n = n_frames * frame_len;
+    AF_TRY(din.reserve(n * sizeof(float)));
+    AF_TRY(dout.reserve(n_frames * sizeof(float)));
+    if (n) AF_HIP(hipMemcpy(din.p, in, n * sizeof(float), hipMemcpyHostToDevice));
+    AF_TRY(af_vad_energy_device(din.as<float>(), n_frames, frame_len, dout.as<float>(), nullptr));
+    AF_HIP(hipMemcpy(energy_out, dout.p, n_frames * sizeof(float), hipMemcpyDeviceToHost));
+    return AF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""Clip sharding across the GPUs of one node (one process per GPU).
+
+Clips are independent end to end (every AudioResampler / VoiceActivityDetector
+in the reference owns its own state: resampler.rs:12-21, vad.rs:60-70), so the
+batch is split into contiguous clip ranges and NO collective sits on the data
+path.  torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
+in the CPU tests) is only used for the barrier, the max-over-ranks time and the
+optional gather of per-rank results.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+
+def shard_range(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced [begin, end) of ``n_items`` for ``rank``: the first
+    ``n_items % world_size`` ranks get one extra item."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad world_size/rank")
+    base, extra = divmod(n_items, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def all_shards(n_items: int, world_size: int) -> List[Tuple[int, int]]:
+    return [shard_range(n_items, world_size, r) for r in range(world_size)]
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """MAX all-reduce of a python float (identity when not distributed)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_rows(local_rows, n_rows_per_rank: List[int]):
+    """All-gather of per-rank ``[n_rows_r, width]`` tensors (ragged first dim) into
+    the full batch order -- the mel gather of SURVEY.md section 8(e).  Pads to the
+    largest shard, one all_gather, then trims."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_rows
+    world = dist.get_world_size()
+    width = local_rows.shape[1]
+    cap = max(n_rows_per_rank)
+    padded = torch.zeros(cap, width, dtype=local_rows.dtype, device=local_rows.device)
+    padded[: local_rows.shape[0]] = local_rows
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded)
+    return torch.cat([b[:n] for b, n in zip(bufs, n_rows_per_rank)], dim=0)

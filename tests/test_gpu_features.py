@@ -1,0 +1,168 @@
+"""GPU parity of the fused STFT+mel path (through the C ABI) against the float64
+oracle and the committed golden vectors.
+
+Tolerance (docs/OPS.md, BASELINE.json north_star "within 1e-5 relative"):
+per spectrogram frame  ||got - ref||_2 / ||ref||_2 <= 1e-5  against float64;
+frame counts and output placement are exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import frame_rel_err, synth_clip
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-5
+
+
+def run_clips(af, clips, ch, sr=48000, hop=256, n_mels=80, fmt=0):
+    pipe = af.FeaturePipeline(sample_rate=sr, channels=ch, hop=hop, n_mels=n_mels, sample_format=fmt)
+    offs = np.zeros(len(clips) + 1, np.int64)
+    for i, c in enumerate(clips):
+        offs[i + 1] = offs[i] + c.size // ch
+    total = pipe.set_batch(offs)
+    dt = np.int16 if fmt else np.float32
+    pcm = np.concatenate(clips) if clips else np.zeros(0, dt)
+    mel = pipe.run(pcm)
+    assert mel.shape == (total, n_mels)
+    return pipe, mel
+
+
+def test_golden_48k_stereo(af):
+    g = np.load(os.path.join(GOLD, "features_48k_stereo.npz"))
+    _, mel = run_clips(af, [g["pcm"]], 2)
+    assert mel.shape == g["mel"].shape
+    assert frame_rel_err(mel, g["mel"]) < TOL
+
+
+def test_golden_16k_mono_config1(af):
+    # BASELINE config 1: 10 s mono 16 kHz -> 622 frames (count exact), values on the fixture part
+    g = np.load(os.path.join(GOLD, "features_16k_mono.npz"))
+    pipe, mel = run_clips(af, [g["pcm"]], 1, sr=16000)
+    assert pipe.n_frames(int(g["n_samples_full"])) == 622
+    assert frame_rel_err(mel, g["mel"]) < TOL
+
+
+@pytest.mark.parametrize("ch", [1, 2])
+@pytest.mark.parametrize("hop", [256, 128, 512, 320, 64, 1024])
+def test_ragged_batch_vs_oracle(af, po, ch, hop):
+    # empty, shorter-than-a-frame, exactly one frame, unit boundaries (16 frames), long
+    lens = [0, 1023, 1024, 1024 + hop * 15, 1024 + hop * 16, 1024 + hop * 16 - 1, 7777, 50000, 3]
+    clips = [synth_clip(i, n, ch, 48000) for i, n in enumerate(lens)]
+    pipe, mel = run_clips(af, clips, ch, hop=hop)
+    row = 0
+    for n, x in zip(lens, clips):
+        ref = po.features(x, ch, 48000.0, hop=hop)
+        nf = po.stft_n_frames(n, 1024, hop)
+        assert ref.shape[0] == nf == pipe.n_frames(n)            # bookkeeping is exact
+        assert frame_rel_err(mel[row:row + nf], ref) < TOL
+        row += nf
+    assert row == mel.shape[0]
+    assert np.all(np.isfinite(mel))
+
+
+def test_unaligned_clip_offsets_take_the_scalar_path(af, po):
+    # odd frame offsets break 16-byte alignment of the clip bases: same results required
+    lens = [3001, 2047, 4099]
+    clips = [synth_clip(20 + i, n, 2, 48000) for i, n in enumerate(lens)]
+    _, mel = run_clips(af, clips, 2)
+    row = 0
+    for x in clips:
+        ref = po.features(x, 2, 48000.0)
+        assert frame_rel_err(mel[row:row + ref.shape[0]], ref) < TOL
+        row += ref.shape[0]
+
+
+@pytest.mark.parametrize("ch", [1, 2])
+def test_i16_input(af, po, ch):
+    x = synth_clip(4, 20000, ch, 48000)
+    xi = np.round(x * 32767.0).astype(np.int16)
+    _, mel = run_clips(af, [xi], ch, fmt=af._ffi.AF_PCM_I16)
+    ref = po.features(xi.astype(np.float32) / np.float32(32768.0), ch, 48000.0)   # docs/OPS.md
+    assert frame_rel_err(mel, ref) < TOL
+
+
+@pytest.mark.parametrize("sr,n_mels", [(16000, 80), (48000, 40), (44100, 128), (48000, 17), (8000, 1)])
+def test_other_filterbanks(af, po, sr, n_mels):
+    x = synth_clip(6, 30000, 1, sr)
+    pipe, mel = run_clips(af, [x], 1, sr=sr, n_mels=n_mels)
+    ref = po.features(x, 1, float(sr), n_mels=n_mels)
+    assert frame_rel_err(mel, ref) < TOL
+    # the device's filterbank is the oracle's, rounded to f32
+    assert np.array_equal(pipe.mel_weights(), po.mel_weights(float(sr), n_mels=n_mels).astype(np.float32))
+
+
+def test_process_batch_surface(af, po):
+    frames = [af.AudioFrame.new(synth_clip(30 + i, n, 2, 48000), 48000, 2, 0)
+              for i, n in enumerate([5000, 1024, 100])]
+    pipe = af.FeaturePipeline()
+    out = pipe.process_batch(frames)
+    assert [m.data.shape[0] for m in out] == [16, 1, 0]
+    for f, m in zip(frames, out):
+        assert frame_rel_err(m.data, po.features(f.samples, 2, 48000.0)) < TOL
+    with pytest.raises(af.AudioError):
+        pipe.process_batch([af.AudioFrame.new(np.zeros(4000, np.float32), 16000, 1, 0)])
+
+
+def test_invalid_configs_are_rejected(af):
+    for kw in [dict(n_fft=512), dict(channels=3), dict(hop=30), dict(hop=258), dict(n_mels=0),
+               dict(n_mels=200), dict(sample_rate=0), dict(f_min=30000.0)]:
+        with pytest.raises(af.AudioError):
+            af.FeaturePipeline(**kw)
+
+
+def test_silence_and_extremes(af, po):
+    z = np.zeros(8000, np.float32)
+    _, mel = run_clips(af, [z], 2)
+    assert np.all(mel == 0.0)
+    full = np.ones(8000, np.float32)            # clipped DC at full scale
+    _, mel = run_clips(af, [full], 2)
+    ref = po.features(full, 2, 48000.0)
+    # a constant signal under a Hann window leaves energy only in bins 0,1: compare absolutely
+    assert np.max(np.abs(mel - ref)) <= 1e-5 * np.max(ref)
+
+
+# ---- full-size properties (BASELINE config 2 shapes) on device-resident data -------------
+def test_full_size_properties(af, po):
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    n_clips, n, ch = 64, 1440000, 2               # 30 s stereo 48 kHz clips, a quarter of config 2
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    pcm = (torch.rand(n_clips, n, ch, device=dev, generator=gen) * 2 - 1) * 0.25
+    t = torch.arange(n, device=dev, dtype=torch.float32) / 48000.0
+    pcm[:, :, 0] += 0.3 * torch.sin(2 * torch.pi * 440.0 * t)
+    pcm[:, :, 1] += 0.2 * torch.sin(2 * torch.pi * 3000.0 * t)
+    pcm[7] = pcm[3]                               # duplicate clips must give identical rows
+    pcm[63] = pcm[0]
+    pipe = af.FeaturePipeline()
+    total = pipe.set_batch_uniform(n_clips, n)
+    nf = pipe.n_frames(n)
+    assert nf == 5622 and total == n_clips * nf    # exact bookkeeping
+    mel = torch.full((total, 80), float("nan"), device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(mel).all())         # every row written
+    m = mel.view(n_clips, nf, 80)
+    # 1. a clip's result does not depend on where it sits in the batch (bit-exact)
+    assert torch.equal(m[7], m[3]) and torch.equal(m[63], m[0])
+    # 2. determinism: a second launch reproduces every bit
+    mel2 = torch.empty_like(mel)
+    pipe.run_device(pcm.data_ptr(), mel2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(mel, mel2)
+    # 3. power-of-two scaling is exact: x*2 -> mel*4
+    pcm2 = pcm[:4] * 2.0
+    pipe4 = af.FeaturePipeline()
+    pipe4.set_batch_uniform(4, n)
+    mel4 = torch.empty(4 * nf, 80, device=dev)
+    pipe4.run_device(pcm2.data_ptr(), mel4.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(mel4.view(4, nf, 80), m[:4] * 4.0)
+    # 4. sampled clips against the float64 oracle
+    for c in (0, 31, 62):
+        ref = po.features(pcm[c].cpu().numpy().reshape(-1), ch, 48000.0)
+        assert frame_rel_err(m[c].cpu().numpy(), ref) < TOL

@@ -1,0 +1,137 @@
+"""GPU parity of the reference's small PCM ops through the C ABI:
+to_mono (capture.rs:30-42), PCM16 quantiser + base64 (websocket.rs:246-254),
+VAD energy + state machine (vad.rs:97-176).  Integer/byte results are bit-exact;
+to_mono is bit-exact (same f32 operations in the same order)."""
+import base64
+
+import numpy as np
+import pytest
+
+from util import synth_clip
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- to_mono -------------------------------------------------------------------------
+def test_to_mono_reference_vectors(af):
+    m = af.AudioFrame.new([0.5, 0.25, -0.5, -0.25], 16000, 2, 1000).to_mono()   # capture.rs:385-400
+    assert m.channels == 1 and m.samples.size == 2
+    assert abs(m.samples[0] - 0.375) < 0.001 and abs(m.samples[1] + 0.375) < 0.001
+    m1 = af.AudioFrame.new([0.5, -0.5], 16000, 1, 1000).to_mono()               # capture.rs:372-382
+    assert np.array_equal(m1.samples, np.array([0.5, -0.5], np.float32))
+
+
+@pytest.mark.parametrize("channels", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 4096, 100003])
+def test_to_mono_bit_exact(af, po, channels, n):
+    x = np.random.default_rng(n + channels).uniform(-1, 1, n).astype(np.float32)
+    got = af.to_mono(x, channels)
+    want = po.to_mono(x, channels)
+    assert got.size == want.size == (n if channels == 1 else -(-n // channels))
+    assert np.array_equal(got, want)
+
+
+def test_to_mono_full_size_round_trip(af, po):
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    dev = torch.device("cuda:0")
+    n_frames = 30 * 48000 * 16                    # 16 clips of config 2
+    x = torch.rand(n_frames, 2, device=dev) * 2 - 1
+    out = torch.empty(n_frames, device=dev)
+    st = af.library().af_to_mono_device(C.c_void_p(x.data_ptr()), x.numel(), 2,
+                                        C.c_void_p(out.data_ptr()), None)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, (x[:, 0] + x[:, 1]) / 2)           # exact: one add, one halving
+    # to_mono of [m, m] interleaved is the identity (idempotence on duplicated channels)
+    dup = torch.stack([out, out], dim=1).contiguous()
+    out2 = torch.empty_like(out)
+    assert af.library().af_to_mono_device(C.c_void_p(dup.data_ptr()), dup.numel(), 2,
+                                          C.c_void_p(out2.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+
+
+# ---- quantiser + base64 ----------------------------------------------------------------
+def test_quantiser_reference_vector_and_edges(af, po):
+    assert af.quantize_pcm16([0.5, -0.5, 0.25, -0.25]).tolist() == [16383, -16383, 8191, -8191]
+    x = np.array([1.0, -1.0, 2.0, -2.0, np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-9, 0.99999,
+                  3.0517578e-05, -3.0517578e-05, 0.1, -0.1], np.float32)
+    assert np.array_equal(af.quantize_pcm16(x), po.quantize_pcm16(x))
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 320, 1001, 250007])
+def test_quantiser_bit_exact(af, po, n):
+    x = (np.random.default_rng(n).standard_normal(n) * 0.6).astype(np.float32)
+    assert np.array_equal(af.quantize_pcm16(x), po.quantize_pcm16(x))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 6, 7, 11, 12, 13, 320, 1000, 99991])
+def test_pcm16_base64_exact(af, po, n):
+    x = (np.random.default_rng(100 + n).standard_normal(n) * 0.5).astype(np.float32)
+    got = af.MessageBuilder.audio_base64(x)
+    want = base64.b64encode(po.quantize_pcm16(x).astype("<i2").tobytes()).decode()
+    assert got == want
+    assert len(got) == af.library().af_base64_len(2 * n)
+
+
+def test_audio_message_envelope(af):
+    import json
+    msg = af.MessageBuilder.audio_message([0.5, -0.5, 0.25, -0.25])              # websocket.rs:376-382
+    assert "audio_base_64" in msg and "input_audio_chunk" in msg
+    d = json.loads(msg)
+    raw = base64.b64decode(d["audio_base_64"])
+    assert np.frombuffer(raw, "<i2").tolist() == [16383, -16383, 8191, -8191]
+
+
+# ---- VAD -------------------------------------------------------------------------------
+def test_energy_reference_vectors(af):
+    assert af.vad_energy(np.zeros(480, np.float32), 480)[0] == 0.0               # vad.rs:288-291
+    assert abs(af.vad_energy(np.full(480, 0.5, np.float32), 480)[0] - 0.25) < 0.0001   # :294-297
+
+
+@pytest.mark.parametrize("frame_len", [1, 63, 64, 160, 480, 1000])
+def test_energy_vs_oracle(af, po, frame_len):
+    x = synth_clip(40, frame_len * 37, 1, 16000)
+    got = af.vad_energy(x, frame_len)
+    want = np.array([po.vad_energy(x[i * frame_len:(i + 1) * frame_len]) for i in range(37)])
+    # the wavefront tree sum reorders a <=1000-term f32 sum of squares: 1e-6 relative
+    assert np.allclose(got, want, rtol=1e-6, atol=0.0)
+
+
+def test_vad_reference_state_tests(af):
+    V, S, C = af.VoiceActivityDetector, af.VadState, af.VadConfig
+    assert V(C(threshold_db=-50.0)).detect(np.full(480, 0.0001, np.float32)) == S.Silence  # vad.rs:211
+    assert V(C(threshold_db=-50.0)).detect(np.full(480, 0.5, np.float32)) == S.Speech     # vad.rs:225
+    v = V(C(threshold_db=-50.0, silence_timeout_frames=2, min_speech_frames=1,
+            smoothing_factor=0.0))                                                       # vad.rs:239-265
+    assert v.state() == S.Silence
+    speech, silence = np.full(480, 0.5, np.float32), np.full(480, 0.0001, np.float32)
+    assert v.detect(speech) == S.Speech
+    assert v.detect(silence) == S.Speech
+    assert v.detect(silence) == S.Ending
+    assert v.detect(silence) == S.Silence
+    v = V(C())                                                                           # vad.rs:267-281
+    v.detect(speech)
+    assert v.is_speaking()
+    v.reset()
+    assert v.state() == S.Silence and not v.is_speaking()
+
+
+def test_vad_state_sequence_vs_oracle(af, po):
+    # a long synthetic utterance: bursts of tone between near-silence, 20 ms frames @ 16 kHz
+    rng = np.random.default_rng(5)
+    frame_len, n_frames = 320, 400
+    x = np.zeros(frame_len * n_frames, np.float32)
+    t = np.arange(frame_len) / 16000.0
+    for f in range(n_frames):
+        amp = 0.3 if (f // 23) % 2 == 0 else 0.0005
+        x[f * frame_len:(f + 1) * frame_len] = amp * np.sin(2 * np.pi * 220 * t) \
+            + 1e-5 * rng.standard_normal(frame_len)
+    v = af.VoiceActivityDetector(af.VadConfig())
+    got = [int(s) for s in v.detect_frames(x, frame_len)]
+    o = po.Vad()
+    want = [o.detect(x[f * frame_len:(f + 1) * frame_len]) for f in range(n_frames)]
+    assert got == want
+    assert {0, 1, 2} <= set(got)                   # the sequence exercises all three states
+    assert v.speech_frame_count() == o.speech_frames

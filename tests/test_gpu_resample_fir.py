@@ -1,0 +1,183 @@
+"""GPU parity of the polyphase resampler and FIR (docs/OPS.md, [B]) and of the
+reference's resampler bookkeeping (resampler.rs:32-167) through the C ABI.
+Values: ||y - ref||_2 / ||ref||_2 <= 1e-5 against float64; lengths, chunk counts
+and streaming-vs-one-shot equality are exact."""
+import os
+
+import numpy as np
+import pytest
+
+from util import rel_err, synth_clip
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("name", ["resample_44k1_16k", "resample_48k_16k", "resample_16k_48k"])
+def test_resample_golden(af, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    y = af.resample_batch(g["x"], int(g["in_hz"]), int(g["out_hz"]))[0]
+    assert y.size == g["y"].size
+    assert rel_err(y, g["y"]) < TOL
+
+
+@pytest.mark.parametrize("fi,fo", [(44100, 16000), (48000, 16000), (16000, 48000), (48000, 44100),
+                                   (8000, 16000), (22050, 16000)])
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 1000, 20011])
+def test_resample_batch_vs_oracle(af, po, fi, fo, n):
+    clips = np.stack([synth_clip(50 + i, n, 1, fi) for i in range(3)])
+    y = af.resample_batch(clips, fi, fo)
+    L, M = po.resample_ratio(fi, fo)
+    assert y.shape == (3, po.resample_out_len(n, L, M))          # ceil(n*L/M), exact
+    for i in range(3):
+        ref = po.resample(clips[i], fi, fo)
+        assert np.linalg.norm(y[i] - ref) <= TOL * max(np.linalg.norm(ref), 1e-30) + 1e-12
+
+
+def test_resample_reference_surface(af):
+    r = af.AudioResampler.new(48000, 16000)                      # resampler.rs:192-198
+    assert r.input_rate() == 48000 and r.output_rate() == 16000 and r.needs_resampling()
+    assert not af.AudioResampler.new(48000, 48000).needs_resampling()   # :200-204
+    p = af.AudioResampler.new(16000, 16000)                      # :184-190 bit-identical passthrough
+    x = np.array([0.1, 0.2, 0.3, 0.4], np.float32)
+    assert np.array_equal(p.process(x), x)
+    d = af.AudioResampler.default()                              # :169-178
+    assert (d.input_rate(), d.output_rate()) == (48000, 16000)
+    assert af.AudioResampler.create_48k_to_16k().needs_resampling()   # :60-62
+
+
+@pytest.mark.parametrize("fi,fo", [(48000, 16000), (44100, 16000), (16000, 48000)])
+def test_streaming_equals_one_shot_bit_exact(af, po, fi, fo):
+    x = synth_clip(60, 10007, 1, fi)
+    one = af.resample_batch(x, fi, fo)[0]
+    r = af.AudioResampler.new(fi, fo)
+    rng = np.random.default_rng(1)
+    parts, pos = [], 0
+    while pos < x.size:
+        n = int(rng.integers(0, 700))
+        parts.append(r.process(x[pos:pos + n]))
+        pos += n
+    parts.append(r.flush())
+    got = np.concatenate(parts)
+    assert got.size == one.size                                   # ceil(n*L/M)
+    assert np.array_equal(got, one)                               # same arithmetic per output index
+    assert rel_err(got, po.resample(x, fi, fo)) < TOL
+
+
+def test_streaming_latency_bookkeeping(af, po):
+    # an output is released once input sample floor(m*M/L) + T/2 has arrived
+    r = af.AudioResampler.new(48000, 16000)
+    x = synth_clip(61, 128 * 5, 1, 48000)
+    total = 0
+    for c in range(5):
+        total += r.process(x[c * 128:(c + 1) * 128]).size
+        n_seen = 128 * (c + 1)
+        assert total == -(-(n_seen - 32) // 3)                    # ceil((n - T/2) * L / M)
+    assert total + r.flush().size == po.resample_out_len(640, 1, 3)
+
+
+def test_batch_resampler_chunking(af, po):
+    # resampler.rs:132-166: whole 128-frame chunks, carry, zero-padded flush
+    b = af.BatchResampler.new(48000, 16000)
+    inner = af.AudioResampler.new(48000, 16000)
+    x = synth_clip(62, 1000, 1, 48000)
+    outs, fed, carry = [], 0, 0
+    for n in (100, 28, 300, 1, 127, 444):
+        seg = x[fed:fed + n]
+        outs.append(b.process(seg))
+        n_chunks, carry = po.chunker_process(carry, n, 128)
+        assert b.buffered() == carry                              # exact carry bookkeeping
+        fed += n
+    assert fed == 1000 and carry == 1000 % 128
+    outs.append(b.flush())
+    assert b.buffered() == 0
+    assert b.flush().size == 0                                    # :153 empty buffer -> nothing
+    got = np.concatenate(outs)
+    # the inner resampler saw 8 chunks: 7 full + the remainder zero-padded to 128
+    padded = np.concatenate([x, np.zeros(8 * 128 - 1000, np.float32)])
+    want = inner.process(padded)
+    assert np.array_equal(got, want)
+    assert got.size == -(-(1024 - 32) // 3)
+
+
+def test_batch_resampler_equal_rates_is_passthrough(af):
+    # the reference never terminates here (chunk_size 0); documented deviation: passthrough
+    b = af.BatchResampler.new(16000, 16000)
+    x = np.arange(10, dtype=np.float32)
+    assert np.array_equal(b.process(x), x)
+    assert b.flush().size == 0
+
+
+def test_resample_full_size_property(af):
+    # BASELINE config 3 shapes (a 64-clip slice): DC gain 1 and linearity at full length
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    dev = torch.device("cuda:0")
+    n_clips, n_in = 64, 441000
+    lib = af.library()
+    n_out = lib.af_resample_out_len(44100, 16000, n_in)
+    assert n_out == 160000
+    a = torch.rand(n_clips, n_in, device=dev) - 0.5
+    b = torch.rand(n_clips, n_in, device=dev) - 0.5
+    ya, yb, yab = (torch.empty(n_clips, n_out, device=dev) for _ in range(3))
+
+    def run(x, y):
+        assert lib.af_resample_batch_device(44100, 16000, C.c_void_p(x.data_ptr()), n_clips, n_in,
+                                            C.c_void_p(y.data_ptr()), None) == 0
+    run(a, ya)
+    run(b, yb)
+    run(a + b, yab)
+    one = torch.ones(n_clips, n_in, device=dev)
+    y1 = torch.empty(n_clips, n_out, device=dev)
+    run(one, y1)
+    torch.cuda.synchronize()
+    assert float((yab - (ya + yb)).abs().max()) < 2e-6            # linearity
+    assert float((y1[:, 64:-64] - 1.0).abs().max()) < 1e-6        # unit DC gain per phase
+    assert bool(torch.isfinite(yab).all())
+
+
+# ---- FIR -----------------------------------------------------------------------------
+def test_fir_golden(af):
+    g = np.load(os.path.join(GOLD, "fir_129.npz"))
+    y = af.fir_batch(g["x"], g["taps"])[0]
+    assert rel_err(y, g["y"]) < TOL
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 64, 129, 1000, 1024])
+@pytest.mark.parametrize("n", [1, 7, 1279, 1280, 1281, 5000])
+def test_fir_batch_vs_oracle(af, po, K, n):
+    rng = np.random.default_rng(K * 7 + n)
+    taps = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
+    clips = np.stack([synth_clip(70 + i, n, 1, 16000) for i in range(2)])
+    y = af.fir_batch(clips, taps)
+    assert y.shape == clips.shape                                 # "same length, causal"
+    for i in range(2):
+        ref = po.fir(clips[i], taps)
+        assert np.linalg.norm(y[i] - ref) <= TOL * max(np.linalg.norm(ref), 1e-30)
+
+
+def test_fir_streaming_equals_one_shot(af, po):
+    taps = np.hamming(129).astype(np.float32) / 70.0
+    x = synth_clip(80, 9000, 1, 16000)
+    one = af.fir_batch(x, taps)[0]
+    f = af.FirFilter.new(taps)
+    rng = np.random.default_rng(2)
+    parts, pos = [], 0
+    while pos < x.size:
+        n = int(rng.integers(1, 900))
+        parts.append(f.process(x[pos:pos + n]))
+        pos += n
+    got = np.concatenate(parts)
+    assert got.size == x.size
+    assert rel_err(got, po.fir(x, taps)) < TOL
+    assert np.max(np.abs(got - one)) <= 1e-6 * np.max(np.abs(one))
+    f.reset()
+    assert rel_err(f.process(x[:500]), po.fir(x[:500], taps)) < TOL
+
+
+def test_fir_rejects_bad_tap_counts(af):
+    with pytest.raises(af.AudioError):
+        af.FirFilter.new(np.zeros(0, np.float32))
+    with pytest.raises(af.AudioError):
+        af.FirFilter.new(np.zeros(1025, np.float32))

@@ -1,0 +1,90 @@
+"""Host-side mirror logic that needs no device: RingBuffer bookkeeping
+(capture.rs:84-161, reference tests capture.rs:426-561), AudioError rendering
+(error.rs:96-111), AudioFrame container, message envelopes."""
+import json
+import threading
+
+import numpy as np
+
+
+def test_ring_buffer_reference_suite(af):
+    r = af.RingBuffer(1024)
+    assert r.capacity == 1024                                   # capture.rs:426-430
+    assert r.write([1.0, 2.0, 3.0]) == 3                        # :432-442
+    assert np.array_equal(r.read(3), [1.0, 2.0, 3.0])
+    r.write([1.0, 2.0, 3.0, 4.0, 5.0])                          # :444-457
+    assert np.array_equal(r.read(2), [1.0, 2.0])
+    assert np.array_equal(r.read(3), [3.0, 4.0, 5.0])
+    assert r.read(100) is None                                  # :487-492
+
+    r = af.RingBuffer(10)                                       # :459-471 wrap-around
+    r.write([1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0])
+    r.read(5)
+    r.write([8.0, 9.0, 10.0])
+    assert np.array_equal(r.read(5), [6.0, 7.0, 8.0, 9.0, 10.0])
+
+    r = af.RingBuffer(10)                                       # :473-485 overflow
+    assert r.write([1.0] * 20) == 9
+    assert np.array_equal(r.read(9), [1.0] * 9)
+
+    r = af.RingBuffer(1024)                                     # :494-514
+    assert r.available() == 0
+    r.write([1.0] * 100)
+    assert r.available() == 100
+    r.read(50)
+    assert r.available() == 50
+    r.clear()
+    assert r.available() == 0
+
+    r = af.RingBuffer(1024)                                     # :546-561
+    t = threading.Thread(target=lambda: r.write([1.0, 2.0, 3.0]))
+    t.start()
+    t.join()
+    assert np.array_equal(r.read(3), [1.0, 2.0, 3.0])
+
+
+def test_ring_buffer_matches_oracle_on_random_traffic(af, po):
+    rng = np.random.default_rng(3)
+    a, b = af.RingBuffer(37), po.Ring(37)
+    for _ in range(400):
+        if rng.random() < 0.55:
+            d = rng.standard_normal(int(rng.integers(0, 30))).astype(np.float32)
+            assert a.write(d) == b.write(d)
+        else:
+            n = int(rng.integers(0, 30))
+            x, y = a.read(n), b.read(n)
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert np.array_equal(x, y)
+        assert a.available() == b.available()
+
+
+def test_audio_error_rendering(af):
+    e = af.AudioError.resampling_failed("boom")
+    assert str(e) == "Resampling failed: boom"                  # error.rs:109
+    assert str(af.AudioError("NoDevice")) == "No input device available"   # error.rs:97
+    assert af.AudioError("CaptureFailed", "x") == af.AudioError("CaptureFailed", "x")
+
+
+def test_audio_frame_container(af):
+    f = af.AudioFrame.new([0.5, -0.5, 0.25], 16000, 1, 1000)    # capture.rs:357-369
+    assert f.samples.size == 3 and f.sample_rate == 16000 and f.channels == 1
+    assert f.timestamp_ns == 1000
+    m = f.to_mono()                                             # capture.rs:371-382 (1 ch: clone)
+    assert m.channels == 1 and np.array_equal(m.samples, f.samples)
+    c = f.clone()                                               # capture.rs:536-544
+    assert np.array_equal(c.samples, f.samples) and c is not f
+
+
+def test_configure_message(af):
+    msg = af.MessageBuilder.configure_message("model_id", "en")   # websocket.rs:384-390
+    d = json.loads(msg)
+    assert d == {"model_id": "model_id", "language_code": "en", "encoding": "pcm_16000",
+                 "message_type": "configure"}
+
+
+def test_vad_config_defaults(af):
+    c = af.VadConfig()                                          # vad.rs:34-43
+    assert (c.threshold_db, c.smoothing_factor, c.silence_timeout_frames, c.min_speech_frames) \
+        == (-50.0, 0.3, 15, 3)
+    assert af.VadState.Silence == 0 and af.VadState.Speech == 1 and af.VadState.Ending == 2

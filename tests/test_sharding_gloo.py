@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world_size-2 gloo processes shard a clip batch the way
+bench.py does (contiguous clip ranges, no data-path collective), then use the
+only collectives the job has: barrier, MAX of the step time, SUM of units and
+the optional mel-row gather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_is_a_balanced_partition(af):
+    from audio_flow_rs_amd.shard import all_shards, shard_range
+    for n in (0, 1, 7, 256, 1000, 8192):
+        for w in (1, 2, 3, 4, 8):
+            sh = all_shards(n, w)
+            assert sh[0][0] == 0 and sh[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+            sizes = [e - b for b, e in sh]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(8192, 8, 3) == (3072, 4096)              # BASELINE config 4: 1024 / GPU
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _worker(rank, world, port, n_clips, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from audio_flow_rs_amd.shard import gather_rows, max_over_ranks, shard_range, sum_over_ranks
+        from oracle import pyoracle as po
+        from util import synth_clip
+        b, e = shard_range(n_clips, world, rank)
+        # each rank computes ITS clips only (the checker stands in for the device here)
+        rows = [po.features(synth_clip(c, 3000, 2, 48000), 2, 48000.0) for c in range(b, e)]
+        local = torch.from_numpy(np.concatenate(rows) if rows else np.zeros((0, 80)))
+        counts = [(shard_range(n_clips, world, r)[1] - shard_range(n_clips, world, r)[0]) * 8
+                  for r in range(world)]
+        dist.barrier()
+        full = gather_rows(local, counts)
+        t = max_over_ranks(1.0 + rank)
+        units = sum_over_ranks(float(local.shape[0]))
+        if rank == 0:
+            q.put((full.numpy(), t, units))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_features_equal_single_process(po):
+    from util import synth_clip
+    n_clips, world = 5, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, t, units = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.concatenate([po.features(synth_clip(c, 3000, 2, 48000), 2, 48000.0)
+                           for c in range(n_clips)])
+    assert full.shape == want.shape == (n_clips * 8, 80)
+    assert np.array_equal(full, want)          # sharding changes nothing, bit for bit
+    assert t == 2.0                            # MAX over ranks of (1 + rank)
+    assert units == n_clips * 8
