@@ -19,7 +19,7 @@ constexpr int kXStride = 33;              // exchange row stride (32 + 1)
 constexpr int kHalfDw = 32 * kXStride;    // exchange region of one half-wave (1056 dwords)
 constexpr int kWbuf = 2 * kHalfDw + 8;    // per-wave LDS buffer (2120 dwords; == 8 mod 32)
 constexpr int kSlotDw = 16 * 17;          // one 16x16 partial tile, rows padded to 17
-constexpr int kMaxSeg = 4;                // K-segments per wave in the mel phase
+constexpr int kMaxSeg = 8;                // K-segments per wave in the mel phase (<= tiles)
 constexpr int kMaxTiles = 8;              // n_mels <= 128
 constexpr int kMaxSlots = kMaxTiles + kWaves - 1;
 
