@@ -18,31 +18,36 @@ constexpr int kProw = 514;                // dwords per power row (513 + 1; == 2
 constexpr int kXStride = 33;              // exchange row stride (32 + 1)
 constexpr int kHalfDw = 32 * kXStride;    // exchange region of one half-wave (1056 dwords)
 constexpr int kWbuf = 2 * kHalfDw + 8;    // per-wave LDS buffer (2120 dwords; == 8 mod 32)
-constexpr int kSlotDw = 16 * 17;          // one 16x16 partial tile, rows padded to 17
-constexpr int kMaxSeg = 8;                // K-segments per wave in the mel phase (<= tiles)
-constexpr int kMaxTiles = 8;              // n_mels <= 128
-constexpr int kMaxSlots = kMaxTiles + kWaves - 1;
+constexpr int kMaxSteps = 64;             // MFMA K-steps (4 bins each) per wave
+constexpr int kWinRow = 36;               // LDS window table row: 32 values + 4 pad
+constexpr int kTwRow = 68;                // LDS twiddle table row: 32 (cos,sin) + 4 pad
 
-// Mel-phase plan: the banded filterbank as a list of 16x16x4 MFMA steps,
-// split into contiguous ranges over the 4 waves (built on the host).
+// Mel-phase plan (built on the host): the filterbank is cut into groups of at
+// most 16 consecutive filters (one MFMA row tile each); a group is multiplied
+// only over the band of bins where it is non-zero, in K-steps of 4 bins.  Whole
+// groups are dealt to the 4 waves so that the busiest wave has as few steps as
+// possible; no group is split, so every wave writes its own mel columns.
+// A wave's steps are laid out in slots of 8 (a group starts on a slot boundary
+// and is padded with zero-weight steps), so the kernel's MFMA sequence is
+// branch-free inside a slot and the "group finished" code exists once per slot.
+constexpr int kSlotSteps = 8;
+constexpr int kMaxSlotsW = kMaxSteps / kSlotSteps;       // slots per wave
 struct Plan {
-    int n_mels, n_tiles, n_slots, n_steps;
-    int wave_nseg[kWaves];
-    int seg_slot[kWaves][kMaxSeg];
-    int seg_bin0[kWaves][kMaxSeg];
-    int seg_step0[kWaves][kMaxSeg];
-    int seg_nsteps[kWaves][kMaxSeg];
-    int tile_slot0[kMaxTiles];
-    int tile_nslots[kMaxTiles];
+    int n_mels, n_groups, n_steps;        // n_steps = real (unpadded) steps over all waves
+    int wave_nslots[kWaves];              // slots used by each wave
+    // per slot: 0 = group continues; else 0x10000 | filters << 8 | first filter
+    // (the group ends with this slot and its accumulator is written out)
+    int slot_end[kWaves][kMaxSlotsW];
 };
 
 struct Params {
     const void* pcm;          // interleaved PCM (f32 or i16)
     float* mel;               // [total_frames][n_mels]
-    const float* wintab;      // [1024] 0.5 * periodic Hann
-    const float2* twtab;      // [32][32] (cos, sin)(2 pi k1 n2 / 1024)
-    const float* wfrag;       // [n_steps][64] MFMA A fragments of the filterbank
-    const Plan* plan;
+    const float* wintab;      // [32][kWinRow]: row n2 holds 0.5 * hann[32 n1 + n2], n1 = 0..31
+    const float* twtab;       // [32][kTwRow]: row n2 holds (cos, sin)(2 pi k1 n2 / 1024), k1 = 0..31
+    const float* wfrag;       // [4][kMaxSteps][64] MFMA A fragments of the filterbank
+    const int* meta;          // [4][kMaxSteps] first bin of every step (0 for padding)
+    Plan plan;                // by value: lives in the kernarg segment -> scalar (SMEM) loads
     const int64_t* pcm_off;   // [n_clips+1] first PCM frame of each clip
     const int64_t* out_off;   // [n_clips+1] first output frame of each clip
     const int64_t* unit_off;  // [n_clips+1] first 16-frame work unit of each clip
@@ -50,12 +55,13 @@ struct Params {
     int n_clips;
     int hop;
     int aligned16;            // every clip base and every staging unit is 16-B aligned
+    unsigned long long* stamps;  // diagnostics only: [4 waves][8] summed phase cycles, or null
 };
 
 // launches the fused kernel; smem_bytes computed by the caller
 af_status launch_features(const Params& p, int channels, bool i16, int grid, size_t smem_bytes,
                           hipStream_t stream);
-size_t features_smem_bytes(int hop, int n_slots);
+size_t features_smem_bytes(int hop);
 
 }  // namespace feat
 }  // namespace af

@@ -1,7 +1,9 @@
 // features_api.hip -- host side of FeaturePipeline (include/audioflow_dsp.h):
 // builds the constant tables (window, twiddles, banded mel plan), the per-batch
 // clip tables, and launches the fused kernel of features_kernel.hip.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -19,9 +21,9 @@ struct af_features {
     Plan plan{};
     DevBuf d_const;                  // wintab | twtab | wfrag | plan
     const float* d_wintab = nullptr;
-    const float2* d_twtab = nullptr;
+    const float* d_twtab = nullptr;
     const float* d_wfrag = nullptr;
-    const Plan* d_plan = nullptr;
+    const int* d_meta = nullptr;
     // batch description
     DevBuf d_tables;                 // pcm_off | out_off | unit_off, (n_clips+1) each
     size_t n_clips = 0;
@@ -31,6 +33,7 @@ struct af_features {
     bool offsets_aligned = false;
     // staging for the host-buffer entry point
     DevBuf d_pcm, d_mel;
+    DevBuf d_stamps;                 // diagnostics: per-phase cycle sums (af_features_debug_stamps)
 };
 
 namespace {
@@ -60,81 +63,101 @@ void build_mel(const af_features_config& c, double f_max, std::vector<float>& W)
     }
 }
 
-// Turn W into MFMA A fragments: per 16-filter tile only the band of bins with
-// a non-zero weight, in K-steps of 4 bins, split contiguously over 4 waves.
+// Turn W into MFMA A fragments.  Filters are handled in units of 4 (one float4
+// of output per lane); a group is 1..4 consecutive units = one 16-row MFMA tile
+// whose K range is the band of bins where any of its filters is non-zero.
+// Dynamic programming picks the groups and deals them, in order, to the 4
+// waves so that the largest per-wave step count is minimal (ties: fewest
+// steps in total).
 af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
-                     std::vector<float>& wfrag)
+                     std::vector<float>& wfrag, std::vector<int>& meta)
 {
     std::memset(&plan, 0, sizeof(plan));
-    const int n_tiles = (n_mels + 15) / 16;
-    if (n_tiles > kMaxTiles) return fail(AF_ERR_UNSUPPORTED, "n_mels %d > %d", n_mels, 16 * kMaxTiles);
     plan.n_mels = n_mels;
-    plan.n_tiles = n_tiles;
-
-    std::vector<int> t_bin0(n_tiles), t_steps(n_tiles), t_step0(n_tiles);
-    int total = 0;
-    for (int t = 0; t < n_tiles; ++t) {
-        int lo = kBins, hi = -1;
-        for (int i = 0; i < 16; ++i) {
-            const int m = 16 * t + i;
-            if (m >= n_mels) break;
-            for (int k = 0; k < kBins; ++k)
-                if (W[(size_t)m * kBins + k] != 0.0f) {
-                    if (k < lo) lo = k;
-                    if (k > hi) hi = k;
-                }
-        }
-        if (hi < lo) { lo = 0; hi = 0; }           // all-zero tile: one harmless step
-        int steps = (hi - lo + 1 + 3) / 4;
-        int bin0 = lo;
-        if (bin0 + 4 * steps > kBins) bin0 = kBins - 4 * steps;  // never read past bin 512
-        if (bin0 < 0) return fail(AF_ERR_UNSUPPORTED, "mel tile wider than the spectrum");
-        t_bin0[t] = bin0;
-        t_steps[t] = steps;
-        t_step0[t] = total;
-        total += steps;
-    }
-    plan.n_steps = total;
-    wfrag.assign((size_t)total * 64, 0.0f);
-    for (int t = 0; t < n_tiles; ++t)
-        for (int s = 0; s < t_steps[t]; ++s)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int m = 16 * t + (lane & 15);
-                const int k = t_bin0[t] + 4 * s + (lane >> 4);
-                wfrag[(size_t)(t_step0[t] + s) * 64 + lane] =
-                    (m < n_mels) ? W[(size_t)m * kBins + k] : 0.0f;
+    const int U = (n_mels + 3) / 4;                      // units of 4 filters
+    // band of each filter
+    std::vector<int> lo(n_mels, kBins), hi(n_mels, -1);
+    for (int m = 0; m < n_mels; ++m)
+        for (int k = 0; k < kBins; ++k)
+            if (W[(size_t)m * kBins + k] != 0.0f) {
+                if (k < lo[m]) lo[m] = k;
+                hi[m] = k;
             }
-
-    // contiguous split of the step list over the waves
-    int slot = 0;
-    int tile = 0, used_in_tile = 0;
-    for (int t = 0; t < n_tiles; ++t) { plan.tile_slot0[t] = -1; plan.tile_nslots[t] = 0; }
-    int remaining = total;
-    for (int w = 0; w < kWaves; ++w) {
-        int quota = (remaining + (kWaves - w) - 1) / (kWaves - w);
-        remaining -= quota;
-        int g = 0;
-        while (quota > 0 && tile < n_tiles) {
-            const int avail = t_steps[tile] - used_in_tile;
-            const int take = avail < quota ? avail : quota;
-            if (g >= kMaxSeg || slot >= kMaxSlots)
-                return fail(AF_ERR_UNSUPPORTED, "mel plan needs more than %d segments per wave",
-                            kMaxSeg);
-            plan.seg_slot[w][g] = slot;
-            plan.seg_bin0[w][g] = t_bin0[tile] + 4 * used_in_tile;
-            plan.seg_step0[w][g] = t_step0[tile] + used_in_tile;
-            plan.seg_nsteps[w][g] = take;
-            if (plan.tile_slot0[tile] < 0) plan.tile_slot0[tile] = slot;
-            plan.tile_nslots[tile] += 1;
-            ++slot;
-            ++g;
-            used_in_tile += take;
-            quota -= take;
-            if (used_in_tile == t_steps[tile]) { ++tile; used_in_tile = 0; }
+    auto band = [&](int u0, int u1, int& b0, int& steps) {  // units [u0, u1)
+        int l = kBins, h = -1;
+        for (int m = 4 * u0; m < 4 * u1 && m < n_mels; ++m)
+            if (hi[m] >= 0) { l = std::min(l, lo[m]); h = std::max(h, hi[m]); }
+        if (h < l) { l = 0; h = 0; }                        // all-zero group: one harmless step
+        steps = (h - l + 1 + 3) / 4;
+        b0 = l;
+        if (b0 + 4 * steps > kBins) b0 = kBins - 4 * steps; // never read past bin 512
+    };
+    const int INF = 1 << 28;
+    // g[i][j]: fewest steps covering units [i, j) with groups of <= 4 units
+    std::vector<std::vector<int>> g(U + 1, std::vector<int>(U + 1, INF)), gcut = g;
+    for (int i = 0; i <= U; ++i) g[i][i] = 0;
+    for (int len = 1; len <= U; ++len)
+        for (int i = 0; i + len <= U; ++i) {
+            const int j = i + len;
+            for (int k = std::max(i, j - 4); k < j; ++k) {  // last group = units [k, j)
+                int b0, st;
+                band(k, j, b0, st);
+                st = (st + kSlotSteps - 1) / kSlotSteps * kSlotSteps;   // groups occupy whole slots
+                if (g[i][k] + st < g[i][j]) { g[i][j] = g[i][k] + st; gcut[i][j] = k; }
+            }
         }
-        plan.wave_nseg[w] = g;
+    // f[w][j]: (max wave load, total) for the first w waves covering units [0, j)
+    struct Cost { int mx, tot; };
+    auto better = [](const Cost& a, const Cost& b) { return a.mx < b.mx || (a.mx == b.mx && a.tot < b.tot); };
+    std::vector<std::vector<Cost>> f(kWaves + 1, std::vector<Cost>(U + 1, Cost{INF, INF}));
+    std::vector<std::vector<int>> fcut(kWaves + 1, std::vector<int>(U + 1, 0));
+    f[0][0] = Cost{0, 0};
+    for (int w = 1; w <= kWaves; ++w)
+        for (int j = 0; j <= U; ++j)
+            for (int i = 0; i <= j; ++i) {
+                if (f[w - 1][i].mx >= INF) continue;
+                const Cost c{std::max(f[w - 1][i].mx, g[i][j]), f[w - 1][i].tot + g[i][j]};
+                if (better(c, f[w][j])) { f[w][j] = c; fcut[w][j] = i; }
+            }
+    if (f[kWaves][U].mx > kMaxSteps)
+        return fail(AF_ERR_UNSUPPORTED, "mel plan needs %d K-steps on one wave (limit %d)",
+                    f[kWaves][U].mx, kMaxSteps);
+    int wave_lo[kWaves + 1];
+    wave_lo[kWaves] = U;
+    for (int w = kWaves; w >= 1; --w) wave_lo[w - 1] = fcut[w][wave_lo[w]];
+
+    wfrag.assign((size_t)kWaves * kMaxSteps * 64, 0.0f);
+    meta.assign((size_t)kWaves * kMaxSteps, 0);
+    for (int w = 0; w < kWaves; ++w) {
+        // groups of this wave, recovered from gcut
+        std::vector<std::pair<int, int>> groups;
+        for (int j = wave_lo[w + 1]; j > wave_lo[w];) {
+            const int k = gcut[wave_lo[w]][j];
+            groups.push_back({k, j});
+            j = k;
+        }
+        int s = 0;
+        for (auto it = groups.rbegin(); it != groups.rend(); ++it) {
+            int b0, st;
+            band(it->first, it->second, b0, st);
+            const int m0 = 4 * it->first;
+            const int cnt = std::min(4 * it->second, n_mels) - m0;
+            for (int i = 0; i < st; ++i, ++s) {
+                const int bin = b0 + 4 * i;
+                meta[(size_t)w * kMaxSteps + s] = bin;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 15, k = bin + (lane >> 4);
+                    wfrag[((size_t)w * kMaxSteps + s) * 64 + lane] =
+                        (r < cnt) ? W[(size_t)(m0 + r) * kBins + k] : 0.0f;
+                }
+            }
+            plan.n_steps += st;
+            s = (s + kSlotSteps - 1) / kSlotSteps * kSlotSteps;   // pad the group to a slot boundary
+            plan.slot_end[w][s / kSlotSteps - 1] = 0x10000 | (cnt << 8) | m0;
+            plan.n_groups += 1;
+        }
+        plan.wave_nslots[w] = s / kSlotSteps;
     }
-    plan.n_slots = slot;
     return AF_OK;
 }
 
@@ -199,8 +222,8 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
                cfg->channels);
     AF_REQUIRE(cfg->hop >= 64 && cfg->hop <= 1024 && cfg->hop % 4 == 0,
                "hop must be a multiple of 4 in [64, 1024] (got %u)", cfg->hop);
-    AF_REQUIRE(cfg->n_mels >= 1 && cfg->n_mels <= 16u * kMaxTiles, "n_mels must be in [1, %d]",
-               16 * kMaxTiles);
+    AF_REQUIRE(cfg->n_mels >= 1 && cfg->n_mels <= 128u, "n_mels must be in [1, %d]",
+               128);
     AF_REQUIRE(cfg->sample_rate > 0, "sample_rate must be positive");
     AF_REQUIRE(cfg->sample_format == AF_PCM_F32 || cfg->sample_format == AF_PCM_I16,
                "unknown sample_format %u", cfg->sample_format);
@@ -217,40 +240,45 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
 
     build_mel(*cfg, f_max, p->W);
     std::vector<float> wfrag;
-    af_status st = build_plan(p->W, (int)cfg->n_mels, p->plan, wfrag);
+    std::vector<int> meta;
+    af_status st = build_plan(p->W, (int)cfg->n_mels, p->plan, wfrag, meta);
     if (st != AF_OK) { delete p; return st; }
 
-    // constant block: wintab[1024] | twtab[32*32] float2 | wfrag | plan
-    std::vector<float> wintab(kNfft);
-    for (int i = 0; i < kNfft; ++i) {
-        const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)kNfft);
-        wintab[i] = 0.5f * (float)w;   // the 1/2 of the two-real-signals split, exact
-    }
-    std::vector<float> twtab(2 * 32 * 32);
-    for (int k1 = 0; k1 < 32; ++k1)
-        for (int n2 = 0; n2 < 32; ++n2) {
+    // constant block: wintab [32][kWinRow] | twtab [32][kTwRow] | wfrag | meta
+    // (the two tables are copied verbatim into LDS by every workgroup; rows are
+    // padded so that 16 lanes reading 16 rows with ds_read_b128 hit 16 bank groups)
+    std::vector<float> wintab(32 * kWinRow, 0.0f);
+    for (int n2 = 0; n2 < 32; ++n2)
+        for (int n1 = 0; n1 < 32; ++n1) {
+            const int i = 32 * n1 + n2;
+            const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)kNfft);
+            wintab[n2 * kWinRow + n1] = 0.5f * (float)w;   // the 1/2 of the two-real-signals split, exact
+        }
+    std::vector<float> twtab(32 * kTwRow, 0.0f);
+    for (int n2 = 0; n2 < 32; ++n2)
+        for (int k1 = 0; k1 < 32; ++k1) {
             const double a = 2.0 * kPi * (double)(k1 * n2) / (double)kNfft;
-            twtab[2 * (k1 * 32 + n2)] = (float)std::cos(a);
-            twtab[2 * (k1 * 32 + n2) + 1] = (float)std::sin(a);
+            twtab[n2 * kTwRow + 2 * k1] = (float)std::cos(a);
+            twtab[n2 * kTwRow + 2 * k1 + 1] = (float)std::sin(a);
         }
     const size_t off_tw = wintab.size() * sizeof(float);
     const size_t off_wf = off_tw + twtab.size() * sizeof(float);
-    const size_t off_plan = (off_wf + wfrag.size() * sizeof(float) + 15) & ~(size_t)15;
-    const size_t total = off_plan + sizeof(Plan);
+    const size_t off_meta = (off_wf + wfrag.size() * sizeof(float) + 15) & ~(size_t)15;
+    const size_t total = off_meta + meta.size() * sizeof(int);
     std::vector<char> blob(total, 0);
     std::memcpy(blob.data(), wintab.data(), off_tw);
     std::memcpy(blob.data() + off_tw, twtab.data(), twtab.size() * sizeof(float));
     std::memcpy(blob.data() + off_wf, wfrag.data(), wfrag.size() * sizeof(float));
-    std::memcpy(blob.data() + off_plan, &p->plan, sizeof(Plan));
+    std::memcpy(blob.data() + off_meta, meta.data(), meta.size() * sizeof(int));
     st = p->d_const.reserve(total);
     if (st == AF_OK && hipMemcpy(p->d_const.p, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess)
         st = fail(AF_ERR_HIP, "uploading feature tables failed");
     if (st != AF_OK) { delete p; return st; }
     char* base = p->d_const.as<char>();
     p->d_wintab = reinterpret_cast<const float*>(base);
-    p->d_twtab = reinterpret_cast<const float2*>(base + off_tw);
+    p->d_twtab = reinterpret_cast<const float*>(base + off_tw);
     p->d_wfrag = reinterpret_cast<const float*>(base + off_wf);
-    p->d_plan = reinterpret_cast<const Plan*>(base + off_plan);
+    p->d_meta = reinterpret_cast<const int*>(base + off_meta);
     *out = p;
     return AF_OK;
 }
@@ -301,7 +329,8 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     prm.wintab = p->d_wintab;
     prm.twtab = p->d_twtab;
     prm.wfrag = p->d_wfrag;
-    prm.plan = p->d_plan;
+    prm.plan = p->plan;
+    prm.meta = p->d_meta;
     const int64_t* tab = p->d_tables.as<int64_t>();
     prm.pcm_off = tab;
     prm.out_off = tab + (p->n_clips + 1);
@@ -309,13 +338,18 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     prm.total_units = p->total_units;
     prm.n_clips = (int)p->n_clips;
     prm.hop = (int)p->cfg.hop;
+    prm.stamps = p->d_stamps.as<unsigned long long>();
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
-    const size_t smem = features_smem_bytes(prm.hop, p->plan.n_slots);
+    const size_t smem = features_smem_bytes(prm.hop);
     AF_REQUIRE(smem <= 160 * 1024, "hop %d needs %zu bytes of LDS", prm.hop, smem);
     // persistent grid: as many workgroups as stay resident (LDS-limited, at most 2 per CU)
     int per_cu = (int)((160 * 1024) / smem);
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
+    if (const char* e = std::getenv("AF_FEATURES_WG_PER_CU")) {   // tuning/diagnostics only
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 8) per_cu = v;
+    }
     int64_t grid = (int64_t)p->n_cus * per_cu;
     if (grid > p->total_units) grid = p->total_units;
     return launch_features(prm, (int)p->cfg.channels, p->cfg.sample_format == AF_PCM_I16,
@@ -349,5 +383,23 @@ af_status af_features_mel_weights(const af_features* p, float* W, size_t cap)
 }
 
 const char* af_features_kernel_name(void) { return "af_features_kernel"; }
+
+// Diagnostics: enable == 1 allocates/zeroes the in-kernel phase stamps (subsequent runs
+// record them, slightly slower); out[32] (optional) receives [wave][phase] cycle sums.
+af_status af_features_debug_stamps(af_features* p, int enable, unsigned long long* out)
+{
+    AF_REQUIRE(p, "af_features_debug_stamps: null handle");
+    if (out && p->d_stamps.p) {
+        AF_HIP(hipDeviceSynchronize());
+        AF_HIP(hipMemcpy(out, p->d_stamps.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (enable) {
+        AF_TRY(p->d_stamps.reserve(32 * sizeof(unsigned long long)));
+        AF_HIP(hipMemset(p->d_stamps.p, 0, 32 * sizeof(unsigned long long)));
+    } else {
+        p->d_stamps.release();
+    }
+    return AF_OK;
+}
 
 }  // extern "C"

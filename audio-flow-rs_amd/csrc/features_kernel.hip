@@ -117,54 +117,66 @@ struct Stage {
         return static_cast<const float*>(pcm)[elem];
     }
 
-    // mono samples [pos, pos+MS) of a clip whose first frame is `base` and
-    // which has `n` frames; zero beyond the end of the clip
+    // the 16 raw bytes holding mono samples [pos, pos+MS) of a clip whose first
+    // frame is `base` and which has `n` frames; zero beyond the end of the clip.
+    // No arithmetic here, so a prefetch does not have to wait for its data.
+    __device__ static __forceinline__ uint4 load_raw(const void* pcm, int64_t base, int64_t pos,
+                                                     int64_t n, bool aligned)
+    {
+        if (aligned && pos + MS <= n)
+            return *reinterpret_cast<const uint4*>(static_cast<const char*>(pcm) +
+                                                   (base + pos) * kBytesPerFrame);
+        uint32_t r[4] = {0u, 0u, 0u, 0u};
+        constexpr int E = I16 ? 8 : 4;                 // elements in 16 bytes
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (pos + e / CH < n) {
+                const int64_t idx = (base + pos) * CH + e;
+                if constexpr (I16)
+                    r[e >> 1] |= (uint32_t)static_cast<const uint16_t*>(pcm)[idx] << (16 * (e & 1));
+                else
+                    r[e] = static_cast<const uint32_t*>(pcm)[idx];
+            }
+        }
+        return uint4{r[0], r[1], r[2], r[3]};
+    }
+
+    // raw bytes -> mono samples
+    __device__ static __forceinline__ void convert(const uint4 raw, float (&m)[MS])
+    {
+        const uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
+        if constexpr (!I16) {
+            float f[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(r[i]);
+            if constexpr (CH == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i] = f[i];
+            } else {
+                m[0] = (f[0] + f[1]) * 0.5f;
+                m[1] = (f[2] + f[3]) * 0.5f;
+            }
+        } else {
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f[2 * i] = (float)(int16_t)(r[i] & 0xffffu) * (1.0f / 32768.0f);
+                f[2 * i + 1] = (float)(int16_t)(r[i] >> 16) * (1.0f / 32768.0f);
+            }
+            if constexpr (CH == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) m[i] = f[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i] = (f[2 * i] + f[2 * i + 1]) * 0.5f;
+            }
+        }
+    }
+
     __device__ static __forceinline__ void load(const void* pcm, int64_t base, int64_t pos,
                                                 int64_t n, bool aligned, float (&m)[MS])
     {
-        if (aligned && pos + MS <= n) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(
-                static_cast<const char*>(pcm) + (base + pos) * kBytesPerFrame);
-            const uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
-            if constexpr (!I16) {
-                float f[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(r[i]);
-                if constexpr (CH == 1) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) m[i] = f[i];
-                } else {
-                    m[0] = (f[0] + f[1]) * 0.5f;
-                    m[1] = (f[2] + f[3]) * 0.5f;
-                }
-            } else {
-                float f[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f[2 * i] = (float)(int16_t)(r[i] & 0xffffu) * (1.0f / 32768.0f);
-                    f[2 * i + 1] = (float)(int16_t)(r[i] >> 16) * (1.0f / 32768.0f);
-                }
-                if constexpr (CH == 1) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) m[i] = f[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) m[i] = (f[2 * i] + f[2 * i + 1]) * 0.5f;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MS; ++i) {
-                float v = 0.0f;
-                if (pos + i < n) {
-                    const int64_t e = (base + pos + i) * CH;
-                    float s = sample(pcm, e);
-                    if (CH == 2) s = (s + sample(pcm, e + 1)) * 0.5f;
-                    v = s;
-                }
-                m[i] = v;
-            }
-        }
+        convert(load_raw(pcm, base, pos, n, aligned), m);
     }
 
     __device__ static __forceinline__ void store(float* dst, const float (&m)[MS])
@@ -178,13 +190,21 @@ struct Stage {
 // FFT phase of one wave: 4 frames (two per half-wave) -> 4 power rows in LDS.
 template <int HOP_T>
 __device__ __forceinline__ void fft_phase(const float* __restrict__ tile, float* wbuf, int hop,
-                                          int w, int lane, const float (&win)[32],
-                                          const float (&twc)[32], const float (&tws)[32])
+                                          int w, int lane, const float* __restrict__ wtab,
+                                          const float* __restrict__ ttab)
 {
     const int half = lane >> 5, n2 = lane & 31;
     const int fa = 4 * w + 2 * half;              // first frame of this half's pair
     float re[32], im[32];
     {
+        // window column of this lane: 0.5 * hann[32 n1 + n2], n1 = 0..31 (8 x ds_read_b128)
+        float win[32];
+        const float4* wrow = reinterpret_cast<const float4*>(wtab + n2 * kWinRow);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 v = wrow[j];
+            win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
+        }
         const float* src = tile + fa * hop + n2;
         if constexpr (HOP_T != 0 && HOP_T % 32 == 0) {
             // frame b = frame a shifted by HOP_T samples = SH registers
@@ -208,13 +228,24 @@ __device__ __forceinline__ void fft_phase(const float* __restrict__ tile, float*
 
     fft32(re, im);                                // over n1 -> Y[k1] at brev5(k1)
 
-    // inter-stage twiddle e^{-2 pi i n2 k1 / 1024}
+    // inter-stage twiddle e^{-2 pi i n2 k1 / 1024}; row n2 of the LDS table holds
+    // (cos, sin) for k1 = 0..31, two k1 per ds_read_b128
+    {
+        const float4* trow = reinterpret_cast<const float4*>(ttab + n2 * kTwRow);
 #pragma unroll
-    for (int k1 = 1; k1 < 32; ++k1) {
-        const int r = brev5(k1);
-        const float xr = re[r], xi = im[r];
-        re[r] = xr * twc[k1] + xi * tws[k1];
-        im[r] = xi * twc[k1] - xr * tws[k1];
+        for (int j = 0; j < 16; ++j) {
+            const float4 t = trow[j];
+            if (j > 0) {
+                const int r = brev5(2 * j);
+                const float xr = re[r], xi = im[r];
+                re[r] = xr * t.x + xi * t.y;
+                im[r] = xi * t.x - xr * t.y;
+            }
+            const int r = brev5(2 * j + 1);
+            const float xr = re[r], xi = im[r];
+            re[r] = xr * t.z + xi * t.w;
+            im[r] = xi * t.z - xr * t.w;
+        }
     }
 
     // transpose (k1, n2) through LDS, real parts then imaginary parts
@@ -283,50 +314,98 @@ __device__ __forceinline__ void fft_phase(const float* __restrict__ tile, float*
 }
 
 // ---------------------------------------------------------------------------
-// mel phase: this wave's share of the banded W (A) x P^T (B) MFMA steps.
-__device__ __forceinline__ void mel_phase(const float* wbufs, float* partials,
-                                          const Plan* __restrict__ plan,
-                                          const float* __restrict__ wfrag, int w, int lane)
+// mel phase: this wave's filter groups, banded W (A operand, in registers) times
+// P^T (B operand, bins x 16 frames from LDS) on v_mfma_f32_16x16x4_f32.  All B
+// operands of the unit are fetched up front so the MFMA chain never waits on LDS.
+// Steps come in slots of 8 (branch-free); when a slot ends a group, the 16 frames
+// x <=16 filters accumulator goes straight to HBM: lane (frame j, quarter kq)
+// owns filters 4kq..4kq+3 of the group = one 16-byte store.
+template <bool STAMPS>
+__device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restrict__ lmeta,
+                                          const float (&wf)[kMaxSteps], int n_slots,
+                                          const int (&slot_end)[kMaxSlotsW],
+                                          float* __restrict__ orow, bool fvalid, bool vec_ok,
+                                          int lane, unsigned long long (&acc_t)[8],
+                                          unsigned long long& t_prev)
 {
     const int f = lane & 15, kq = lane >> 4;
     const float* pbase = wbufs + (f >> 2) * kWbuf + (f & 3) * kProw + kq;
-    const int nseg = plan->wave_nseg[w];
-    for (int g = 0; g < nseg; ++g) {
-        const int slot = plan->seg_slot[w][g];
-        const int bin0 = plan->seg_bin0[w][g];
-        const int step0 = plan->seg_step0[w][g];
-        const int ns = plan->seg_nsteps[w][g];
-        const float* pw = wfrag + (size_t)step0 * 64 + lane;
-        const float* pp = pbase + bin0;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 2 <= ns; s += 2) {
-            const float a0 = pw[s * 64], a1 = pw[s * 64 + 64];
-            const float b0 = pp[4 * s], b1 = pp[4 * s + 4];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+    float b[kMaxSteps];
+#pragma unroll
+    for (int q = 0; q < kMaxSlotsW; ++q) {
+        if (q < n_slots) {                        // wave-uniform: skip unused slots
+            int meta[kSlotSteps];
+#pragma unroll
+            for (int s = 0; s < kSlotSteps; ++s) meta[s] = lmeta[q * kSlotSteps + s];   // broadcast
+#pragma unroll
+            for (int s = 0; s < kSlotSteps; ++s) b[q * kSlotSteps + s] = pbase[meta[s]];
+        } else {
+#pragma unroll
+            for (int s = 0; s < kSlotSteps; ++s) b[q * kSlotSteps + s] = 0.0f;
         }
-        if (s < ns)
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[s * 64], pp[4 * s], acc0, 0, 0, 0);
-        acc0 += acc1;
-        // D[i = mel row 4*kq + r][j = frame f]  ->  slot[j][i]
-        float* ps = partials + slot * kSlotDw + f * 17 + 4 * kq;
-        ps[0] = acc0[0];
-        ps[1] = acc0[1];
-        ps[2] = acc0[2];
-        ps[3] = acc0[3];
+    }
+    if constexpr (STAMPS) {                       // diagnostics: operands landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        acc_t[5] += t - t_prev;
+        t_prev = t;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < kMaxSlotsW; ++q) {
+        if (q < n_slots) {
+#pragma unroll
+            for (int s = q * kSlotSteps; s < (q + 1) * kSlotSteps; s += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], b[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s + 1], b[s + 1], acc1, 0, 0, 0);
+            }
+            const int e = slot_end[q];            // wave-uniform (kernarg)
+            if (e != 0) {
+                const f32x4 r = acc0 + acc1;
+                acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int m0 = e & 255, cnt = (e >> 8) & 31;
+                const int i0 = 4 * kq;            // first filter of this lane in the group
+                float* o = orow + m0 + i0;
+                if (vec_ok && (cnt & 3) == 0) {   // wave-uniform choice
+                    if (fvalid && i0 < cnt)
+                        *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
+                } else if (fvalid) {
+                    if (i0 < cnt) o[0] = r[0];
+                    if (i0 + 1 < cnt) o[1] = r[1];
+                    if (i0 + 2 < cnt) o[2] = r[2];
+                    if (i0 + 3 < cnt) o[3] = r[3];
+                }
+            }
+        }
     }
 }
 
+// Diagnostics (Params::stamps != null only): per-phase cycle sums of every wave.
+#define AF_STAMP(i)                                                         \
+    do {                                                                    \
+        if constexpr (STAMPS) {                                             \
+            __builtin_amdgcn_sched_barrier(0);                              \
+            const unsigned long long _t = __builtin_amdgcn_s_memtime();     \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+            acc_t[i] += _t - t_prev;                                        \
+            t_prev = _t;                                                    \
+            __builtin_amdgcn_sched_barrier(0);                              \
+        }                                                                   \
+    } while (0)
+
 // ---------------------------------------------------------------------------
-template <int HOP_T, int CH, bool I16>
+template <int HOP_T, int CH, bool I16, bool STAMPS>
 __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p)
 {
     using St = Stage<CH, I16>;
     constexpr int MS = St::MS;
     // prefetch units per thread and iteration (compile-time only for HOP_T != 0)
     constexpr int PFU = HOP_T ? (16 * HOP_T / MS + kThreads - 1) / kThreads : 1;
-    constexpr bool kPrefetch = HOP_T != 0 && PFU * MS <= 32;
+    constexpr bool kPrefetch = HOP_T != 0 && PFU <= 8;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int hop = HOP_T ? HOP_T : p.hop;
@@ -335,11 +414,12 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
     const int tail_len = kNfft - hop;             // samples shared with the next unit
     float* tile = smem;
     float* wbufs = smem + tile_alloc;
-    float* partials = wbufs + kWaves * kWbuf;
+    float* wtab = wbufs + kWaves * kWbuf;                     // [32][kWinRow]
+    float* ttab = wtab + 32 * kWinRow;                        // [32][kTwRow]
+    int* lmeta = reinterpret_cast<int*>(ttab + 32 * kTwRow);  // [4][kMaxSteps]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n2 = lane & 31;
     const bool aligned = p.aligned16 != 0;
 
     // work range of this workgroup, in 16-frame units
@@ -348,18 +428,20 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
     const int64_t u_end = p.total_units * (b + 1) / G;
     if (u >= u_end) return;
 
-    // per-lane constants: window column and inter-stage twiddles
-    float win[32], twc[32], tws[32];
+    // window and twiddle tables -> LDS (made visible by the first barrier below)
+    for (int i = tid; i < 32 * kWinRow / 4; i += kThreads)
+        reinterpret_cast<float4*>(wtab)[i] = reinterpret_cast<const float4*>(p.wintab)[i];
+    for (int i = tid; i < 32 * kTwRow / 4; i += kThreads)
+        reinterpret_cast<float4*>(ttab)[i] = reinterpret_cast<const float4*>(p.twtab)[i];
+    for (int i = tid; i < kWaves * kMaxSteps; i += kThreads) lmeta[i] = p.meta[i];
+    // this wave's share of the mel plan
+    const float* __restrict__ wfrag_w = p.wfrag + ((size_t)w * kMaxSteps) * 64 + lane;
+    const int n_slots_w = p.plan.wave_nslots[w];
+    int slot_end_w[kMaxSlotsW];
 #pragma unroll
-    for (int n1 = 0; n1 < 32; ++n1) win[n1] = p.wintab[32 * n1 + n2];
-    twc[0] = 1.0f;
-    tws[0] = 0.0f;
-#pragma unroll
-    for (int k1 = 1; k1 < 32; ++k1) {
-        const float2 t = p.twtab[k1 * 32 + n2];
-        twc[k1] = t.x;
-        tws[k1] = t.y;
-    }
+    for (int q = 0; q < kMaxSlotsW; ++q) slot_end_w[q] = p.plan.slot_end[w][q];
+    const int n_mels = p.plan.n_mels;
+    const bool vec_ok = (n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(p.mel) % 16 == 0);
 
     // clip containing unit u: largest c with unit_off[c] <= u
     int c;
@@ -371,8 +453,10 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         }
         c = lo;
     }
-    const int n_mels = p.plan->n_mels;
     bool fresh = true;
+
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memtime() : 0;
 
     while (u < u_end) {
         while (p.unit_off[c + 1] <= u) ++c;       // skip clips without frames
@@ -393,10 +477,11 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
             }
         }
         __syncthreads();                          // B1: tile ready
+        AF_STAMP(0);
 
         const bool has_next = (u + 1 < u_end) && (u + 1 < c_u1);
         const int64_t next_pos0 = (F0 + kFramesPerIter) * hop + tail_len;  // first new sample
-        float pf[PFU][MS];
+        uint4 pf[PFU];
         float tailr[4];
         if (has_next) {
             if constexpr (kPrefetch) {
@@ -404,7 +489,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
                 for (int i = 0; i < PFU; ++i) {
                     const int v = tid + i * kThreads;
                     if (v * MS < 16 * hop)
-                        St::load(p.pcm, c_pcm0, next_pos0 + (int64_t)v * MS, c_n, aligned, pf[i]);
+                        pf[i] = St::load_raw(p.pcm, c_pcm0, next_pos0 + (int64_t)v * MS, c_n, aligned);
                 }
             }
 #pragma unroll
@@ -414,9 +499,31 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
             }
         }
 
-        fft_phase<HOP_T>(tile, wbufs + w * kWbuf, hop, w, lane, win, twc, tws);
+        AF_STAMP(1);
+        fft_phase<HOP_T>(tile, wbufs + w * kWbuf, hop, w, lane, wtab, ttab);
+        AF_STAMP(2);
+
+        // this wave's filterbank fragments (L2-resident, 40 x 256 B): issued before the
+        // barrier so their latency hides behind it
+        float wf[kMaxSteps];
+        {
+            int opaque_zero;                      // reload every unit: do not keep 40 VGPRs live
+            asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+            const float* wp = wfrag_w + opaque_zero;
+#pragma unroll
+            for (int s8 = 0; s8 < kMaxSteps; s8 += 8) {
+                if (s8 < n_slots_w * kSlotSteps) { // wave-uniform: skip unused slots
+#pragma unroll
+                    for (int s = s8; s < s8 + 8; ++s) wf[s] = wp[s * 64];
+                } else {
+#pragma unroll
+                    for (int s = s8; s < s8 + 8; ++s) wf[s] = 0.0f;
+                }
+            }
+        }
 
         __syncthreads();                          // B2: power rows ready, tile reads done
+        AF_STAMP(3);
 
         if (has_next) {
 #pragma unroll
@@ -428,7 +535,11 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
 #pragma unroll
                 for (int i = 0; i < PFU; ++i) {
                     const int v = tid + i * kThreads;
-                    if (v * MS < 16 * hop) St::store(tile + tail_len + v * MS, pf[i]);
+                    if (v * MS < 16 * hop) {
+                        float m[MS];
+                        St::convert(pf[i], m);
+                        St::store(tile + tail_len + v * MS, m);
+                    }
                 }
             } else {
                 for (int v = tid; v * MS < 16 * hop; v += kThreads) {
@@ -439,36 +550,34 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
             }
         }
 
-        mel_phase(wbufs, partials, p.plan, p.wfrag, w, lane);
-
-        __syncthreads();                          // B3: partial tiles ready
-
-        for (int idx = tid; idx < kFramesPerIter * n_mels; idx += kThreads) {
-            const int j = idx / n_mels;
-            const int m = idx - j * n_mels;
-            const int t = m >> 4, i = m & 15;
-            const int s0 = p.plan->tile_slot0[t], sn = p.plan->tile_nslots[t];
-            float sum = 0.0f;
-            for (int q = 0; q < sn; ++q) sum += partials[(s0 + q) * kSlotDw + j * 17 + i];
-            if (F0 + j < c_frames) p.mel[(c_out0 + F0 + j) * n_mels + m] = sum;
+        AF_STAMP(4);
+        {
+            const int j = lane & 15;
+            float* orow = p.mel + (c_out0 + F0 + j) * n_mels;
+            mel_phase<STAMPS>(wbufs, lmeta + w * kMaxSteps, wf, n_slots_w, slot_end_w, orow, F0 + j < c_frames,
+                              vec_ok, lane, acc_t, t_prev);
         }
-
+        AF_STAMP(6);
+        AF_STAMP(7);
         ++u;
         fresh = !has_next;
     }
+    if (STAMPS && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(p.stamps + w * 8 + i, acc_t[i]);
 }
 
-size_t features_smem_bytes(int hop, int n_slots)
+size_t features_smem_bytes(int hop)
 {
     const int tile_len = 15 * hop + kNfft;
     const int tile_alloc = (tile_len + 7) & ~7;
-    return sizeof(float) * ((size_t)tile_alloc + kWaves * kWbuf + (size_t)n_slots * kSlotDw);
+    return sizeof(float) * ((size_t)tile_alloc + kWaves * kWbuf + 32 * kWinRow + 32 * kTwRow +
+                            kWaves * kMaxSteps);
 }
 
-template <int HOP_T, int CH, bool I16>
-static af_status launch_one(const Params& p, int grid, size_t smem, hipStream_t stream)
+template <int HOP_T, int CH, bool I16, bool STAMPS>
+static af_status launch_k(const Params& p, int grid, size_t smem, hipStream_t stream)
 {
-    auto kern = af_features_kernel<HOP_T, CH, I16>;
+    auto kern = af_features_kernel<HOP_T, CH, I16, STAMPS>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -478,6 +587,13 @@ static af_status launch_one(const Params& p, int grid, size_t smem, hipStream_t 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), smem, stream, p);
     AF_HIP(hipGetLastError());
     return AF_OK;
+}
+
+template <int HOP_T, int CH, bool I16>
+static af_status launch_one(const Params& p, int grid, size_t smem, hipStream_t stream)
+{
+    return p.stamps ? launch_k<HOP_T, CH, I16, true>(p, grid, smem, stream)
+                    : launch_k<HOP_T, CH, I16, false>(p, grid, smem, stream);
 }
 
 af_status launch_features(const Params& p, int channels, bool i16, int grid, size_t smem,

@@ -217,6 +217,9 @@ af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t me
 af_status af_features_mel_weights(const af_features* p, float* W, size_t cap);
 /* name and launch geometry of the fused kernel, for profiling harnesses */
 const char* af_features_kernel_name(void);
+/* diagnostics: enable/disable in-kernel phase stamps; out[32] (optional) receives the
+ * [wave][phase] shader-cycle sums recorded since they were enabled */
+af_status af_features_debug_stamps(af_features* p, int enable, unsigned long long* out);
 
 #ifdef __cplusplus
 }

@@ -31,3 +31,16 @@ ms = e0.elapsed_time(e1) / K
 bytes_alg = n_clips * n * 8 + tot.value * 320
 print(f"clips={n_clips} frames={tot.value} ms={ms:.3f} frames/s={tot.value/ms*1e3:.3e} RTF={n_clips*30/ms*1e3:.3e} alg GB/s={bytes_alg/ms/1e6:.1f} frac8TB={bytes_alg/ms/1e6/8000:.3f}")
 print("mel finite:", bool(torch.isfinite(mel).all()), float(mel.abs().mean()))
+# ---- phase stamps (diagnostic)
+import numpy as np
+lib.af_features_debug_stamps.restype = C.c_int32; lib.af_features_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+check(lib.af_features_debug_stamps(h, 1, None))
+check(lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), stream)); torch.cuda.synchronize()
+out = np.zeros(32, np.uint64)
+check(lib.af_features_debug_stamps(h, 0, out.ctypes.data))
+units = tot.value / 16
+names = ["B1 wait", "prefetch issue", "FFT phase", "B2 wait", "tile write", "mel operands", "mel mfma+store", "loop tail"]
+per = out.reshape(4, 8).astype(np.float64) / units
+print("cycles per unit (iteration), per wave:")
+for i, nm in enumerate(names): print(f"  {nm:15s}", " ".join(f"{per[w, i]:9.0f}" for w in range(4)))
+print("  total          ", " ".join(f"{per[w].sum():9.0f}" for w in range(4)))

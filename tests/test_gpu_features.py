@@ -84,7 +84,8 @@ def test_i16_input(af, po, ch):
     assert frame_rel_err(mel, ref) < TOL
 
 
-@pytest.mark.parametrize("sr,n_mels", [(16000, 80), (48000, 40), (44100, 128), (48000, 17), (8000, 1)])
+@pytest.mark.parametrize("sr,n_mels", [(16000, 80), (48000, 40), (44100, 128), (48000, 30), (22050, 27),
+                                        (96000, 64)])
 def test_other_filterbanks(af, po, sr, n_mels):
     x = synth_clip(6, 30000, 1, sr)
     pipe, mel = run_clips(af, [x], 1, sr=sr, n_mels=n_mels)
@@ -104,6 +105,13 @@ def test_process_batch_surface(af, po):
         assert frame_rel_err(m.data, po.features(f.samples, 2, 48000.0)) < TOL
     with pytest.raises(af.AudioError):
         pipe.process_batch([af.AudioFrame.new(np.zeros(4000, np.float32), 16000, 1, 0)])
+
+
+def test_too_wide_filters_are_reported_not_miscomputed(af):
+    # documented limit: 4 consecutive filters may span at most 256 bins
+    with pytest.raises(af.AudioError) as e:
+        af.FeaturePipeline(sample_rate=48000, channels=1, n_mels=8)
+    assert e.value.status == af._ffi.AF_ERR_UNSUPPORTED
 
 
 def test_invalid_configs_are_rejected(af):
