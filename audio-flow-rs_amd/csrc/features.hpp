@@ -27,10 +27,10 @@ constexpr int kTwRow = 68;                // LDS twiddle table row: 32 (cos,sin)
 // only over the band of bins where it is non-zero, in K-steps of 4 bins.  Whole
 // groups are dealt to the 4 waves so that the busiest wave has as few steps as
 // possible; no group is split, so every wave writes its own mel columns.
-// A wave's steps are laid out in slots of 8 (a group starts on a slot boundary
+// A wave's steps are laid out in slots of 4 (a group starts on a slot boundary
 // and is padded with zero-weight steps), so the kernel's MFMA sequence is
 // branch-free inside a slot and the "group finished" code exists once per slot.
-constexpr int kSlotSteps = 8;
+constexpr int kSlotSteps = 4;
 constexpr int kMaxSlotsW = kMaxSteps / kSlotSteps;       // slots per wave
 struct Plan {
     int n_mels, n_groups, n_steps;        // n_steps = real (unpadded) steps over all waves
@@ -45,7 +45,7 @@ struct Params {
     float* mel;               // [total_frames][n_mels]
     const float* wintab;      // [32][kWinRow]: row n2 holds 0.5 * hann[32 n1 + n2], n1 = 0..31
     const float* twtab;       // [32][kTwRow]: row n2 holds (cos, sin)(2 pi k1 n2 / 1024), k1 = 0..31
-    const float* wfrag;       // [4][kMaxSteps][64] MFMA A fragments of the filterbank
+    const float* wfrag;       // [4][kMaxSlotsW][64][4] MFMA A fragments: one float4 per lane and slot
     const int* meta;          // [4][kMaxSteps] first bin of every step (0 for padding)
     Plan plan;                // by value: lives in the kernarg segment -> scalar (SMEM) loads
     const int64_t* pcm_off;   // [n_clips+1] first PCM frame of each clip

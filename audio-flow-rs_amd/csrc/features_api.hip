@@ -147,8 +147,8 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
                 meta[(size_t)w * kMaxSteps + s] = bin;
                 for (int lane = 0; lane < 64; ++lane) {
                     const int r = lane & 15, k = bin + (lane >> 4);
-                    wfrag[((size_t)w * kMaxSteps + s) * 64 + lane] =
-                        (r < cnt) ? W[(size_t)(m0 + r) * kBins + k] : 0.0f;
+                    wfrag[(((size_t)w * kMaxSlotsW + s / kSlotSteps) * 64 + lane) * kSlotSteps +
+                          s % kSlotSteps] = (r < cnt) ? W[(size_t)(m0 + r) * kBins + k] : 0.0f;
                 }
             }
             plan.n_steps += st;

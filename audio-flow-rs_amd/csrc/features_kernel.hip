@@ -188,10 +188,13 @@ struct Stage {
 
 // ---------------------------------------------------------------------------
 // FFT phase of one wave: 4 frames (two per half-wave) -> 4 power rows in LDS.
+// Part A: window, first radix-32, twiddles, transpose through LDS -> ur/ui hold the
+// second stage's inputs.  Part B: second radix-32, spectrum split, power rows.
 template <int HOP_T>
-__device__ __forceinline__ void fft_phase(const float* __restrict__ tile, float* wbuf, int hop,
-                                          int w, int lane, const float* __restrict__ wtab,
-                                          const float* __restrict__ ttab)
+__device__ __forceinline__ void fft_phase_a(const float* __restrict__ tile, float* wbuf, int hop,
+                                            int w, int lane, const float* __restrict__ wtab,
+                                            const float* __restrict__ ttab, float (&ur)[32],
+                                            float (&ui)[32])
 {
     const int half = lane >> 5, n2 = lane & 31;
     const int fa = 4 * w + 2 * half;              // first frame of this half's pair
@@ -250,7 +253,6 @@ __device__ __forceinline__ void fft_phase(const float* __restrict__ tile, float*
 
     // transpose (k1, n2) through LDS, real parts then imaginary parts
     float* xb = wbuf + half * kHalfDw;
-    float ur[32], ui[32];
 #pragma unroll
     for (int k1 = 0; k1 < 32; ++k1) xb[k1 * kXStride + n2] = re[brev5(k1)];
     wave_sync();
@@ -264,6 +266,12 @@ __device__ __forceinline__ void fft_phase(const float* __restrict__ tile, float*
     for (int n = 0; n < 32; ++n) ui[n] = xb[n2 * kXStride + n];
     wave_sync();
 
+}
+
+__device__ __forceinline__ void fft_phase_b(float* wbuf, int lane, float (&ur)[32], float (&ui)[32])
+{
+    const int half = lane >> 5, n2 = lane & 31;
+    float* xb = wbuf + half * kHalfDw;
     fft32(ur, ui);                                // over n2 -> Z[k1 + 32 k2] at brev5(k2)
 
     // Split the packed spectrum: A[k] = (Z[k] + conj Z[N-k])/2 (frame a),
@@ -330,19 +338,15 @@ __device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restr
 {
     const int f = lane & 15, kq = lane >> 4;
     const float* pbase = wbufs + (f >> 2) * kWbuf + (f & 3) * kProw + kq;
+    // Branch-free on purpose: one batch of broadcast reads for the bin offsets, one
+    // batch of operand reads (padding steps read bin 0 and multiply it by zero weights).
     float b[kMaxSteps];
+    {
+        int meta[kMaxSteps];
 #pragma unroll
-    for (int q = 0; q < kMaxSlotsW; ++q) {
-        if (q < n_slots) {                        // wave-uniform: skip unused slots
-            int meta[kSlotSteps];
+        for (int s = 0; s < kMaxSteps; ++s) meta[s] = lmeta[s];
 #pragma unroll
-            for (int s = 0; s < kSlotSteps; ++s) meta[s] = lmeta[q * kSlotSteps + s];   // broadcast
-#pragma unroll
-            for (int s = 0; s < kSlotSteps; ++s) b[q * kSlotSteps + s] = pbase[meta[s]];
-        } else {
-#pragma unroll
-            for (int s = 0; s < kSlotSteps; ++s) b[q * kSlotSteps + s] = 0.0f;
-        }
+        for (int s = 0; s < kMaxSteps; ++s) b[s] = pbase[meta[s]];
     }
     if constexpr (STAMPS) {                       // diagnostics: operands landed
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
     constexpr int MS = St::MS;
     // prefetch units per thread and iteration (compile-time only for HOP_T != 0)
     constexpr int PFU = HOP_T ? (16 * HOP_T / MS + kThreads - 1) / kThreads : 1;
-    constexpr bool kPrefetch = HOP_T != 0 && PFU <= 8;
+    constexpr bool kPrefetch = HOP_T != 0 && PFU <= 8 && (16 * HOP_T / MS) % kThreads == 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int hop = HOP_T ? HOP_T : p.hop;
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         reinterpret_cast<float4*>(ttab)[i] = reinterpret_cast<const float4*>(p.twtab)[i];
     for (int i = tid; i < kWaves * kMaxSteps; i += kThreads) lmeta[i] = p.meta[i];
     // this wave's share of the mel plan
-    const float* __restrict__ wfrag_w = p.wfrag + ((size_t)w * kMaxSteps) * 64 + lane;
+    const float* __restrict__ wfrag_w = p.wfrag + (((size_t)w * kMaxSlotsW) * 64 + lane) * 4;
     const int n_slots_w = p.plan.wave_nslots[w];
     int slot_end_w[kMaxSlotsW];
 #pragma unroll
@@ -485,11 +489,19 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         float tailr[4];
         if (has_next) {
             if constexpr (kPrefetch) {
+                if (aligned && next_pos0 + 16 * hop <= c_n) {
+                    // common case (wave-uniform): the whole new region lies inside the clip
+                    const char* src = static_cast<const char*>(p.pcm) +
+                                      (c_pcm0 + next_pos0) * St::kBytesPerFrame;
 #pragma unroll
-                for (int i = 0; i < PFU; ++i) {
-                    const int v = tid + i * kThreads;
-                    if (v * MS < 16 * hop)
+                    for (int i = 0; i < PFU; ++i)
+                        pf[i] = *reinterpret_cast<const uint4*>(src + (unsigned)(tid + i * kThreads) * 16u);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PFU; ++i) {
+                        const int v = tid + i * kThreads;
                         pf[i] = St::load_raw(p.pcm, c_pcm0, next_pos0 + (int64_t)v * MS, c_n, aligned);
+                    }
                 }
             }
 #pragma unroll
@@ -500,27 +512,35 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         }
 
         AF_STAMP(1);
-        fft_phase<HOP_T>(tile, wbufs + w * kWbuf, hop, w, lane, wtab, ttab);
-        AF_STAMP(2);
-
-        // this wave's filterbank fragments (L2-resident, 40 x 256 B): issued before the
-        // barrier so their latency hides behind it
         float wf[kMaxSteps];
         {
-            int opaque_zero;                      // reload every unit: do not keep 40 VGPRs live
-            asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
-            const float* wp = wfrag_w + opaque_zero;
+            float ur[32], ui[32];
+            fft_phase_a<HOP_T>(tile, wbufs + w * kWbuf, hop, w, lane, wtab, ttab, ur, ui);
+            // This wave's filterbank fragments (L2-resident, one float4 per slot).  A global
+            // load takes several microseconds to come back while the chip streams PCM, so
+            // they are issued here -- register pressure is lowest between the two radix-32
+            // stages -- and consumed in the mel phase.
+            {
+                int opaque_zero;                  // pins the loads here (and defeats hoisting)
+                asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+                const float4* wp = reinterpret_cast<const float4*>(wfrag_w) + opaque_zero;
 #pragma unroll
-            for (int s8 = 0; s8 < kMaxSteps; s8 += 8) {
-                if (s8 < n_slots_w * kSlotSteps) { // wave-uniform: skip unused slots
+                for (int q4 = 0; q4 < kMaxSlotsW; q4 += 4) {
+                    if (q4 < n_slots_w) {         // wave-uniform: skip unused slots
 #pragma unroll
-                    for (int s = s8; s < s8 + 8; ++s) wf[s] = wp[s * 64];
-                } else {
+                        for (int q = q4; q < q4 + 4; ++q) {
+                            const float4 v = wp[q * 64];
+                            wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+                        }
+                    } else {
 #pragma unroll
-                    for (int s = s8; s < s8 + 8; ++s) wf[s] = 0.0f;
+                        for (int s = 4 * q4; s < 4 * q4 + 16; ++s) wf[s] = 0.0f;
+                    }
                 }
             }
+            fft_phase_b(wbufs + w * kWbuf, lane, ur, ui);
         }
+        AF_STAMP(2);
 
         __syncthreads();                          // B2: power rows ready, tile reads done
         AF_STAMP(3);
@@ -535,11 +555,9 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
 #pragma unroll
                 for (int i = 0; i < PFU; ++i) {
                     const int v = tid + i * kThreads;
-                    if (v * MS < 16 * hop) {
-                        float m[MS];
-                        St::convert(pf[i], m);
-                        St::store(tile + tail_len + v * MS, m);
-                    }
+                    float m[MS];
+                    St::convert(pf[i], m);
+                    St::store(tile + tail_len + v * MS, m);
                 }
             } else {
                 for (int v = tid; v * MS < 16 * hop; v += kThreads) {
