@@ -1,0 +1,280 @@
+// audioflow.hpp -- header-only C++17 mirror of the reference's audio module
+// (forfd8960/audio-flow-rs, src-tauri/src/modules/audio/*.rs) over the C ABI of
+// audioflow_dsp.h.  The reference is Rust; this image has no Rust toolchain, so
+// the host side above the C ABI is written in C++ (the Rust shim a maintainer
+// would add is in INTEGRATION.md, as source).  Same names, argument meaning and
+// error behaviour as the reference:
+//
+//   AudioFrame::to_mono                 capture.rs:30
+//   AudioResampler::{new_, create_48k_to_16k, process, input_rate, ...}   resampler.rs:32-108
+//   BatchResampler::{new_, process, flush}                                resampler.rs:121-166
+//   VoiceActivityDetector::{detect, reset, state, is_speaking, ...}       vad.rs:80-205
+//   AudioError::ResamplingFailed(String)                                  error.rs:109
+//
+// Every failure of the library surfaces as AudioError (a std::runtime_error
+// whose what() is "Resampling failed: <msg>", error.rs:109-110), mirroring
+// `map_err(|e| AudioError::ResamplingFailed(e.to_string()))` (resampler.rs:49,:85).
+#pragma once
+
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "audioflow_dsp.h"
+
+namespace audioflow {
+
+struct AudioError : std::runtime_error {
+    af_status status;
+    AudioError(af_status st, const std::string& detail)
+        : std::runtime_error("Resampling failed: " + detail), status(st) {}
+};
+
+namespace detail {
+inline void check(af_status st)
+{
+    if (st != AF_OK) throw AudioError(st, af_last_error());
+}
+}  // namespace detail
+
+// capture.rs:13-43
+struct AudioFrame {
+    std::vector<float> samples;
+    uint32_t sample_rate = 0;
+    uint16_t channels = 1;
+    unsigned __int128 timestamp_ns = 0;
+
+    static AudioFrame new_(std::vector<float> samples, uint32_t sample_rate, uint16_t channels,
+                           unsigned __int128 timestamp_ns)
+    {
+        return AudioFrame{std::move(samples), sample_rate, channels, timestamp_ns};
+    }
+
+    AudioFrame to_mono() const
+    {   // capture.rs:30-42
+        if (channels == 1) return *this;
+        std::vector<float> mono(af_to_mono_out_len(samples.size(), channels));
+        size_t n = 0;
+        detail::check(af_to_mono(samples.data(), samples.size(), channels, mono.data(), mono.size(), &n));
+        mono.resize(n);
+        return AudioFrame{std::move(mono), sample_rate, 1, timestamp_ns};
+    }
+};
+
+// resampler.rs:12-109
+class AudioResampler {
+public:
+    static AudioResampler new_(uint32_t input_rate, uint32_t output_rate)
+    {
+        af_resampler* h = nullptr;
+        detail::check(af_resampler_create(input_rate, output_rate, &h));
+        return AudioResampler(h);
+    }
+    static AudioResampler create_48k_to_16k() { return new_(48000, 16000); }   // resampler.rs:60
+    AudioResampler() : AudioResampler(new_(48000, 16000)) {}                    // Default, :169
+    AudioResampler(AudioResampler&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    AudioResampler& operator=(AudioResampler&& o) noexcept
+    {
+        if (this != &o) { af_resampler_destroy(h_); h_ = o.h_; o.h_ = nullptr; }
+        return *this;
+    }
+    AudioResampler(const AudioResampler&) = delete;
+    AudioResampler& operator=(const AudioResampler&) = delete;
+    ~AudioResampler() { af_resampler_destroy(h_); }
+
+    std::vector<float> process(const std::vector<float>& input)
+    {   // resampler.rs:71-93
+        std::vector<float> out(af_resampler_out_len(h_, input.size()));
+        size_t n = 0;
+        detail::check(af_resampler_process(h_, input.data(), input.size(), out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
+    std::vector<float> flush()
+    {
+        std::vector<float> out(af_resampler_out_len(h_, 0));
+        size_t n = 0;
+        detail::check(af_resampler_flush(h_, out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
+    uint32_t input_rate() const { return af_resampler_input_rate(h_); }           // :96
+    uint32_t output_rate() const { return af_resampler_output_rate(h_); }         // :101
+    bool needs_resampling() const { return af_resampler_needs_resampling(h_); }   // :106
+
+private:
+    explicit AudioResampler(af_resampler* h) : h_(h) {}
+    af_resampler* h_ = nullptr;
+};
+
+// resampler.rs:114-167
+class BatchResampler {
+public:
+    static BatchResampler new_(uint32_t input_rate, uint32_t output_rate)
+    {
+        af_batch_resampler* h = nullptr;
+        detail::check(af_batch_resampler_create(input_rate, output_rate, &h));
+        return BatchResampler(h);
+    }
+    BatchResampler(BatchResampler&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    BatchResampler(const BatchResampler&) = delete;
+    BatchResampler& operator=(const BatchResampler&) = delete;
+    ~BatchResampler() { af_batch_resampler_destroy(h_); }
+
+    std::vector<float> process(const std::vector<float>& input)
+    {   // resampler.rs:132-147
+        std::vector<float> out(af_batch_resampler_out_len(h_, input.size()));
+        size_t n = 0;
+        detail::check(af_batch_resampler_process(h_, input.data(), input.size(), out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
+    std::vector<float> flush()
+    {   // resampler.rs:150-166
+        std::vector<float> out(af_batch_resampler_out_len(h_, 0));
+        size_t n = 0;
+        detail::check(af_batch_resampler_flush(h_, out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
+    size_t buffered() const { return af_batch_resampler_buffered(h_); }
+
+private:
+    explicit BatchResampler(af_batch_resampler* h) : h_(h) {}
+    af_batch_resampler* h_ = nullptr;
+};
+
+// vad.rs:21-54
+struct VadConfig {
+    float threshold_db = -50.0f;
+    float smoothing_factor = 0.3f;
+    size_t silence_timeout_frames = 15;
+    size_t min_speech_frames = 3;
+};
+enum class VadState { Silence = AF_VAD_SILENCE, Speech = AF_VAD_SPEECH, Ending = AF_VAD_ENDING };
+
+// vad.rs:60-205
+class VoiceActivityDetector {
+public:
+    explicit VoiceActivityDetector(const VadConfig& c = VadConfig())
+    {
+        af_vad_config cfg{c.threshold_db, c.smoothing_factor, c.silence_timeout_frames, c.min_speech_frames};
+        detail::check(af_vad_create(&cfg, &h_));
+    }
+    VoiceActivityDetector(const VoiceActivityDetector&) = delete;
+    VoiceActivityDetector& operator=(const VoiceActivityDetector&) = delete;
+    ~VoiceActivityDetector() { af_vad_destroy(h_); }
+
+    VadState detect(const std::vector<float>& frame)
+    {   // vad.rs:97-154
+        int st = 0;
+        detail::check(af_vad_detect(h_, frame.data(), frame.size(), &st));
+        return static_cast<VadState>(st);
+    }
+    void reset() { af_vad_reset(h_); }                                            // :179
+    VadState state() const { return static_cast<VadState>(af_vad_state(h_)); }    // :187
+    float energy_db() const { return af_vad_energy_db(h_); }                      // :192
+    bool is_speaking() const { return state() == VadState::Speech; }              // :197
+    size_t speech_frame_count() const { return af_vad_speech_frame_count(h_); }   // :202
+
+private:
+    af_vad* h_ = nullptr;
+};
+
+// websocket.rs:246-251
+inline std::vector<int16_t> quantize_pcm16(const std::vector<float>& audio)
+{
+    std::vector<int16_t> out(audio.size());
+    detail::check(af_quantize_pcm16(audio.data(), audio.size(), out.data()));
+    return out;
+}
+
+// build-defined siblings (docs/OPS.md)
+class FirFilter {
+public:
+    static FirFilter new_(const std::vector<float>& taps)
+    {
+        af_fir* h = nullptr;
+        detail::check(af_fir_create(taps.data(), taps.size(), &h));
+        return FirFilter(h);
+    }
+    FirFilter(FirFilter&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    FirFilter(const FirFilter&) = delete;
+    FirFilter& operator=(const FirFilter&) = delete;
+    ~FirFilter() { af_fir_destroy(h_); }
+    std::vector<float> process(const std::vector<float>& input)
+    {
+        std::vector<float> out(input.size());
+        detail::check(af_fir_process(h_, input.data(), input.size(), out.data()));
+        return out;
+    }
+    void reset() { af_fir_reset(h_); }
+
+private:
+    explicit FirFilter(af_fir* h) : h_(h) {}
+    af_fir* h_ = nullptr;
+};
+
+struct MelSpectrogram {
+    std::vector<float> data;   // [n_frames][n_mels]
+    size_t n_frames = 0, n_mels = 0;
+};
+
+class FeaturePipeline {
+public:
+    explicit FeaturePipeline(const af_features_config& cfg) : cfg_(cfg)
+    {
+        detail::check(af_features_create(&cfg_, &h_));
+    }
+    FeaturePipeline() : FeaturePipeline(default_config()) {}
+    FeaturePipeline(const FeaturePipeline&) = delete;
+    FeaturePipeline& operator=(const FeaturePipeline&) = delete;
+    ~FeaturePipeline() { af_features_destroy(h_); }
+
+    static af_features_config default_config()
+    {
+        af_features_config c;
+        af_features_default_config(&c);
+        return c;
+    }
+    size_t n_frames(size_t n_pcm_frames) const { return af_features_n_frames(h_, n_pcm_frames); }
+
+    // FeaturePipeline::process_batch(&[AudioFrame]) -> Result<Vec<MelSpectrogram>, AudioError>
+    std::vector<MelSpectrogram> process_batch(const std::vector<AudioFrame>& frames)
+    {
+        std::vector<int64_t> off(frames.size() + 1, 0);
+        std::vector<float> pcm;
+        for (size_t i = 0; i < frames.size(); ++i) {
+            if (frames[i].channels != cfg_.channels || frames[i].sample_rate != cfg_.sample_rate)
+                throw AudioError(AF_ERR_INVALID_ARG, "frame format does not match the pipeline");
+            const size_t nf = frames[i].samples.size() / cfg_.channels;
+            off[i + 1] = off[i] + (int64_t)nf;
+            pcm.insert(pcm.end(), frames[i].samples.begin(), frames[i].samples.begin() + nf * cfg_.channels);
+        }
+        size_t total = 0;
+        detail::check(af_features_set_batch(h_, off.data(), frames.size(), &total));
+        std::vector<float> mel(total * cfg_.n_mels);
+        detail::check(af_features_run(h_, pcm.data(), mel.data(), mel.size()));
+        std::vector<MelSpectrogram> out;
+        size_t row = 0;
+        for (size_t i = 0; i < frames.size(); ++i) {
+            const size_t nf = n_frames((size_t)(off[i + 1] - off[i]));
+            MelSpectrogram m;
+            m.n_frames = nf;
+            m.n_mels = cfg_.n_mels;
+            m.data.assign(mel.begin() + row * cfg_.n_mels, mel.begin() + (row + nf) * cfg_.n_mels);
+            out.push_back(std::move(m));
+            row += nf;
+        }
+        return out;
+    }
+
+private:
+    af_features_config cfg_;
+    af_features* h_ = nullptr;
+};
+
+}  // namespace audioflow

@@ -1,0 +1,62 @@
+"""Timings of the secondary kernels at BASELINE shapes (device-resident data, HIP events on
+torch's stream): config 3 resample, FIR (config 4 stage), to_mono, quantise, base64, VAD energy,
+plus the PCIe-inclusive rate of the fused feature path through the host-buffer entry point."""
+import ctypes as C, os, sys, time, json
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import audio_flow_rs_amd as af
+lib = af.library(); dev = torch.device("cuda:0"); P = C.c_void_p
+def timeit(fn, k=10, w=2):
+    for _ in range(w): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(k): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / k
+out = {}
+# config 3: 4096 x 10 s mono 44.1 kHz -> 16 kHz (7.2 GB in, 2.6 GB out)
+nc, nin = 4096, 441000
+nout = lib.af_resample_out_len(44100, 16000, nin)
+x = torch.rand(nc, nin, device=dev) - 0.5; y = torch.empty(nc, nout, device=dev)
+ms = timeit(lambda: lib.af_resample_batch_device(44100, 16000, P(x.data_ptr()), nc, nin, P(y.data_ptr()), None), k=5)
+b = (x.numel() + y.numel()) * 4
+out["resample_44k1_16k_cfg3"] = dict(ms=ms, alg_GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / 8000, rtf=nc * 10 / ms * 1e3)
+del x, y
+# 48k -> 16k, 1024 x 30 s mono (config 4 stage)
+nc, nin = 1024, 1440000
+nout = lib.af_resample_out_len(48000, 16000, nin)
+x = torch.rand(nc, nin, device=dev) - 0.5; y = torch.empty(nc, nout, device=dev)
+ms = timeit(lambda: lib.af_resample_batch_device(48000, 16000, P(x.data_ptr()), nc, nin, P(y.data_ptr()), None), k=5)
+b = (x.numel() + y.numel()) * 4
+out["resample_48k_16k_cfg4"] = dict(ms=ms, alg_GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / 8000)
+# FIR K=129 on the 16 kHz clips
+taps = torch.rand(129, device=dev) / 129; z = torch.empty_like(y)
+ms = timeit(lambda: lib.af_fir_batch_device(P(taps.data_ptr()), 129, P(y.data_ptr()), nc, nout, P(z.data_ptr()), None), k=5)
+b = 2 * y.numel() * 4
+out["fir129_cfg4"] = dict(ms=ms, alg_GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / 8000, tflops=2 * 129 * y.numel() / ms / 1e9)
+# quantise / base64 / vad energy on the same buffer
+q = torch.empty(y.numel(), dtype=torch.int16, device=dev)
+ms = timeit(lambda: lib.af_quantize_pcm16_device(P(y.data_ptr()), y.numel(), P(q.data_ptr()), None))
+out["quantize_pcm16"] = dict(ms=ms, alg_GBps=y.numel() * 6 / ms / 1e6, frac_hbm=y.numel() * 6 / ms / 1e6 / 8000)
+b64 = torch.empty(lib.af_base64_len(2 * y.numel()) + 16, dtype=torch.uint8, device=dev)
+ms = timeit(lambda: lib.af_pcm16_base64_device(P(y.data_ptr()), y.numel(), P(b64.data_ptr()), None))
+bb = y.numel() * 4 + b64.numel()
+out["pcm16_base64"] = dict(ms=ms, alg_GBps=bb / ms / 1e6, frac_hbm=bb / ms / 1e6 / 8000)
+en = torch.empty(y.numel() // 320, device=dev)
+ms = timeit(lambda: lib.af_vad_energy_device(P(y.data_ptr()), y.numel() // 320, 320, P(en.data_ptr()), None))
+out["vad_energy_320"] = dict(ms=ms, alg_GBps=y.numel() * 4 / ms / 1e6, frac_hbm=y.numel() * 4 / ms / 1e6 / 8000)
+del x, y, z, q, b64, en
+# to_mono on config 2's input
+s = torch.rand(256 * 1440000, 2, device=dev); m = torch.empty(256 * 1440000, device=dev)
+ms = timeit(lambda: lib.af_to_mono_device(P(s.data_ptr()), s.numel(), 2, P(m.data_ptr()), None))
+out["to_mono_cfg2"] = dict(ms=ms, alg_GBps=s.numel() * 6 / ms / 1e6, frac_hbm=s.numel() * 6 / ms / 1e6 / 8000)
+# PCIe-inclusive fused features (host buffers), 64 clips
+k = 64
+pipe = af.FeaturePipeline(); pipe.set_batch_uniform(k, 1440000)
+host = s[: k * 1440000].cpu().numpy()
+pipe.run(host)
+t0 = time.perf_counter(); mel = pipe.run(host); dt = time.perf_counter() - t0
+out["features_host_buffers_64clips"] = dict(ms=dt * 1e3, frames_per_s=mel.shape[0] / dt, note="H2D + kernel + D2H, pageable host memory")
+print(json.dumps(out, indent=1))

@@ -1,0 +1,116 @@
+// harness.cpp -- C++ twin of the reference's own unit tests, driven through the C++ host
+// mirror (include/audioflow.hpp) and therefore through the exact C-ABI entry points the Rust
+// shim of INTEGRATION.md binds.  Each check cites the #[test] it ports
+// (forfd8960/audio-flow-rs, src-tauri/src/...).  Needs an MI355X; exit code 0 = all passed.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "audioflow.hpp"
+
+using namespace audioflow;
+
+static int failures = 0;
+#define CHECK(cond)                                                               \
+    do {                                                                          \
+        if (!(cond)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+int main()
+{
+    // capture.rs:371-382 test_audio_frame_to_mono_single_channel
+    {
+        auto f = AudioFrame::new_({0.5f, -0.5f}, 16000, 1, 1000);
+        auto m = f.to_mono();
+        CHECK(m.channels == 1 && m.samples == std::vector<float>({0.5f, -0.5f}));
+    }
+    // capture.rs:384-400 test_audio_frame_to_mono_stereo
+    {
+        auto f = AudioFrame::new_({0.5f, 0.25f, -0.5f, -0.25f}, 16000, 2, 1000);
+        auto m = f.to_mono();
+        CHECK(m.channels == 1 && m.samples.size() == 2);
+        CHECK(std::fabs(m.samples[0] - 0.375f) < 0.001f && std::fabs(m.samples[1] + 0.375f) < 0.001f);
+    }
+    // resampler.rs:184-190 test_no_resample_needed
+    {
+        auto r = AudioResampler::new_(16000, 16000);
+        std::vector<float> in = {0.1f, 0.2f, 0.3f, 0.4f};
+        CHECK(r.process(in) == in);
+    }
+    // resampler.rs:192-198 test_resample_rates, :200-204 test_same_rates_no_resampling
+    {
+        auto r = AudioResampler::new_(48000, 16000);
+        CHECK(r.input_rate() == 48000 && r.output_rate() == 16000 && r.needs_resampling());
+        CHECK(!AudioResampler::new_(48000, 48000).needs_resampling());
+    }
+    // resampler.rs:132-166 chunk/carry/flush bookkeeping + the 480 -> 160 framing of specs/0001-spec.md:270-272
+    {
+        auto b = BatchResampler::new_(48000, 16000);
+        std::vector<float> x(480, 0.25f);
+        size_t total = b.process(x).size();
+        CHECK(b.buffered() == 480 % 128);
+        total += b.flush().size();
+        CHECK(b.buffered() == 0);
+        CHECK(total == (512 - 32 + 2) / 3);          // ceil((4*128 - T/2) / 3) outputs released
+        auto one = AudioResampler::new_(48000, 16000);
+        auto y = one.process(x);
+        auto tail = one.flush();
+        CHECK(y.size() + tail.size() == 160);         // ceil(480 / 3)
+        CHECK(std::fabs(y[60] - 0.25f) < 1e-6f);      // unit DC gain
+    }
+    // error mapping, resampler.rs:49 -> error.rs:109
+    {
+        bool threw = false;
+        try { (void)AudioResampler::new_(0, 16000); }
+        catch (const AudioError& e) { threw = std::string(e.what()).rfind("Resampling failed: ", 0) == 0; }
+        CHECK(threw);
+    }
+    // vad.rs:283-298 test_energy_calculation (through the batched energy entry point)
+    {
+        std::vector<float> z(480, 0.0f), h(480, 0.5f);
+        float e = 1.0f;
+        CHECK(af_vad_energy(z.data(), 1, 480, &e) == AF_OK && e == 0.0f);
+        CHECK(af_vad_energy(h.data(), 1, 480, &e) == AF_OK && std::fabs(e - 0.25f) < 0.0001f);
+    }
+    // vad.rs:211-237 silence / speech detection, :239-265 transitions, :267-281 reset
+    {
+        std::vector<float> silence(480, 0.0001f), speech(480, 0.5f);
+        CHECK(VoiceActivityDetector(VadConfig{-50.0f}).detect(silence) == VadState::Silence);
+        CHECK(VoiceActivityDetector(VadConfig{-50.0f}).detect(speech) == VadState::Speech);
+        VoiceActivityDetector v(VadConfig{-50.0f, 0.0f, 2, 1});
+        CHECK(v.state() == VadState::Silence);
+        CHECK(v.detect(speech) == VadState::Speech);
+        CHECK(v.detect(silence) == VadState::Speech);
+        CHECK(v.detect(silence) == VadState::Ending);
+        CHECK(v.detect(silence) == VadState::Silence);
+        VoiceActivityDetector d;
+        d.detect(speech);
+        CHECK(d.is_speaking());
+        d.reset();
+        CHECK(d.state() == VadState::Silence && !d.is_speaking());
+    }
+    // websocket.rs:376-382 test_message_builder_audio (values per :342)
+    {
+        auto q = quantize_pcm16({0.5f, -0.5f, 0.25f, -0.25f});
+        CHECK(q == std::vector<int16_t>({16383, -16383, 8191, -8191}));
+    }
+    // build-defined siblings: shapes and a sanity value
+    {
+        FeaturePipeline p;
+        std::vector<float> pcm(2 * 6000, 0.0f);
+        for (size_t i = 0; i < 6000; ++i) pcm[2 * i] = pcm[2 * i + 1] = 0.5f * std::sin(2.0 * M_PI * 1000.0 * i / 48000.0);
+        auto out = p.process_batch({AudioFrame::new_(pcm, 48000, 2, 0), AudioFrame::new_({}, 48000, 2, 0)});
+        CHECK(out.size() == 2 && out[0].n_frames == 20 && out[0].n_mels == 80 && out[1].n_frames == 0);
+        size_t arg = 0;                                // the 1 kHz tone peaks in the filter around 1 kHz
+        for (size_t m = 1; m < 80; ++m) if (out[0].data[m] > out[0].data[arg]) arg = m;
+        CHECK(arg >= 18 && arg <= 22);
+        auto fir = FirFilter::new_({0.5f, 0.5f});
+        auto y = fir.process({1.0f, 1.0f, 1.0f});
+        CHECK(y == std::vector<float>({0.5f, 1.0f, 1.0f}));
+        y = fir.process({1.0f});
+        CHECK(y == std::vector<float>({1.0f}));       // history carried
+    }
+    std::printf(failures ? "%d check(s) failed\n" : "harness ok\n", failures);
+    return failures ? 1 : 0;
+}
