@@ -30,6 +30,13 @@ class FeaturesConfig(C.Structure):
                 ("f_max", C.c_float), ("sample_format", C.c_uint32), ("device", C.c_int32)]
 
 
+class ChainConfig(C.Structure):
+    _fields_ = [("input_rate", C.c_uint32), ("channels", C.c_uint32), ("output_rate", C.c_uint32),
+                ("fir_taps", C.c_void_p), ("n_fir_taps", C.c_size_t), ("hop", C.c_uint32),
+                ("n_mels", C.c_uint32), ("f_min", C.c_float), ("f_max", C.c_float),
+                ("device", C.c_int32)]
+
+
 class VadConfig(C.Structure):
     _fields_ = [("threshold_db", C.c_float), ("smoothing_factor", C.c_float),
                 ("silence_timeout_frames", C.c_size_t), ("min_speech_frames", C.c_size_t)]
@@ -105,11 +112,20 @@ SIGNATURES = {
     "af_features_n_frames": (_sz, [_vp, _sz]),
     "af_features_set_batch": (_st, [_vp, _vp, _sz, _szp]),
     "af_features_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp]),
+    "af_features_set_batch_spans": (_st, [_vp, _vp, _vp, _sz, _szp]),
     "af_features_run_device": (_st, [_vp, _vp, _vp, _vp]),
     "af_features_run": (_st, [_vp, _vp, _vp, _sz]),
     "af_features_mel_weights": (_st, [_vp, _vp, _sz]),
     "af_features_kernel_name": (C.c_char_p, []),
     "af_features_debug_stamps": (_st, [_vp, C.c_int, _vp]),
+    # full chain
+    "af_chain_default_config": (None, [C.POINTER(ChainConfig)]),
+    "af_chain_create": (_st, [C.POINTER(ChainConfig), C.POINTER(_vp)]),
+    "af_chain_destroy": (None, [_vp]),
+    "af_chain_n_frames": (_sz, [_vp, _sz]),
+    "af_chain_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp]),
+    "af_chain_run_device": (_st, [_vp, _vp, _vp, _vp]),
+    "af_chain_run": (_st, [_vp, _vp, _vp, _sz]),
 }
 
 _lib = None

@@ -458,6 +458,32 @@ class FeaturePipeline:
         self.total_frames = tot.value
         return self.total_frames
 
+    def set_batch_spans(self, starts: Sequence[int], lengths: Sequence[int]) -> int:
+        """Spans ``[start, start + length)`` of one PCM buffer; they may overlap (streaming)."""
+        st = np.ascontiguousarray(starts, np.int64)
+        ln = np.ascontiguousarray(lengths, np.int64)
+        tot = C.c_size_t()
+        _check(self._lib.af_features_set_batch_spans(self._h, _ptr(st), _ptr(ln), st.size,
+                                                     C.byref(tot)))
+        self.total_frames = tot.value
+        return self.total_frames
+
+    @staticmethod
+    def stream_spans(n_total: int, chunk: int, n_fft: int = 1024, hop: int = 256):
+        """Cut a stream of ``n_total`` frames into chunks of ``chunk`` frames (a multiple of
+        16*hop) with a right halo of ``n_fft - hop``: frame f belongs to the chunk that holds
+        sample f*hop, so the concatenated chunk outputs are the one-shot framing."""
+        if chunk % (16 * hop) != 0:
+            raise ValueError("chunk must be a multiple of 16*hop")
+        starts, lengths = [], []
+        pos = 0
+        while pos < n_total:
+            ln = min(chunk + n_fft - hop, n_total - pos)
+            starts.append(pos)
+            lengths.append(ln)
+            pos += chunk
+        return starts, lengths
+
     # -- execution
     def run_device(self, pcm_ptr: int, mel_ptr: int, stream: int = 0) -> None:
         """Enqueue on ``stream`` (a hipStream_t as int); device pointers as ints."""
@@ -493,3 +519,45 @@ class FeaturePipeline:
             out.append(MelSpectrogram(mel[row:row + nf], self.cfg.sample_rate, self.cfg.hop))
             row += nf
         return out
+
+
+class ChainPipeline:
+    """BASELINE config 4 chain [B]: to_mono -> resample -> FIR -> STFT -> mel on the device."""
+
+    def __init__(self, input_rate: int = 48000, channels: int = 2, output_rate: int = 16000,
+                 fir_taps=None, hop: int = 256, n_mels: int = 80, f_min: float = 0.0,
+                 f_max: float = 0.0, device: int = -1):
+        self._lib = library()
+        self._taps = _f32(fir_taps) if fir_taps is not None and len(fir_taps) else None
+        self.cfg = _ffi.ChainConfig(input_rate, channels, output_rate,
+                                    _ptr(self._taps) if self._taps is not None else None,
+                                    self._taps.size if self._taps is not None else 0,
+                                    hop, n_mels, f_min, f_max, device)
+        h = C.c_void_p()
+        _check(self._lib.af_chain_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h
+        self.total_frames = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_chain_destroy(h)
+
+    def n_frames(self, n_pcm_frames: int) -> int:
+        return int(self._lib.af_chain_n_frames(self._h, n_pcm_frames))
+
+    def set_batch_uniform(self, n_clips: int, frames_per_clip: int) -> int:
+        tot = C.c_size_t()
+        _check(self._lib.af_chain_set_batch_uniform(self._h, n_clips, frames_per_clip, C.byref(tot)))
+        self.total_frames = tot.value
+        return self.total_frames
+
+    def run_device(self, pcm_ptr: int, mel_ptr: int, stream: int = 0) -> None:
+        _check(self._lib.af_chain_run_device(self._h, C.c_void_p(pcm_ptr), C.c_void_p(mel_ptr),
+                                             C.c_void_p(stream)))
+
+    def run(self, pcm) -> np.ndarray:
+        x = np.ascontiguousarray(pcm, np.float32).reshape(-1)
+        mel = np.empty((self.total_frames, self.cfg.n_mels), np.float32)
+        _check(self._lib.af_chain_run(self._h, _ptr(x), _ptr(mel), mel.size))
+        return mel

@@ -1,0 +1,144 @@
+// chain.hip -- the full feature chain of BASELINE config 4 as one handle:
+//   interleaved PCM -> to_mono [R capture.rs:30-42] -> polyphase resample [B]
+//   -> FIR [B] -> Hann STFT -> |X|^2 -> mel [B]
+// Every stage is the corresponding device entry point of this library, enqueued
+// back to back on the caller's stream; all intermediate buffers are allocated
+// when the batch is described, so af_chain_run_device() only launches kernels
+// (it can be captured into a hipGraph and replayed per streaming step).
+#include <new>
+#include <vector>
+
+#include "af_common.hpp"
+
+using namespace af;
+
+struct af_chain {
+    af_chain_config cfg{};
+    af_features* feat = nullptr;
+    DevBuf d_taps, d_mono, d_res, d_fir, d_pcm, d_mel;
+    size_t n_clips = 0, n_in = 0, n_res = 0, total_frames = 0;
+};
+
+extern "C" {
+
+void af_chain_default_config(af_chain_config* c)
+{
+    if (!c) return;
+    c->input_rate = 48000;
+    c->channels = 2;
+    c->output_rate = 16000;
+    c->fir_taps = nullptr;
+    c->n_fir_taps = 0;
+    c->hop = 256;
+    c->n_mels = 80;
+    c->f_min = 0.0f;
+    c->f_max = 0.0f;
+    c->device = -1;
+}
+
+af_status af_chain_create(const af_chain_config* cfg, af_chain** out)
+{
+    AF_REQUIRE(cfg && out, "af_chain_create: null argument");
+    *out = nullptr;
+    AF_REQUIRE(cfg->input_rate > 0 && cfg->output_rate > 0, "sample rates must be positive");
+    AF_REQUIRE(cfg->channels == 1 || cfg->channels == 2, "channels must be 1 or 2 (got %u)", cfg->channels);
+    AF_REQUIRE(cfg->n_fir_taps == 0 || cfg->fir_taps, "fir_taps is null");
+    AF_REQUIRE(cfg->n_fir_taps <= 1024, "FIR needs at most 1024 taps (got %zu)", cfg->n_fir_taps);
+    AF_TRY(ensure_device(cfg->device));
+    af_chain* c = new (std::nothrow) af_chain();
+    if (!c) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
+    c->cfg = *cfg;
+    c->cfg.fir_taps = nullptr;            // the taps are copied to the device below
+    af_features_config fc;
+    af_features_default_config(&fc);
+    fc.sample_rate = cfg->output_rate;
+    fc.channels = 1;
+    fc.hop = cfg->hop;
+    fc.n_mels = cfg->n_mels;
+    fc.f_min = cfg->f_min;
+    fc.f_max = cfg->f_max;
+    fc.device = -1;
+    af_status st = af_features_create(&fc, &c->feat);
+    if (st == AF_OK && cfg->n_fir_taps) {
+        st = c->d_taps.reserve(cfg->n_fir_taps * sizeof(float));
+        if (st == AF_OK && hipMemcpy(c->d_taps.p, cfg->fir_taps, cfg->n_fir_taps * sizeof(float),
+                                     hipMemcpyHostToDevice) != hipSuccess)
+            st = fail(AF_ERR_HIP, "uploading FIR taps failed");
+    }
+    if (st != AF_OK) { af_chain_destroy(c); return st; }
+    *out = c;
+    return AF_OK;
+}
+
+void af_chain_destroy(af_chain* c)
+{
+    if (!c) return;
+    af_features_destroy(c->feat);
+    delete c;
+}
+
+size_t af_chain_n_frames(const af_chain* c, size_t n_pcm_frames)
+{
+    if (!c) return 0;
+    const size_t n_res = af_resample_out_len(c->cfg.input_rate, c->cfg.output_rate, n_pcm_frames);
+    return af_features_n_frames(c->feat, n_res);
+}
+
+af_status af_chain_set_batch_uniform(af_chain* c, size_t n_clips, size_t frames_per_clip,
+                                     size_t* total_frames_out)
+{
+    AF_REQUIRE(c, "af_chain_set_batch_uniform: null handle");
+    c->n_clips = n_clips;
+    c->n_in = frames_per_clip;
+    c->n_res = af_resample_out_len(c->cfg.input_rate, c->cfg.output_rate, frames_per_clip);
+    if (c->cfg.channels == 2) AF_TRY(c->d_mono.reserve(n_clips * frames_per_clip * sizeof(float)));
+    if (c->cfg.input_rate != c->cfg.output_rate) AF_TRY(c->d_res.reserve(n_clips * c->n_res * sizeof(float)));
+    if (c->cfg.n_fir_taps) AF_TRY(c->d_fir.reserve(n_clips * c->n_res * sizeof(float)));
+    size_t total = 0;
+    AF_TRY(af_features_set_batch_uniform(c->feat, n_clips, c->n_res, &total));
+    c->total_frames = total;
+    if (total_frames_out) *total_frames_out = total;
+    return AF_OK;
+}
+
+af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev, void* stream)
+{
+    AF_REQUIRE(c, "af_chain_run_device: null handle");
+    if (c->n_clips == 0 || c->n_in == 0) return AF_OK;
+    AF_REQUIRE(pcm_dev && (mel_dev || c->total_frames == 0), "af_chain_run_device: null buffer");
+    const float* cur = pcm_dev;
+    if (c->cfg.channels == 2) {
+        AF_TRY(af_to_mono_device(cur, c->n_clips * c->n_in * 2, 2, c->d_mono.as<float>(), stream));
+        cur = c->d_mono.as<float>();
+    }
+    if (c->cfg.input_rate != c->cfg.output_rate) {
+        AF_TRY(af_resample_batch_device(c->cfg.input_rate, c->cfg.output_rate, cur, c->n_clips, c->n_in,
+                                        c->d_res.as<float>(), stream));
+        cur = c->d_res.as<float>();
+    }
+    if (c->cfg.n_fir_taps) {
+        AF_TRY(af_fir_batch_device(c->d_taps.as<float>(), c->cfg.n_fir_taps, cur, c->n_clips, c->n_res,
+                                   c->d_fir.as<float>(), stream));
+        cur = c->d_fir.as<float>();
+    }
+    return af_features_run_device(c->feat, cur, mel_dev, stream);
+}
+
+af_status af_chain_run(af_chain* c, const float* pcm, float* mel, size_t mel_cap)
+{
+    AF_REQUIRE(c, "af_chain_run: null handle");
+    const size_t n_out = c->total_frames * c->cfg.n_mels;
+    if (mel_cap < n_out) return fail(AF_ERR_BUFFER_TOO_SMALL, "mel buffer holds %zu floats, need %zu", mel_cap, n_out);
+    if (c->n_clips == 0 || c->n_in == 0) return AF_OK;
+    AF_REQUIRE(pcm && (mel || n_out == 0), "af_chain_run: null buffer");
+    const size_t in_bytes = c->n_clips * c->n_in * c->cfg.channels * sizeof(float);
+    AF_TRY(c->d_pcm.reserve(in_bytes));
+    AF_TRY(c->d_mel.reserve((n_out ? n_out : 1) * sizeof(float)));
+    AF_HIP(hipMemcpy(c->d_pcm.p, pcm, in_bytes, hipMemcpyHostToDevice));
+    AF_TRY(af_chain_run_device(c, c->d_pcm.as<float>(), c->d_mel.as<float>(), nullptr));
+    if (n_out) AF_HIP(hipMemcpy(mel, c->d_mel.p, n_out * sizeof(float), hipMemcpyDeviceToHost));
+    else AF_HIP(hipDeviceSynchronize());
+    return AF_OK;
+}
+
+}  // extern "C"

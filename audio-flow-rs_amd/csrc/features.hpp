@@ -48,7 +48,8 @@ struct Params {
     const float* wfrag;       // [4][kMaxSlotsW][64][4] MFMA A fragments: one float4 per lane and slot
     const int* meta;          // [4][kMaxSteps] first bin of every step (0 for padding)
     Plan plan;                // by value: lives in the kernarg segment -> scalar (SMEM) loads
-    const int64_t* pcm_off;   // [n_clips+1] first PCM frame of each clip
+    const int64_t* pcm_off;   // [n_clips] first PCM frame of each clip (spans may overlap)
+    const int64_t* pcm_len;   // [n_clips] PCM frames in each clip
     const int64_t* out_off;   // [n_clips+1] first output frame of each clip
     const int64_t* unit_off;  // [n_clips+1] first 16-frame work unit of each clip
     int64_t total_units;

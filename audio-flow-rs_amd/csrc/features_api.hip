@@ -25,7 +25,7 @@ struct af_features {
     const float* d_wfrag = nullptr;
     const int* d_meta = nullptr;
     // batch description
-    DevBuf d_tables;                 // pcm_off | out_off | unit_off, (n_clips+1) each
+    DevBuf d_tables;                 // start[n] | len[n] | out_off[n+1] | unit_off[n+1]
     size_t n_clips = 0;
     int64_t total_pcm_frames = 0;
     int64_t total_frames = 0;
@@ -157,6 +157,15 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
             plan.n_groups += 1;
         }
         plan.wave_nslots[w] = s / kSlotSteps;
+        if (std::getenv("AF_DEBUG_PLAN")) {
+            std::fprintf(stderr, "[af plan] wave %d: %d slots (%d steps):", w, plan.wave_nslots[w], s);
+            for (auto it = groups.rbegin(); it != groups.rend(); ++it) {
+                int b0, st;
+                band(it->first, it->second, b0, st);
+                std::fprintf(stderr, " mels[%d,%d) bins[%d,%d) %d steps;", 4 * it->first, std::min(4 * it->second, n_mels), b0, b0 + 4 * st, st);
+            }
+            std::fprintf(stderr, "\n");
+        }
     }
     return AF_OK;
 }
@@ -166,32 +175,38 @@ size_t bytes_per_frame(const af_features_config& c)
     return (size_t)c.channels * (c.sample_format == AF_PCM_I16 ? 2 : 4);
 }
 
-af_status upload_tables(af_features* p, const std::vector<int64_t>& pcm_off)
+// spans: clip c = PCM frames [start[c], start[c] + len[c]) of the buffer (may overlap)
+af_status upload_tables(af_features* p, const std::vector<int64_t>& start,
+                        const std::vector<int64_t>& len)
 {
     const size_t n = p->n_clips;
-    std::vector<int64_t> tab(3 * (n + 1));
-    int64_t* out_off = tab.data() + (n + 1);
-    int64_t* unit_off = tab.data() + 2 * (n + 1);
-    std::memcpy(tab.data(), pcm_off.data(), (n + 1) * sizeof(int64_t));
+    // start[n] | len[n] | out_off[n+1] | unit_off[n+1]
+    std::vector<int64_t> tab(2 * n + 2 * (n + 1));
+    int64_t* t_start = tab.data();
+    int64_t* t_len = tab.data() + n;
+    int64_t* out_off = tab.data() + 2 * n;
+    int64_t* unit_off = out_off + (n + 1);
     out_off[0] = 0;
     unit_off[0] = 0;
     const size_t bpf = bytes_per_frame(p->cfg);
     bool aligned = (p->cfg.hop * bpf) % 16 == 0;
+    int64_t end = 0;
     for (size_t c = 0; c < n; ++c) {
-        const int64_t len = pcm_off[c + 1] - pcm_off[c];
-        if (len < 0) return fail(AF_ERR_INVALID_ARG, "clip offsets must be non-decreasing");
-        const int64_t nf = (int64_t)af_features_n_frames(p, (size_t)len);
+        if (start[c] < 0 || len[c] < 0) return fail(AF_ERR_INVALID_ARG, "negative clip start or length");
+        t_start[c] = start[c];
+        t_len[c] = len[c];
+        const int64_t nf = (int64_t)af_features_n_frames(p, (size_t)len[c]);
         out_off[c + 1] = out_off[c] + nf;
         unit_off[c + 1] = unit_off[c] + (nf + kFramesPerIter - 1) / kFramesPerIter;
-        if ((pcm_off[c] * (int64_t)bpf) % 16 != 0) aligned = false;
+        if ((start[c] * (int64_t)bpf) % 16 != 0) aligned = false;
+        end = std::max(end, start[c] + len[c]);
     }
-    p->total_pcm_frames = pcm_off[n];
+    p->total_pcm_frames = end;
     p->total_frames = out_off[n];
     p->total_units = unit_off[n];
     p->offsets_aligned = aligned;
-    AF_TRY(p->d_tables.reserve(tab.size() * sizeof(int64_t)));
-    AF_HIP(hipMemcpy(p->d_tables.p, tab.data(), tab.size() * sizeof(int64_t),
-                     hipMemcpyHostToDevice));
+    AF_TRY(p->d_tables.reserve((tab.size() ? tab.size() : 1) * sizeof(int64_t)));
+    AF_HIP(hipMemcpy(p->d_tables.p, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     return AF_OK;
 }
 
@@ -296,11 +311,14 @@ af_status af_features_set_batch(af_features* p, const int64_t* clip_offsets, siz
 {
     AF_REQUIRE(p && (clip_offsets || n_clips == 0), "af_features_set_batch: null argument");
     AF_REQUIRE(n_clips < (size_t)1 << 30, "too many clips");
-    std::vector<int64_t> off(n_clips + 1, 0);
-    for (size_t c = 0; c <= n_clips && clip_offsets; ++c) off[c] = clip_offsets[c];
-    AF_REQUIRE(off[0] >= 0, "clip offsets must be non-negative");
+    std::vector<int64_t> start(n_clips), len(n_clips);
+    for (size_t c = 0; c < n_clips; ++c) {
+        start[c] = clip_offsets[c];
+        len[c] = clip_offsets[c + 1] - clip_offsets[c];
+        if (len[c] < 0) return fail(AF_ERR_INVALID_ARG, "clip offsets must be non-decreasing");
+    }
     p->n_clips = n_clips;
-    AF_TRY(upload_tables(p, off));
+    AF_TRY(upload_tables(p, start, len));
     if (total_frames_out) *total_frames_out = (size_t)p->total_frames;
     return AF_OK;
 }
@@ -310,10 +328,22 @@ af_status af_features_set_batch_uniform(af_features* p, size_t n_clips, size_t f
 {
     AF_REQUIRE(p, "af_features_set_batch_uniform: null handle");
     AF_REQUIRE(n_clips < (size_t)1 << 30, "too many clips");
-    std::vector<int64_t> off(n_clips + 1);
-    for (size_t c = 0; c <= n_clips; ++c) off[c] = (int64_t)(c * frames_per_clip);
+    std::vector<int64_t> start(n_clips), len(n_clips, (int64_t)frames_per_clip);
+    for (size_t c = 0; c < n_clips; ++c) start[c] = (int64_t)(c * frames_per_clip);
     p->n_clips = n_clips;
-    AF_TRY(upload_tables(p, off));
+    AF_TRY(upload_tables(p, start, len));
+    if (total_frames_out) *total_frames_out = (size_t)p->total_frames;
+    return AF_OK;
+}
+
+af_status af_features_set_batch_spans(af_features* p, const int64_t* starts, const int64_t* lengths,
+                                      size_t n_spans, size_t* total_frames_out)
+{
+    AF_REQUIRE(p && ((starts && lengths) || n_spans == 0), "af_features_set_batch_spans: null argument");
+    AF_REQUIRE(n_spans < (size_t)1 << 30, "too many spans");
+    std::vector<int64_t> start(starts, starts + n_spans), len(lengths, lengths + n_spans);
+    p->n_clips = n_spans;
+    AF_TRY(upload_tables(p, start, len));
     if (total_frames_out) *total_frames_out = (size_t)p->total_frames;
     return AF_OK;
 }
@@ -333,8 +363,9 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     prm.meta = p->d_meta;
     const int64_t* tab = p->d_tables.as<int64_t>();
     prm.pcm_off = tab;
-    prm.out_off = tab + (p->n_clips + 1);
-    prm.unit_off = tab + 2 * (p->n_clips + 1);
+    prm.pcm_len = tab + p->n_clips;
+    prm.out_off = tab + 2 * p->n_clips;
+    prm.unit_off = tab + 2 * p->n_clips + (p->n_clips + 1);
     prm.total_units = p->total_units;
     prm.n_clips = (int)p->n_clips;
     prm.hop = (int)p->cfg.hop;

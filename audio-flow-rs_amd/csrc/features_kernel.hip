@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
     while (u < u_end) {
         while (p.unit_off[c + 1] <= u) ++c;       // skip clips without frames
         const int64_t c_pcm0 = p.pcm_off[c];
-        const int64_t c_n = p.pcm_off[c + 1] - c_pcm0;
+        const int64_t c_n = p.pcm_len[c];
         const int64_t c_out0 = p.out_off[c];
         const int64_t c_frames = p.out_off[c + 1] - c_out0;
         const int64_t c_u1 = p.unit_off[c + 1];

@@ -208,6 +208,14 @@ af_status af_features_set_batch(af_features* p, const int64_t* clip_offsets,
 af_status af_features_set_batch_uniform(af_features* p, size_t n_clips,
                                         size_t frames_per_clip,
                                         size_t* total_frames_out);
+/* General form: span c = PCM frames [starts[c], starts[c] + lengths[c]) of the buffer.
+ * Spans may overlap: a long recording is cut into chunks of C frames (C a multiple of
+ * 16*hop) that each carry a right halo of n_fft - hop frames, so chunk k produces exactly
+ * the frames that start inside it and the chunked result equals the one-shot framing bit
+ * for bit (BASELINE config 5; resampler.rs:132-166 is the reference's carry/flush analogue). */
+af_status af_features_set_batch_spans(af_features* p, const int64_t* starts,
+                                      const int64_t* lengths, size_t n_spans,
+                                      size_t* total_frames_out);
 /* enqueue the fused kernel on `stream` for the batch set above */
 af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel_dev,
                                  void* stream);
@@ -220,6 +228,32 @@ const char* af_features_kernel_name(void);
 /* diagnostics: enable/disable in-kernel phase stamps; out[32] (optional) receives the
  * [wave][phase] shader-cycle sums recorded since they were enabled */
 af_status af_features_debug_stamps(af_features* p, int enable, unsigned long long* out);
+
+/* The whole chain of BASELINE config 4 behind one handle:
+ * interleaved PCM -> to_mono (capture.rs:30-42) -> polyphase resample -> FIR -> STFT -> mel,
+ * every stage a kernel of this library enqueued on the caller's stream.  Equal-length clips;
+ * intermediates are allocated by set_batch, so run_device only launches (hipGraph-capturable).
+ * input_rate == output_rate skips the resampler, n_fir_taps == 0 skips the FIR. */
+typedef struct af_chain af_chain;
+typedef struct {
+    uint32_t input_rate;     /* Hz of the PCM handed in */
+    uint32_t channels;       /* 1 or 2, interleaved f32 */
+    uint32_t output_rate;    /* Hz the spectrogram is computed at */
+    const float* fir_taps;   /* host pointer, copied at create; may be NULL */
+    size_t   n_fir_taps;     /* 0..1024 */
+    uint32_t hop;
+    uint32_t n_mels;
+    float    f_min, f_max;   /* f_max 0 => output_rate/2 */
+    int32_t  device;
+} af_chain_config;
+void      af_chain_default_config(af_chain_config* cfg);  /* 48 kHz stereo -> 16 kHz, no FIR, 1024/256, 80 mels */
+af_status af_chain_create(const af_chain_config* cfg, af_chain** out);
+void      af_chain_destroy(af_chain* c);
+size_t    af_chain_n_frames(const af_chain* c, size_t n_pcm_frames);
+af_status af_chain_set_batch_uniform(af_chain* c, size_t n_clips, size_t frames_per_clip,
+                                     size_t* total_frames_out);
+af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev, void* stream);
+af_status af_chain_run(af_chain* c, const float* pcm, float* mel, size_t mel_cap);
 
 #ifdef __cplusplus
 }
