@@ -19,17 +19,6 @@ constexpr int kXStride = 33;              // exchange row stride (32 + 1)
 constexpr int kHalfDw = 32 * kXStride;    // exchange region of one half-wave (1056 dwords)
 constexpr int kWbuf = 2 * kHalfDw + 8;    // per-wave LDS buffer (2120 dwords; == 8 mod 32)
 constexpr int kMaxSteps = 64;             // MFMA K-steps (4 bins each) per wave
-// ---- pair kernel (features_pair_kernel.hip): one complex FFT per wave, 8 waves per workgroup
-constexpr int kPairWaves = 8;
-constexpr int kPairThreads = 64 * kPairWaves;
-constexpr int kPairWbuf = 1060;           // per-wave LDS buffer: 32 x 33 exchange / 2 x 514 power rows; == 4 mod 32
-constexpr int kPairSteps = 24;            // MFMA K-steps per wave kept in registers (a group's K range is
-                                          // split over the wave pair w, w+4; partial tiles meet in LDS)
-constexpr int kPairSlots = kPairSteps / 4;
-constexpr int kPairMaxGroups = 7;         // partial-tile slots in LDS (1 KB each)
-constexpr int kPairWinRow = 20;           // [64 lanes][16 + 4]
-constexpr int kPairTwRow = 36;            // [64 lanes][16 (cos,sin) + 4]
-
 constexpr int kWinRow = 36;               // LDS window table row: 32 values + 4 pad
 constexpr int kTwRow = 68;                // LDS twiddle table row: 32 (cos,sin) + 4 pad
 
@@ -51,15 +40,6 @@ struct Plan {
     int slot_end[kWaves][kMaxSlotsW];
 };
 
-// Plan of the pair kernel: wave v < 4 runs the first half of the slots of every group of plan
-// wave v, wave v + 4 the second half.  slot_end: 0 = group continues, else
-// 0x10000 | first filter | filters << 8 | group id << 24 | ordinal in wave << 28 | has partner << 30.
-struct PairPlan {
-    int n_groups;
-    int nslots[kPairWaves];
-    int slot_end[kPairWaves][kPairSlots];
-};
-
 struct Params {
     const void* pcm;          // interleaved PCM (f32 or i16)
     float* mel;               // [total_frames][n_mels]
@@ -67,13 +47,7 @@ struct Params {
     const float* twtab;       // [32][kTwRow]: row n2 holds (cos, sin)(2 pi k1 n2 / 1024), k1 = 0..31
     const float* wfrag;       // [4][kMaxSlotsW][64][4] MFMA A fragments: one float4 per lane and slot
     const int* meta;          // [4][kMaxSteps] first bin of every step (0 for padding)
-    const float* pair_win;    // [64][kPairWinRow]: lane (n2,h) -> 0.5 hann[32(16h+a)+n2], a = 0..15
-    const float* pair_tw;     // [64][kPairTwRow]: lane (n2,h) -> (cos,sin)(2 pi n2 (2k'+h)/1024), k' = 0..15
-    const float* pair_xtw;    // [2][kPairTwRow]: h -> (cos,sin)(2 pi a/32) for h = 1, (1,0) for h = 0
     Plan plan;                // by value: lives in the kernarg segment -> scalar (SMEM) loads
-    PairPlan pplan;
-    const float* pair_wfrag;  // [8][kPairSlots][64][4]
-    const int* pair_meta;     // [8][kPairSteps] first bin of every step
     const int64_t* pcm_off;   // [n_clips] first PCM frame of each clip (spans may overlap)
     const int64_t* pcm_len;   // [n_clips] PCM frames in each clip
     const int64_t* out_off;   // [n_clips+1] first output frame of each clip
@@ -82,7 +56,6 @@ struct Params {
     int n_clips;
     int hop;
     int aligned16;            // every clip base and every staging unit is 16-B aligned
-    int stagger_mode, stagger_len;   // tuning
     unsigned long long* stamps;  // diagnostics only: [4 waves][8] summed phase cycles, or null
 };
 
@@ -90,9 +63,6 @@ struct Params {
 af_status launch_features(const Params& p, int channels, bool i16, int grid, size_t smem_bytes,
                           hipStream_t stream);
 size_t features_smem_bytes(int hop);
-// pair kernel (hop 256): one complex FFT per wave, 8-wave workgroups, 16 waves per CU
-af_status launch_features_pair(const Params& p, int channels, bool i16, int grid, hipStream_t stream);
-size_t features_pair_smem_bytes();
 
 }  // namespace feat
 }  // namespace af

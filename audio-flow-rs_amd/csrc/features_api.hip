@@ -5,7 +5,6 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
-#include <string>
 #include <new>
 #include <vector>
 
@@ -25,12 +24,6 @@ struct af_features {
     const float* d_twtab = nullptr;
     const float* d_wfrag = nullptr;
     const int* d_meta = nullptr;
-    const float* d_pwin = nullptr;
-    const float* d_ptw = nullptr;
-    const float* d_pxtw = nullptr;
-    const float* d_pwf = nullptr;
-    const int* d_pmeta = nullptr;
-    PairPlan pplan{};
     // batch description
     DevBuf d_tables;                 // start[n] | len[n] | out_off[n+1] | unit_off[n+1]
     size_t n_clips = 0;
@@ -38,7 +31,6 @@ struct af_features {
     int64_t total_frames = 0;
     int64_t total_units = 0;
     bool offsets_aligned = false;
-    bool pair_ok = false;            // the plan fits the pair kernel (<= kPairSlots slots per wave)
     // staging for the host-buffer entry point
     DevBuf d_pcm, d_mel;
     DevBuf d_stamps;                 // diagnostics: per-phase cycle sums (af_features_debug_stamps)
@@ -77,13 +69,9 @@ void build_mel(const af_features_config& c, double f_max, std::vector<float>& W)
 // Dynamic programming picks the groups and deals them, in order, to the 4
 // waves so that the largest per-wave step count is minimal (ties: fewest
 // steps in total).
-struct GroupInfo { int wave, m0, cnt, bin0, steps; };
-
 af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
-                     std::vector<float>& wfrag, std::vector<int>& meta,
-                     std::vector<GroupInfo>& ginfo)
+                     std::vector<float>& wfrag, std::vector<int>& meta)
 {
-    ginfo.clear();
     std::memset(&plan, 0, sizeof(plan));
     plan.n_mels = n_mels;
     const int U = (n_mels + 3) / 4;                      // units of 4 filters
@@ -164,66 +152,13 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
                 }
             }
             plan.n_steps += st;
-            ginfo.push_back(GroupInfo{w, m0, cnt, b0, st});
             s = (s + kSlotSteps - 1) / kSlotSteps * kSlotSteps;   // pad the group to a slot boundary
             plan.slot_end[w][s / kSlotSteps - 1] = 0x10000 | (cnt << 8) | m0;
             plan.n_groups += 1;
         }
         plan.wave_nslots[w] = s / kSlotSteps;
-        if (std::getenv("AF_DEBUG_PLAN")) {
-            std::fprintf(stderr, "[af plan] wave %d: %d slots (%d steps):", w, plan.wave_nslots[w], s);
-            for (auto it = groups.rbegin(); it != groups.rend(); ++it) {
-                int b0, st;
-                band(it->first, it->second, b0, st);
-                std::fprintf(stderr, " mels[%d,%d) bins[%d,%d) %d steps;", 4 * it->first, std::min(4 * it->second, n_mels), b0, b0 + 4 * st, st);
-            }
-            std::fprintf(stderr, "\n");
-        }
     }
     return AF_OK;
-}
-
-// Pair-kernel plan: split every group's K range (in 4-step slots) over the wave pair (w, w+4).
-bool build_pair_plan(const std::vector<float>& W, int n_mels, const std::vector<GroupInfo>& ginfo,
-                     PairPlan& pp, std::vector<float>& wfrag, std::vector<int>& meta)
-{
-    std::memset(&pp, 0, sizeof(pp));
-    if ((int)ginfo.size() > kPairMaxGroups) return false;
-    pp.n_groups = (int)ginfo.size();
-    wfrag.assign((size_t)kPairWaves * kPairSlots * 64 * 4, 0.0f);
-    meta.assign((size_t)kPairWaves * kPairSteps, 0);
-    int used[kPairWaves] = {0}, ord[kPairWaves] = {0};
-    for (int gid = 0; gid < (int)ginfo.size(); ++gid) {
-        const GroupInfo& g = ginfo[gid];
-        const int slots = (g.steps + kSlotSteps - 1) / kSlotSteps;
-        const int first = (slots + 1) / 2, second = slots - first;
-        for (int part = 0; part < 2; ++part) {
-            const int v = g.wave + 4 * part;
-            const int ns = part ? second : first;
-            if (ns == 0) continue;
-            if (used[v] + ns > kPairSlots) return false;
-            const int step_lo = part ? first * kSlotSteps : 0;
-            const int step_hi = std::min(g.steps, (part ? slots : first) * kSlotSteps);
-            for (int i = step_lo; i < step_hi; ++i) {
-                const int s = used[v] * kSlotSteps + (i - step_lo);
-                const int bin = g.bin0 + 4 * i;
-                meta[(size_t)v * kPairSteps + s] = bin;
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int r = lane & 15, k = bin + (lane >> 4);
-                    wfrag[(((size_t)v * kPairSlots + s / kSlotSteps) * 64 + lane) * kSlotSteps + s % kSlotSteps] =
-                        (r < g.cnt) ? W[(size_t)(g.m0 + r) * kBins + k] : 0.0f;
-                }
-            }
-            used[v] += ns;
-            if (ord[v] >= 4) return false;
-            pp.slot_end[v][used[v] - 1] = 0x10000 | g.m0 | (g.cnt << 8) | (gid << 24) | (ord[v] << 28) |
-                                          ((second > 0 ? 1 : 0) << 30);
-            ord[v] += 1;
-        }
-    }
-    for (int v = 0; v < kPairWaves; ++v) pp.nslots[v] = used[v];
-    (void)n_mels;
-    return true;
 }
 
 size_t bytes_per_frame(const af_features_config& c)
@@ -312,12 +247,7 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     build_mel(*cfg, f_max, p->W);
     std::vector<float> wfrag;
     std::vector<int> meta;
-    std::vector<GroupInfo> ginfo;
-    af_status st = build_plan(p->W, (int)cfg->n_mels, p->plan, wfrag, meta, ginfo);
-    std::vector<float> pwfrag;
-    std::vector<int> pmeta;
-    p->pair_ok = st == AF_OK && build_pair_plan(p->W, (int)cfg->n_mels, ginfo, p->pplan, pwfrag, pmeta);
-    if (!p->pair_ok) { pwfrag.assign(4, 0.0f); pmeta.assign(4, 0); }
+    af_status st = build_plan(p->W, (int)cfg->n_mels, p->plan, wfrag, meta);
     if (st != AF_OK) { delete p; return st; }
 
     // constant block: wintab [32][kWinRow] | twtab [32][kTwRow] | wfrag | meta
@@ -337,43 +267,15 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
             twtab[n2 * kTwRow + 2 * k1] = (float)std::cos(a);
             twtab[n2 * kTwRow + 2 * k1 + 1] = (float)std::sin(a);
         }
-    // pair-kernel tables (features_pair_kernel.hip): lane = 2*n2 + h
-    std::vector<float> pwin(64 * kPairWinRow, 0.0f), ptw(64 * kPairTwRow, 0.0f), pxtw(2 * kPairTwRow, 0.0f);
-    for (int lane = 0; lane < 64; ++lane) {
-        const int n2 = lane >> 1, h = lane & 1;
-        for (int a = 0; a < 16; ++a) {
-            const int i = 32 * (16 * h + a) + n2;
-            const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)kNfft);
-            pwin[lane * kPairWinRow + a] = 0.5f * (float)w;
-            const double ang = 2.0 * kPi * (double)(n2 * (2 * a + h)) / (double)kNfft;   // a plays k'
-            ptw[lane * kPairTwRow + 2 * a] = (float)std::cos(ang);
-            ptw[lane * kPairTwRow + 2 * a + 1] = (float)std::sin(ang);
-        }
-    }
-    for (int a = 0; a < 16; ++a) {
-        pxtw[2 * a] = 1.0f;                                   // h = 0: no twiddle
-        pxtw[kPairTwRow + 2 * a] = (float)std::cos(2.0 * kPi * a / 32.0);
-        pxtw[kPairTwRow + 2 * a + 1] = (float)std::sin(2.0 * kPi * a / 32.0);
-    }
     const size_t off_tw = wintab.size() * sizeof(float);
     const size_t off_wf = off_tw + twtab.size() * sizeof(float);
     const size_t off_meta = (off_wf + wfrag.size() * sizeof(float) + 15) & ~(size_t)15;
-    const size_t off_pwin = (off_meta + meta.size() * sizeof(int) + 15) & ~(size_t)15;
-    const size_t off_ptw = off_pwin + pwin.size() * sizeof(float);
-    const size_t off_pxtw = off_ptw + ptw.size() * sizeof(float);
-    const size_t off_pwf = (off_pxtw + pxtw.size() * sizeof(float) + 15) & ~(size_t)15;
-    const size_t off_pmeta = off_pwf + pwfrag.size() * sizeof(float);
-    const size_t total = off_pmeta + pmeta.size() * sizeof(int);
+    const size_t total = off_meta + meta.size() * sizeof(int);
     std::vector<char> blob(total, 0);
     std::memcpy(blob.data(), wintab.data(), off_tw);
     std::memcpy(blob.data() + off_tw, twtab.data(), twtab.size() * sizeof(float));
     std::memcpy(blob.data() + off_wf, wfrag.data(), wfrag.size() * sizeof(float));
     std::memcpy(blob.data() + off_meta, meta.data(), meta.size() * sizeof(int));
-    std::memcpy(blob.data() + off_pwin, pwin.data(), pwin.size() * sizeof(float));
-    std::memcpy(blob.data() + off_ptw, ptw.data(), ptw.size() * sizeof(float));
-    std::memcpy(blob.data() + off_pxtw, pxtw.data(), pxtw.size() * sizeof(float));
-    std::memcpy(blob.data() + off_pwf, pwfrag.data(), pwfrag.size() * sizeof(float));
-    std::memcpy(blob.data() + off_pmeta, pmeta.data(), pmeta.size() * sizeof(int));
     st = p->d_const.reserve(total);
     if (st == AF_OK && hipMemcpy(p->d_const.p, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess)
         st = fail(AF_ERR_HIP, "uploading feature tables failed");
@@ -383,11 +285,6 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     p->d_twtab = reinterpret_cast<const float*>(base + off_tw);
     p->d_wfrag = reinterpret_cast<const float*>(base + off_wf);
     p->d_meta = reinterpret_cast<const int*>(base + off_meta);
-    p->d_pwin = reinterpret_cast<const float*>(base + off_pwin);
-    p->d_ptw = reinterpret_cast<const float*>(base + off_ptw);
-    p->d_pxtw = reinterpret_cast<const float*>(base + off_pxtw);
-    p->d_pwf = reinterpret_cast<const float*>(base + off_pwf);
-    p->d_pmeta = reinterpret_cast<const int*>(base + off_pmeta);
     *out = p;
     return AF_OK;
 }
@@ -455,12 +352,6 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     prm.wfrag = p->d_wfrag;
     prm.plan = p->plan;
     prm.meta = p->d_meta;
-    prm.pair_win = p->d_pwin;
-    prm.pair_tw = p->d_ptw;
-    prm.pair_xtw = p->d_pxtw;
-    prm.pplan = p->pplan;
-    prm.pair_wfrag = p->d_pwf;
-    prm.pair_meta = p->d_pmeta;
     const int64_t* tab = p->d_tables.as<int64_t>();
     prm.pcm_off = tab;
     prm.pcm_len = tab + p->n_clips;
@@ -470,40 +361,21 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     prm.n_clips = (int)p->n_clips;
     prm.hop = (int)p->cfg.hop;
     prm.stamps = p->d_stamps.as<unsigned long long>();
-    if (const char* e = std::getenv("AF_FEATURES_STAGGER")) {
-        prm.stagger_mode = std::atoi(e);
-        const char* l = std::getenv("AF_FEATURES_STAGGER_LEN");
-        prm.stagger_len = l ? std::atoi(l) : 80;
-    }
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
-    // Two instantiations of the fused kernel: the "pair" kernel (hop 256, one complex FFT per
-    // wave, 16 waves per CU) and the general LDS-tile kernel (any hop, 8 waves per CU).
-    // AF_FEATURES_KERNEL=tile|pair overrides the choice (tuning/diagnostics).
-    bool pair = prm.hop == 256 && p->pair_ok;
-    if (const char* e = std::getenv("AF_FEATURES_KERNEL")) {
-        if (std::string(e) == "tile") pair = false;
-    }
-    int per_cu;
-    size_t smem = 0;
-    if (pair) {
-        smem = features_pair_smem_bytes();
-        per_cu = 2;
-    } else {
-        smem = features_smem_bytes(prm.hop);
-        AF_REQUIRE(smem <= 160 * 1024, "hop %d needs %zu bytes of LDS", prm.hop, smem);
-        per_cu = (int)((160 * 1024) / smem);
-        if (per_cu > 2) per_cu = 2;
-        if (per_cu < 1) per_cu = 1;
-    }
+    const size_t smem = features_smem_bytes(prm.hop);
+    AF_REQUIRE(smem <= 160 * 1024, "hop %d needs %zu bytes of LDS", prm.hop, smem);
+    // persistent grid: as many workgroups as stay resident (LDS-limited, at most 2 per CU)
+    int per_cu = (int)((160 * 1024) / smem);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
     if (const char* e = std::getenv("AF_FEATURES_WG_PER_CU")) {   // tuning/diagnostics only
         const int v = std::atoi(e);
         if (v >= 1 && v <= 8) per_cu = v;
     }
     int64_t grid = (int64_t)p->n_cus * per_cu;
     if (grid > p->total_units) grid = p->total_units;
-    const bool i16 = p->cfg.sample_format == AF_PCM_I16;
-    if (pair) return launch_features_pair(prm, (int)p->cfg.channels, i16, (int)grid, as_stream(stream));
-    return launch_features(prm, (int)p->cfg.channels, i16, (int)grid, smem, as_stream(stream));
+    return launch_features(prm, (int)p->cfg.channels, p->cfg.sample_format == AF_PCM_I16,
+                           (int)grid, smem, as_stream(stream));
 }
 
 af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t mel_cap)

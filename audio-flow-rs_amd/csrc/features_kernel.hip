@@ -23,10 +23,370 @@
 //     non-zero band of each 16-filter tile is multiplied (about 134 K-steps of 4 bins
 //     instead of 645 dense); the K-steps are split evenly over the 4 waves,
 //     partial 16x16 tiles meet in LDS and are written out coalesced.
-#include "features_dev.hpp"
+#include "features.hpp"
 
 namespace af {
 namespace feat {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ constexpr int brev5(int x)
+{
+    return ((x & 1) << 4) | ((x & 2) << 2) | (x & 4) | ((x & 8) >> 2) | ((x & 16) >> 4);
+}
+
+// cos / sin (2 pi j / 32), j = 0..15
+__device__ static constexpr float kC32[16] = {
+    1.0f, 0.980785251f, 0.923879504f, 0.831469595f, 0.707106769f, 0.555570245f,
+    0.382683426f, 0.195090324f, 0.0f, -0.195090324f, -0.382683426f, -0.555570245f,
+    -0.707106769f, -0.831469595f, -0.923879504f, -0.980785251f};
+__device__ static constexpr float kS32[16] = {
+    0.0f, 0.195090324f, 0.382683426f, 0.555570245f, 0.707106769f, 0.831469595f,
+    0.923879504f, 0.980785251f, 1.0f, 0.980785251f, 0.923879504f, 0.831469595f,
+    0.707106769f, 0.555570245f, 0.382683426f, 0.195090324f};
+
+// One decimation-in-frequency stage over 32 register-resident complex points.
+// Everything is compile-time indexed after unrolling.
+template <int SPAN>
+__device__ __forceinline__ void dif_stage(float (&re)[32], float (&im)[32])
+{
+#pragma unroll
+    for (int g = 0; g < 32; g += 2 * SPAN) {
+#pragma unroll
+        for (int j = 0; j < SPAN; ++j) {
+            const int a = g + j, b = a + SPAN;
+            const int t = j * (16 / SPAN);        // twiddle e^{-2 pi i t / 32}
+            const float ar = re[a], ai = im[a], br = re[b], bi = im[b];
+            re[a] = ar + br;
+            im[a] = ai + bi;
+            const float dr = ar - br, di = ai - bi;
+            if (t == 0) {
+                re[b] = dr;
+                im[b] = di;
+            } else if (t == 8) {                  // * (-i)
+                re[b] = di;
+                im[b] = -dr;
+            } else if (t == 4) {                  // * (1 - i)/sqrt2
+                re[b] = (dr + di) * 0.707106769f;
+                im[b] = (di - dr) * 0.707106769f;
+            } else if (t == 12) {                 // * (-1 - i)/sqrt2
+                re[b] = (di - dr) * 0.707106769f;
+                im[b] = (-dr - di) * 0.707106769f;
+            } else {                              // (dr + i di)(c - i s)
+                const float c = kC32[t], s = kS32[t];
+                re[b] = dr * c + di * s;
+                im[b] = di * c - dr * s;
+            }
+        }
+    }
+}
+
+// 32-point DFT in registers; output X[k] lands in element brev5(k).
+__device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32])
+{
+    dif_stage<16>(re, im);
+    dif_stage<8>(re, im);
+    dif_stage<4>(re, im);
+    dif_stage<2>(re, im);
+    dif_stage<1>(re, im);
+}
+
+// LDS traffic inside one wave needs no s_barrier (a wave's DS operations are
+// executed in order); this only stops the compiler from moving LDS accesses
+// across the hand-off.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------
+// PCM staging: one 16-byte unit of interleaved PCM -> MS mono samples.
+// to_mono semantics (capture.rs:34-40): sequential f32 sum over the channels,
+// then divided by the channel count (x0.5 is exact for stereo).
+// i16 samples are scaled by 1/32768 (docs/OPS.md "PCM formats").
+template <int CH, bool I16>
+struct Stage {
+    static constexpr int kBytesPerFrame = CH * (I16 ? 2 : 4);
+    static constexpr int MS = 16 / kBytesPerFrame;   // mono samples per 16-B unit
+
+    __device__ static __forceinline__ float sample(const void* pcm, int64_t elem)
+    {
+        if (I16) return (float)static_cast<const int16_t*>(pcm)[elem] * (1.0f / 32768.0f);
+        return static_cast<const float*>(pcm)[elem];
+    }
+
+    // the 16 raw bytes holding mono samples [pos, pos+MS) of a clip whose first
+    // frame is `base` and which has `n` frames; zero beyond the end of the clip.
+    // No arithmetic here, so a prefetch does not have to wait for its data.
+    __device__ static __forceinline__ uint4 load_raw(const void* pcm, int64_t base, int64_t pos,
+                                                     int64_t n, bool aligned)
+    {
+        if (aligned && pos + MS <= n)
+            return *reinterpret_cast<const uint4*>(static_cast<const char*>(pcm) +
+                                                   (base + pos) * kBytesPerFrame);
+        uint32_t r[4] = {0u, 0u, 0u, 0u};
+        constexpr int E = I16 ? 8 : 4;                 // elements in 16 bytes
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (pos + e / CH < n) {
+                const int64_t idx = (base + pos) * CH + e;
+                if constexpr (I16)
+                    r[e >> 1] |= (uint32_t)static_cast<const uint16_t*>(pcm)[idx] << (16 * (e & 1));
+                else
+                    r[e] = static_cast<const uint32_t*>(pcm)[idx];
+            }
+        }
+        return uint4{r[0], r[1], r[2], r[3]};
+    }
+
+    // raw bytes -> mono samples
+    __device__ static __forceinline__ void convert(const uint4 raw, float (&m)[MS])
+    {
+        const uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
+        if constexpr (!I16) {
+            float f[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(r[i]);
+            if constexpr (CH == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i] = f[i];
+            } else {
+                m[0] = (f[0] + f[1]) * 0.5f;
+                m[1] = (f[2] + f[3]) * 0.5f;
+            }
+        } else {
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f[2 * i] = (float)(int16_t)(r[i] & 0xffffu) * (1.0f / 32768.0f);
+                f[2 * i + 1] = (float)(int16_t)(r[i] >> 16) * (1.0f / 32768.0f);
+            }
+            if constexpr (CH == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) m[i] = f[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i] = (f[2 * i] + f[2 * i + 1]) * 0.5f;
+            }
+        }
+    }
+
+    __device__ static __forceinline__ void load(const void* pcm, int64_t base, int64_t pos,
+                                                int64_t n, bool aligned, float (&m)[MS])
+    {
+        convert(load_raw(pcm, base, pos, n, aligned), m);
+    }
+
+    __device__ static __forceinline__ void store(float* dst, const float (&m)[MS])
+    {
+#pragma unroll
+        for (int i = 0; i < MS; ++i) dst[i] = m[i];
+    }
+};
+
+// ---------------------------------------------------------------------------
+// FFT phase of one wave: 4 frames (two per half-wave) -> 4 power rows in LDS.
+// Part A: window, first radix-32, twiddles, transpose through LDS -> ur/ui hold the
+// second stage's inputs.  Part B: second radix-32, spectrum split, power rows.
+template <int HOP_T>
+__device__ __forceinline__ void fft_phase_a(const float* __restrict__ tile, float* wbuf, int hop,
+                                            int w, int lane, const float* __restrict__ wtab,
+                                            const float* __restrict__ ttab, float (&ur)[32],
+                                            float (&ui)[32])
+{
+    const int half = lane >> 5, n2 = lane & 31;
+    const int fa = 4 * w + 2 * half;              // first frame of this half's pair
+    float re[32], im[32];
+    {
+        // window column of this lane: 0.5 * hann[32 n1 + n2], n1 = 0..31 (8 x ds_read_b128)
+        float win[32];
+        const float4* wrow = reinterpret_cast<const float4*>(wtab + n2 * kWinRow);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 v = wrow[j];
+            win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
+        }
+        const float* src = tile + fa * hop + n2;
+        if constexpr (HOP_T != 0 && HOP_T % 32 == 0) {
+            // frame b = frame a shifted by HOP_T samples = SH registers
+            constexpr int SH = HOP_T / 32;
+            float s[32 + SH];
+#pragma unroll
+            for (int j = 0; j < 32 + SH; ++j) s[j] = src[32 * j];
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                re[n1] = s[n1] * win[n1];
+                im[n1] = s[n1 + SH] * win[n1];
+            }
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                re[n1] = src[32 * n1] * win[n1];
+                im[n1] = src[hop + 32 * n1] * win[n1];
+            }
+        }
+    }
+
+    fft32(re, im);                                // over n1 -> Y[k1] at brev5(k1)
+
+    // inter-stage twiddle e^{-2 pi i n2 k1 / 1024}; row n2 of the LDS table holds
+    // (cos, sin) for k1 = 0..31, two k1 per ds_read_b128
+    {
+        const float4* trow = reinterpret_cast<const float4*>(ttab + n2 * kTwRow);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 t = trow[j];
+            if (j > 0) {
+                const int r = brev5(2 * j);
+                const float xr = re[r], xi = im[r];
+                re[r] = xr * t.x + xi * t.y;
+                im[r] = xi * t.x - xr * t.y;
+            }
+            const int r = brev5(2 * j + 1);
+            const float xr = re[r], xi = im[r];
+            re[r] = xr * t.z + xi * t.w;
+            im[r] = xi * t.z - xr * t.w;
+        }
+    }
+
+    // transpose (k1, n2) through LDS, real parts then imaginary parts
+    float* xb = wbuf + half * kHalfDw;
+#pragma unroll
+    for (int k1 = 0; k1 < 32; ++k1) xb[k1 * kXStride + n2] = re[brev5(k1)];
+    wave_sync();
+#pragma unroll
+    for (int n = 0; n < 32; ++n) ur[n] = xb[n2 * kXStride + n];
+    wave_sync();
+#pragma unroll
+    for (int k1 = 0; k1 < 32; ++k1) xb[k1 * kXStride + n2] = im[brev5(k1)];
+    wave_sync();
+#pragma unroll
+    for (int n = 0; n < 32; ++n) ui[n] = xb[n2 * kXStride + n];
+    wave_sync();
+
+}
+
+__device__ __forceinline__ void fft_phase_b(float* wbuf, int lane, float (&ur)[32], float (&ui)[32])
+{
+    const int half = lane >> 5, n2 = lane & 31;
+    float* xb = wbuf + half * kHalfDw;
+    fft32(ur, ui);                                // over n2 -> Z[k1 + 32 k2] at brev5(k2)
+
+    // Split the packed spectrum: A[k] = (Z[k] + conj Z[N-k])/2 (frame a),
+    // B[k] = (Z[k] - conj Z[N-k])/(2i) (frame b); the 1/2 is folded into the
+    // window table.  Lane k1 needs Z[N-k] = lane (32-k1)%32, k2' = 31-q
+    // (lane 0: k2' = (32-q)%32).  Publish k2 in {0,16..31} -> slots {0,1..16}.
+    const int k1 = n2;
+    const int d = (k1 == 0) ? 1 : 0;
+    float* mine = xb + k1 * kXStride;
+    const float* theirs = xb + ((32 - k1) & 31) * kXStride + d;
+    const int first = d ? 0 : 16;                 // slot of the q = 0 partner
+    float pr[17], pi[17];
+
+    mine[0] = ur[brev5(0)];
+#pragma unroll
+    for (int k2 = 16; k2 < 32; ++k2) mine[k2 - 15] = ur[brev5(k2)];
+    wave_sync();
+    pr[0] = xb[((32 - k1) & 31) * kXStride + first];
+#pragma unroll
+    for (int q = 1; q <= 16; ++q) pr[q] = theirs[16 - q];
+    wave_sync();
+    mine[0] = ui[brev5(0)];
+#pragma unroll
+    for (int k2 = 16; k2 < 32; ++k2) mine[k2 - 15] = ui[brev5(k2)];
+    wave_sync();
+    pi[0] = xb[((32 - k1) & 31) * kXStride + first];
+#pragma unroll
+    for (int q = 1; q <= 16; ++q) pi[q] = theirs[16 - q];
+    wave_sync();
+
+    float* prow_a = wbuf + (2 * half) * kProw + k1;
+    float* prow_b = prow_a + kProw;
+#pragma unroll
+    for (int q = 0; q <= 16; ++q) {
+        const float zr = ur[brev5(q)], zi = ui[brev5(q)];
+        const float a1 = zr + pr[q], a2 = zi - pi[q];
+        const float b1 = zi + pi[q], b2 = zr - pr[q];
+        const float pa = a1 * a1 + a2 * a2;
+        const float pb = b1 * b1 + b2 * b2;
+        if (q < 16) {
+            prow_a[32 * q] = pa;
+            prow_b[32 * q] = pb;
+        } else if (k1 == 0) {                     // Nyquist bin 512
+            prow_a[512] = pa;
+            prow_b[512] = pb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// mel phase: this wave's filter groups, banded W (A operand, in registers) times
+// P^T (B operand, bins x 16 frames from LDS) on v_mfma_f32_16x16x4_f32.  All B
+// operands of the unit are fetched up front so the MFMA chain never waits on LDS.
+// Steps come in slots of 8 (branch-free); when a slot ends a group, the 16 frames
+// x <=16 filters accumulator goes straight to HBM: lane (frame j, quarter kq)
+// owns filters 4kq..4kq+3 of the group = one 16-byte store.
+template <bool STAMPS>
+__device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restrict__ lmeta,
+                                          const float (&wf)[kMaxSteps], int n_slots,
+                                          const int (&slot_end)[kMaxSlotsW],
+                                          float* __restrict__ orow, bool fvalid, bool vec_ok,
+                                          int lane, unsigned long long (&acc_t)[8],
+                                          unsigned long long& t_prev)
+{
+    const int f = lane & 15, kq = lane >> 4;
+    const float* pbase = wbufs + (f >> 2) * kWbuf + (f & 3) * kProw + kq;
+    // Branch-free on purpose: one batch of broadcast reads for the bin offsets, one
+    // batch of operand reads (padding steps read bin 0 and multiply it by zero weights).
+    float b[kMaxSteps];
+    {
+        int meta[kMaxSteps];
+#pragma unroll
+        for (int s = 0; s < kMaxSteps; ++s) meta[s] = lmeta[s];
+#pragma unroll
+        for (int s = 0; s < kMaxSteps; ++s) b[s] = pbase[meta[s]];
+    }
+    if constexpr (STAMPS) {                       // diagnostics: operands landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        acc_t[5] += t - t_prev;
+        t_prev = t;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < kMaxSlotsW; ++q) {
+        if (q < n_slots) {
+#pragma unroll
+            for (int s = q * kSlotSteps; s < (q + 1) * kSlotSteps; s += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], b[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s + 1], b[s + 1], acc1, 0, 0, 0);
+            }
+            const int e = slot_end[q];            // wave-uniform (kernarg)
+            if (e != 0) {
+                const f32x4 r = acc0 + acc1;
+                acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int m0 = e & 255, cnt = (e >> 8) & 31;
+                const int i0 = 4 * kq;            // first filter of this lane in the group
+                float* o = orow + m0 + i0;
+                if (vec_ok && (cnt & 3) == 0) {   // wave-uniform choice
+                    if (fvalid && i0 < cnt)
+                        *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
+                } else if (fvalid) {
+                    if (i0 < cnt) o[0] = r[0];
+                    if (i0 + 1 < cnt) o[1] = r[1];
+                    if (i0 + 2 < cnt) o[2] = r[2];
+                    if (i0 + 3 < cnt) o[3] = r[3];
+                }
+            }
+        }
+    }
+}
 
 // Diagnostics (Params::stamps != null only): per-phase cycle sums of every wave.
 #define AF_STAMP(i)                                                         \
@@ -97,10 +457,6 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         }
         c = lo;
     }
-    // experimental stagger (AF_FEATURES_STAGGER): delay a subset of workgroups by about half a
-    // unit so that co-resident workgroups alternate VALU-heavy and MFMA/barrier phases
-    if (p.stagger_mode == 1 && (blockIdx.x & 1)) for (int i = 0; i < p.stagger_len; ++i) __builtin_amdgcn_s_sleep(64);
-    if (p.stagger_mode == 2 && blockIdx.x >= gridDim.x / 2) for (int i = 0; i < p.stagger_len; ++i) __builtin_amdgcn_s_sleep(64);
     bool fresh = true;
 
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -216,8 +572,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         {
             const int j = lane & 15;
             float* orow = p.mel + (c_out0 + F0 + j) * n_mels;
-            const float* pbase = wbufs + (j >> 2) * kWbuf + (j & 3) * kProw + (lane >> 4);
-            mel_phase<kMaxSteps, STAMPS>(pbase, lmeta + w * kMaxSteps, wf, n_slots_w, slot_end_w, orow, F0 + j < c_frames,
+            mel_phase<STAMPS>(wbufs, lmeta + w * kMaxSteps, wf, n_slots_w, slot_end_w, orow, F0 + j < c_frames,
                               vec_ok, lane, acc_t, t_prev);
         }
         AF_STAMP(6);
