@@ -28,12 +28,12 @@ from .errors import AudioError
 from .audio import (AudioFrame, AudioResampler, BatchResampler, ChainPipeline, FeaturePipeline, FirFilter,
                     MelSpectrogram, MessageBuilder, RingBuffer, VadConfig, VadLevel, VadState,
                     VoiceActivityDetector, device_count, library, quantize_pcm16, to_mono,
-                    vad_energy, resample_batch, fir_batch)
+                    vad_energy, resample_batch, fir_batch, AudioLevel, level_meter)
 
 __all__ = [
     "AudioError", "AudioFrame", "AudioResampler", "BatchResampler", "ChainPipeline", "FeaturePipeline",
     "FirFilter",
     "MelSpectrogram", "MessageBuilder", "RingBuffer", "VadConfig", "VadLevel", "VadState",
     "VoiceActivityDetector", "device_count", "library", "quantize_pcm16", "to_mono", "vad_energy",
-    "resample_batch", "fir_batch",
+    "resample_batch", "fir_batch", "AudioLevel", "level_meter",
 ]

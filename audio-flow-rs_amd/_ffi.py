@@ -66,6 +66,8 @@ SIGNATURES = {
     # VAD
     "af_vad_energy": (_st, [_vp, _sz, _sz, _vp]),
     "af_vad_energy_device": (_st, [_vp, _sz, _sz, _vp, _vp]),
+    "af_level_meter": (_st, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    "af_level_meter_device": (_st, [_vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     "af_vad_default_config": (None, [C.POINTER(VadConfig)]),
     "af_vad_create": (_st, [C.POINTER(VadConfig), C.POINTER(_vp)]),
     "af_vad_destroy": (None, [_vp]),

@@ -72,6 +72,24 @@ def vad_energy(frames, frame_len: int) -> np.ndarray:
     return out
 
 
+@dataclass
+class AudioLevel:
+    """specs/0002-design.md:727-732"""
+    rms: float
+    peak: float
+    dbfs: float
+
+
+def level_meter(samples, window_len: int) -> List[AudioLevel]:
+    """rms / peak / dBFS of consecutive windows (the ``audio_level`` event payload,
+    events/mod.rs:73-75; spec'd every 50 ms = 800 samples at 16 kHz)."""
+    x = _f32(samples)
+    n = x.size // window_len if window_len else 0
+    rms, peak, dbfs = (np.empty(max(n, 1), np.float32) for _ in range(3))
+    _check(library().af_level_meter(_ptr(x), n, window_len, _ptr(rms), _ptr(peak), _ptr(dbfs)))
+    return [AudioLevel(float(rms[i]), float(peak[i]), float(dbfs[i])) for i in range(n)]
+
+
 def resample_batch(clips, input_rate: int, output_rate: int) -> np.ndarray:
     """One-shot polyphase resample of equal-length mono clips ``[n_clips, n_in]``."""
     x = np.ascontiguousarray(clips, np.float32)

@@ -4,6 +4,7 @@
 //   VAD energy     modules/audio/vad.rs:157-168
 // All are pure streaming kernels: 16-byte loads/stores per lane, grid-stride
 // over at most 2048 workgroups, no LDS except the wave reduction of the energy.
+#include <cmath>
 #include <vector>
 
 #include "af_common.hpp"
@@ -162,6 +163,38 @@ __global__ void vad_energy_kernel(const float* __restrict__ in, size_t n_frames,
     }
 }
 
+// ---- level meter --------------------------------------------------------------
+// AudioLevel{rms, peak, dbfs} per window (specs/0002-design.md:727-732; payload of the
+// audio_level event, events/mod.rs:73-75,112-115).  One wave64 per window.
+__global__ void level_meter_kernel(const float* __restrict__ in, size_t n_windows, size_t window_len,
+                                   float* __restrict__ rms, float* __restrict__ peak,
+                                   float* __restrict__ dbfs)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t f = wave; f < n_windows; f += n_waves) {
+        const float* x = in + f * window_len;
+        float s = 0.0f, m = 0.0f;
+        for (size_t i = lane; i < window_len; i += 64) {
+            const float v = x[i];
+            s += v * v;
+            m = fmaxf(m, fabsf(v));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s += __shfl_xor(s, off, 64);
+            m = fmaxf(m, __shfl_xor(m, off, 64));
+        }
+        if (lane == 0) {
+            const float r = window_len ? sqrtf(s / (float)window_len) : 0.0f;
+            rms[f] = r;
+            peak[f] = m;
+            dbfs[f] = r > 0.0f ? 20.0f * log10f(r) : -INFINITY;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace af
 
@@ -305,6 +338,43 @@ af_status af_vad_energy(const float* in, size_t n_frames, size_t frame_len, floa
     if (n) AF_HIP(hipMemcpy(din.p, in, n * sizeof(float), hipMemcpyHostToDevice));
     AF_TRY(af_vad_energy_device(din.as<float>(), n_frames, frame_len, dout.as<float>(), nullptr));
     AF_HIP(hipMemcpy(energy_out, dout.p, n_frames * sizeof(float), hipMemcpyDeviceToHost));
+    return AF_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+af_status af_level_meter_device(const float* in_dev, size_t n_windows, size_t window_len,
+                                float* rms_dev, float* peak_dev, float* dbfs_dev, void* stream)
+{
+    if (n_windows == 0) return AF_OK;
+    AF_REQUIRE(rms_dev && peak_dev && dbfs_dev && (in_dev || window_len == 0), "level_meter: null buffer");
+    size_t g = (n_windows * 64 + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(level_meter_kernel, dim3((int)g), dim3(kBlock), 0, as_stream(stream), in_dev,
+                       n_windows, window_len, rms_dev, peak_dev, dbfs_dev);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+af_status af_level_meter(const float* in, size_t n_windows, size_t window_len, float* rms,
+                         float* peak, float* dbfs)
+{
+    if (n_windows == 0) return AF_OK;
+    AF_REQUIRE(rms && peak && dbfs && (in || window_len == 0), "level_meter: null buffer");
+    AF_TRY(ensure_device(-1));
+    DevBuf din, dout;
+    const size_t n = n_windows * window_len;
+    AF_TRY(din.reserve(n * sizeof(float)));
+    AF_TRY(dout.reserve(3 * n_windows * sizeof(float)));
+    if (n) AF_HIP(hipMemcpy(din.p, in, n * sizeof(float), hipMemcpyHostToDevice));
+    float* o = dout.as<float>();
+    AF_TRY(af_level_meter_device(din.as<float>(), n_windows, window_len, o, o + n_windows,
+                                 o + 2 * n_windows, nullptr));
+    AF_HIP(hipMemcpy(rms, o, n_windows * sizeof(float), hipMemcpyDeviceToHost));
+    AF_HIP(hipMemcpy(peak, o + n_windows, n_windows * sizeof(float), hipMemcpyDeviceToHost));
+    AF_HIP(hipMemcpy(dbfs, o + 2 * n_windows, n_windows * sizeof(float), hipMemcpyDeviceToHost));
     return AF_OK;
 }
 

@@ -192,6 +192,20 @@ inline std::vector<int16_t> quantize_pcm16(const std::vector<float>& audio)
     return out;
 }
 
+// specs/0002-design.md:727-732 (payload of the audio_level event, events/mod.rs:73-75)
+struct AudioLevel {
+    float rms, peak, dbfs;
+};
+inline std::vector<AudioLevel> level_meter(const std::vector<float>& samples, size_t window_len)
+{
+    const size_t n = window_len ? samples.size() / window_len : 0;
+    std::vector<float> r(n), p(n), d(n);
+    detail::check(af_level_meter(samples.data(), n, window_len, r.data(), p.data(), d.data()));
+    std::vector<AudioLevel> out(n);
+    for (size_t i = 0; i < n; ++i) out[i] = {r[i], p[i], d[i]};
+    return out;
+}
+
 // build-defined siblings (docs/OPS.md)
 class FirFilter {
 public:

@@ -84,6 +84,15 @@ af_status af_vad_energy(const float* in, size_t n_frames, size_t frame_len,
 af_status af_vad_energy_device(const float* in_dev, size_t n_frames, size_t frame_len,
                                float* energy_dev, void* stream);
 
+/* Level meter [B]: AudioLevel{rms, peak, dbfs} of specs/0002-design.md:727-732 (the payload
+ * of the `audio_level` event, events/mod.rs:73-75,112-115; spec'd every 50 ms,
+ * specs/0001-spec.md:457) for n_windows consecutive windows of window_len samples:
+ * rms = sqrt(mean x^2), peak = max |x|, dbfs = 20 log10(rms) (-inf for silence). */
+af_status af_level_meter(const float* in, size_t n_windows, size_t window_len,
+                         float* rms, float* peak, float* dbfs);
+af_status af_level_meter_device(const float* in_dev, size_t n_windows, size_t window_len,
+                                float* rms_dev, float* peak_dev, float* dbfs_dev, void* stream);
+
 /* VoiceActivityDetector, vad.rs:21-43 (config), :80 new, :97 detect,
  * :179 reset.  detect() runs the energy reduction on the device and the
  * EMA / dBFS / 3-state machine (vad.rs:102-151) on the host. */

@@ -396,6 +396,19 @@ void afo_dft_power_naive_f64(const float* x, size_t n_fft, const double* w,
     }
 }
 
+void afo_level_meter_f64(const float* x, size_t n, double* rms, double* peak, double* dbfs)
+{
+    double s = 0.0, m = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        double v = (double)x[i];
+        s += v * v;
+        if (fabs(v) > m) m = fabs(v);
+    }
+    *rms = n ? sqrt(s / (double)n) : 0.0;
+    *peak = m;
+    *dbfs = *rms > 0.0 ? 20.0 * log10(*rms) : -INFINITY;
+}
+
 double afo_hz_to_mel_htk(double hz) { return 2595.0 * log10(1.0 + hz / 700.0); }
 double afo_mel_to_hz_htk(double mel) { return 700.0 * (pow(10.0, mel / 2595.0) - 1.0); }
 

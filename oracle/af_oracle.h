@@ -133,6 +133,10 @@ void   afo_stft_power_f64(const float* x, size_t n, size_t n_fft, size_t hop,
 void   afo_dft_power_naive_f64(const float* x, size_t n_fft, const double* w,
                                double* power);
 
+/* docs/OPS.md "Level meter": rms = sqrt(mean x^2), peak = max|x|, dbfs = 20 log10(rms)
+ * (float64; specs/0002-design.md:727-732). */
+void afo_level_meter_f64(const float* x, size_t n, double* rms, double* peak, double* dbfs);
+
 /* docs/OPS.md "Mel filterbank": HTK mel, triangular, no area normalisation.
  * W[n_mels][n_fft/2+1]. */
 double afo_hz_to_mel_htk(double hz);

@@ -91,6 +91,8 @@ _res32 = _sig("afo_resample_f32", None, _f32p, C.c_size_t, _f32p, C.c_uint32, C.
               C.c_uint32, C.c_size_t, C.c_size_t, _f32p)
 _fir64 = _sig("afo_fir_f64", None, _f32p, C.c_size_t, _f32p, C.c_size_t, _f64p)
 _fir32 = _sig("afo_fir_f32", None, _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p)
+_level = _sig("afo_level_meter_f64", None, _f32p, C.c_size_t, C.POINTER(C.c_double),
+             C.POINTER(C.c_double), C.POINTER(C.c_double))
 _nframes = _sig("afo_stft_n_frames", C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t)
 _hann = _sig("afo_hann_periodic", None, C.c_size_t, _f64p)
 _stft = _sig("afo_stft_power_f64", None, _f32p, C.c_size_t, C.c_size_t, C.c_size_t, _f64p)
@@ -269,6 +271,13 @@ def fir_f32(x, h) -> np.ndarray:
     y = np.empty(x.size, np.float32)
     _fir32(x, x.size, h, h.size, y)
     return y
+
+
+def level_meter(window):
+    x = _f32(window).ravel()
+    r, p, d = C.c_double(), C.c_double(), C.c_double()
+    _level(x, x.size, C.byref(r), C.byref(p), C.byref(d))
+    return r.value, p.value, d.value
 
 
 def stft_n_frames(n: int, n_fft: int = 1024, hop: int = 256) -> int:

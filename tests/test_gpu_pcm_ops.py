@@ -139,3 +139,20 @@ def test_vad_state_sequence_vs_oracle(af, po):
     assert got == want
     assert {0, 1, 2} <= set(got)                   # the sequence exercises all three states
     assert v.speech_frame_count() == o.speech_frames
+
+
+# ---- level meter (specs/0002-design.md:727-732) ------------------------------------------------
+@pytest.mark.parametrize("window", [1, 64, 800, 2400])
+def test_level_meter_vs_oracle(af, po, window):
+    x = synth_clip(41, window * 23, 1, 16000)
+    x[:window] = 0.0                                     # a silent window: dbfs = -inf
+    got = af.level_meter(x, window)
+    assert len(got) == 23
+    for i, lv in enumerate(got):
+        r, p, d = po.level_meter(x[i * window:(i + 1) * window])
+        assert abs(lv.rms - r) <= 1e-6 * max(r, 1e-30)
+        assert lv.peak == np.float32(p)                  # max |x| is exact
+        if r == 0.0:
+            assert lv.dbfs == float("-inf")
+        else:
+            assert abs(lv.dbfs - d) < 1e-4

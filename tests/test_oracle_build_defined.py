@@ -152,3 +152,13 @@ def test_empty_and_short_inputs(po):
     assert po.features(np.zeros(2000, np.float32), 2, 48000.0).shape == (0, 80)
     assert po.resample(np.zeros(0, np.float32), 48000, 16000).size == 0
     assert po.fir(np.zeros(0, np.float32), [1.0]).size == 0
+
+
+def test_level_meter_oracle(po):
+    r, p, d = po.level_meter(np.full(800, 0.5, np.float32))
+    assert abs(r - 0.5) < 1e-12 and p == 0.5 and abs(d - 20 * np.log10(0.5)) < 1e-12
+    r, p, d = po.level_meter(np.zeros(10, np.float32))
+    assert r == 0.0 and p == 0.0 and d == float("-inf")
+    x = np.array([0.1, -0.9, 0.3], np.float32)
+    r, p, d = po.level_meter(x)
+    assert abs(r - np.sqrt(np.mean(x.astype(np.float64) ** 2))) < 1e-15 and p == float(np.float32(0.9))
