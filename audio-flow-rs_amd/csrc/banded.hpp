@@ -1,0 +1,54 @@
+// banded.hpp -- the polyphase resampler and the FIR as one banded matrix product on MFMA.
+//
+// Both filters are  y[m] = sum_{k<T} proto[r(m) + k L] * x[q(m) + c - k],
+//   q(m) = floor(m M / L), r(m) = m M mod L
+// (docs/OPS.md "Polyphase resampler": c = T/2; "FIR": L = M = 1, c = 0, proto = taps).
+//
+// 16 consecutive outputs m = 16 b + i read one window of x that is only
+// W = T + floor((r(16b) + 15 M) / L) samples wide, so they are a [16 x W] banded matrix
+// A_p (p = b mod nb, nb = L / gcd(16, L) distinct matrices) times the window.  16 blocks of
+// the same p, one "block period" (S = 16 M / gcd(16, L) input samples) apart, are the 16
+// columns of one v_mfma_f32_16x16x4_f32 chain of NK = ceil(W / 4) steps.  A_p stays in the
+// wave's registers for the whole launch, the windows come from LDS, one ds_read_b32 per MFMA.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "af_common.hpp"
+
+namespace af {
+namespace banded {
+
+struct Plan {
+    bool ok = false;          // false: shape not covered, the caller runs its VALU kernel
+    uint32_t L = 1, M = 1;
+    int T = 0;                // taps per phase
+    int c = 0;                // x offset of tap 0
+    int nb = 0;               // distinct block matrices
+    int S = 0;                // input samples per block period
+    int NK = 0;               // MFMA steps per chain (template instance)
+    int wpp = 0;              // waves sharing one block matrix
+    int nwaves = 0;           // nb * wpp
+    int G = 0;                // block periods per column and tile
+    int seg_len = 0;          // floats of x per column segment
+    int seg_stride = 0;       // odd, >= seg_len
+    int64_t out_per_tile = 0; // 256 * G * nb
+    size_t smem = 0;
+    size_t afrag_floats() const { return (size_t)nb * NK * 64; }
+};
+
+// Decide whether (L, M, T) runs on the MFMA kernel and with which tile shape.
+Plan make_plan(uint32_t L, uint32_t M, int T, int c);
+
+// Gather the A fragments [nb][NK][64] from the prototype (device, prototype order, L*T floats).
+af_status build_afrag(const Plan& p, const float* proto_dev, float* afrag_dev, hipStream_t stream);
+
+// Outputs m in [m0, m0 + n_out) of every clip; x[0] of a clip has absolute index x_abs0,
+// samples outside [x_abs0, x_abs0 + x_len) read as zero.  The tile grid is anchored at
+// absolute output 0, so a sample's summation order does not depend on m0 / chunking.
+af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int64_t x_abs0,
+                 int64_t x_len, int64_t x_stride, float* y_dev, int64_t y_stride, int64_t m0,
+                 int64_t n_out, int64_t n_clips, hipStream_t stream);
+
+}  // namespace banded
+}  // namespace af

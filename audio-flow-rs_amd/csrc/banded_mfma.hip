@@ -1,0 +1,298 @@
+// banded_mfma.hip -- see banded.hpp.  One workgroup = nwaves waves; wave w owns block matrix
+// p = w / wpp (its NK A fragments live in registers for the whole launch) and the block
+// periods g in [gsub * gpw, (gsub + 1) * gpw) of every column.  A tile is 16 columns, each a
+// private LDS segment of G block periods of x (+ the window halo) with an odd stride, so the
+// 16 columns x 2 k-groups of a ds_read_b32 lane group fall into 32 different banks.
+//
+// k-slot mapping: MFMA step t, k-group g4 = lane / 16 reads window sample
+//   w(t, g4) = 64 (t / 16) + t % 16 + 16 g4      for the NK / 16 full 16-step chunks,
+//   w(t, g4) = 64 FULL + (t - 16 FULL) + TAILQ g4  for the TAILQ = NK % 16 tail steps,
+// i.e. the two k-groups of a lane group are 16 samples apart (bank-conflict free with an odd
+// column stride).  The A fragments are gathered with the same mapping (build_afrag_kernel).
+#include <cstdlib>
+#include <numeric>
+
+#include "banded.hpp"
+
+namespace af {
+namespace banded {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCols = 16;
+constexpr int kPfSlots = 2;          // x prefetch registers per column and thread
+constexpr int kMaxSeg = 1000;        // floats per column segment (16 segments <= 64 KB)
+
+struct Geom {
+    const float* x;
+    float* y;
+    const float* afrag;
+    int64_t x_abs0, x_len, x_stride, y_stride, m0, n_out;
+    int64_t tile0;                   // absolute index of the first tile of every clip
+    int64_t tiles_per_clip, n_tiles;
+    uint32_t L, M;
+    int lo_off;                      // c - (T - 1): first window sample relative to q(16 b)
+    int nb, S, G, wpp, gpw, seg_len, seg_stride;
+};
+
+__device__ __forceinline__ int w_of(int t, int g4, int nk)
+{
+    const int full = nk / 16, tailq = nk % 16;
+    return t < 16 * full ? 64 * (t / 16) + (t % 16) + 16 * g4 : 64 * full + (t - 16 * full) + tailq * g4;
+}
+
+__global__ void build_afrag_kernel(const float* __restrict__ proto, float* __restrict__ afrag,
+                                   uint32_t L, uint32_t M, int T, int nb, int nk)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nb * nk * 64) return;
+    const int lane = idx & 63, t = (idx >> 6) % nk, p = (idx >> 6) / nk;
+    const int i = lane & 15, g4 = lane >> 4;
+    const uint64_t r0 = ((uint64_t)16 * p * M) % L;
+    const uint64_t pos = r0 + (uint64_t)i * M;           // = r_i + d_i L
+    const int d = (int)(pos / L);
+    const uint32_t r = (uint32_t)(pos % L);
+    const int k = d + (T - 1) - w_of(t, g4, nk);
+    afrag[idx] = (k >= 0 && k < T) ? proto[(size_t)r + (size_t)k * L] : 0.0f;
+}
+
+// A zero the compiler cannot see through: offsets derived from it are recomputed where they
+// are used instead of being hoisted out of the tile loop into 30+ live registers.
+__device__ __forceinline__ int opaque_zero()
+{
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+
+template <int NK>
+__global__ __launch_bounds__(1024) void banded_kernel(const Geom g)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    constexpr int FULL = NK / 16, TAILQ = NK % 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nthreads = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = wave / g.wpp, gsub = wave - p * g.wpp;
+    const int qp = (int)(((int64_t)16 * p * g.M) / g.L);      // q(16 p)
+
+    float a[NK];
+#pragma unroll
+    for (int t = 0; t < NK; ++t) a[t] = g.afrag[((size_t)p * NK + t) * 64 + lane];
+
+    const int col = lane & 15, g4 = lane >> 4;
+    const int wave_off = qp + gsub * g.gpw * g.S;
+    const int base_full = col * g.seg_stride + 16 * g4 + wave_off;
+    const int base_tail = col * g.seg_stride + TAILQ * g4 + 64 * FULL + wave_off;
+    // this lane's outputs: rows 4 g4 .. 4 g4 + 3 of block (p, column col, period g)
+    const int out_lane = 16 * (p + g.nb * (col * g.G + gsub * g.gpw)) + 4 * g4;
+    const int out_step = 16 * g.nb;                             // per block period
+    const int64_t out_per_tile = (int64_t)256 * g.G * g.nb;
+    const int col_span = g.G * g.S;
+
+    float pf[kCols * kPfSlots];
+    auto load_tile = [&](int64_t tile) {
+        const int64_t clip = tile / g.tiles_per_clip;
+        const int64_t t_abs = g.tile0 + (tile - clip * g.tiles_per_clip);
+        // absolute x index of segment 0, sample 0, relative to the clip buffer
+        const int64_t base = t_abs * (16 * (int64_t)col_span) + g.lo_off - g.x_abs0;
+        const float* xc = g.x + clip * g.x_stride + base;
+        const int64_t lo64 = base < 0 ? -base : 0;
+        int64_t hi64 = g.x_len - base;
+        if (hi64 < 0) hi64 = 0;
+        const int lo = lo64 > (1 << 30) ? (1 << 30) : (int)lo64;
+        const int hi = hi64 > (1 << 30) ? (1 << 30) : (int)hi64;
+        const int u0 = tid + opaque_zero();                     // keeps the 32 offsets out of registers
+#pragma unroll
+        for (int cc = 0; cc < kCols; ++cc) {
+            const float* xcc = xc + cc * col_span;              // uniform
+            const int lo_c = lo - cc * col_span, hi_c = hi - cc * col_span;
+#pragma unroll
+            for (int h = 0; h < kPfSlots; ++h) {
+                const int u = u0 + h * nthreads;
+                float v = 0.0f;
+                if (u < g.seg_len && u >= lo_c && u < hi_c) v = xcc[u];
+                pf[cc * kPfSlots + h] = v;
+            }
+        }
+    };
+
+    int64_t tile = blockIdx.x;
+    if (tile < g.n_tiles) load_tile(tile);
+    for (; tile < g.n_tiles; tile += gridDim.x) {
+        __syncthreads();                                        // readers of the previous tile done
+        {
+            const int u0 = tid + opaque_zero();
+#pragma unroll
+            for (int cc = 0; cc < kCols; ++cc) {
+#pragma unroll
+                for (int h = 0; h < kPfSlots; ++h) {
+                    const int u = u0 + h * nthreads;
+                    if (u < g.seg_len) xs[cc * g.seg_stride + u] = pf[cc * kPfSlots + h];
+                }
+            }
+        }
+        __syncthreads();
+        const int64_t clip = tile / g.tiles_per_clip;
+        const int64_t t_abs = g.tile0 + (tile - clip * g.tiles_per_clip);
+        if (tile + gridDim.x < g.n_tiles) load_tile(tile + gridDim.x);   // in flight during the MFMAs
+
+        const int64_t mbase = t_abs * out_per_tile - g.m0;      // output index of the tile - m0
+        float* yc = g.y + clip * g.y_stride + mbase;
+        const int64_t lo64 = mbase < 0 ? -mbase : 0;
+        int64_t hi64 = g.n_out - mbase;
+        if (hi64 < 0) hi64 = 0;
+        const int lo = lo64 > (1 << 30) ? (1 << 30) : (int)lo64;
+        const int hi = hi64 > (1 << 30) ? (1 << 30) : (int)hi64;
+        const bool vec_ok = ((reinterpret_cast<uintptr_t>(yc) >> 2) & 3) == 0;
+
+        for (int gi = 0; gi < g.gpw; gi += 2) {
+            const int off0 = gi * g.S;
+            const float* b0p = xs + base_full + off0;
+            const float* b1p = b0p + g.S;
+            const float* t0p = xs + base_tail + off0;
+            const float* t1p = t0p + g.S;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 16 * FULL; ++t) {
+                const int o = 64 * (t / 16) + (t % 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b0p[o], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b1p[o], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < TAILQ; ++t) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[16 * FULL + t], t0p[t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[16 * FULL + t], t1p[t], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x4 acc = e ? acc1 : acc0;
+                const int o = out_lane + (gi + e) * out_step;
+                if (vec_ok && o >= lo && o + 3 < hi) {
+                    *reinterpret_cast<f32x4*>(yc + o) = acc;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (o + j >= lo && o + j < hi) yc[o + j] = acc[j];
+                }
+            }
+        }
+    }
+}
+
+const int kNkInstances[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 48};
+
+template <int NK>
+void launch_nk(const Geom& g, unsigned grid, unsigned block, size_t smem, hipStream_t s)
+{
+    hipLaunchKernelGGL(banded_kernel<NK>, dim3(grid), dim3(block), smem, s, g);
+}
+
+}  // namespace
+
+Plan make_plan(uint32_t L, uint32_t M, int T, int c)
+{
+    Plan p;
+    p.L = L;
+    p.M = M;
+    p.T = T;
+    p.c = c;
+    if (L == 0 || M == 0 || T < 1) return p;
+    if (std::getenv("AF_BANDED_OFF")) return p;              // diagnostics: force the VALU kernels
+    const uint32_t g16 = std::gcd(16u, L);
+    const uint64_t nb = L / g16;
+    const uint64_t S = (uint64_t)(16 / g16) * M;
+    if (nb > 16 || S > (uint64_t)kMaxSeg) return p;
+    p.nb = (int)nb;
+    p.S = (int)S;
+    uint64_t d15 = 0;
+    for (uint64_t b = 0; b < nb; ++b) {
+        const uint64_t r0 = (16 * b * M) % L;
+        const uint64_t d = (r0 + 15ull * M) / L;
+        if (d > d15) d15 = d;
+    }
+    const uint64_t W = (uint64_t)T + d15;
+    const uint64_t need = 16 * (W / 64) + ((W % 64) + 3) / 4;
+    for (int nk : kNkInstances)
+        if ((uint64_t)nk >= need) { p.NK = nk; break; }
+    if (!p.NK) return p;
+    p.wpp = nb >= 5 ? 1 : nb == 1 ? 8 : nb == 2 ? 4 : 2;
+    p.nwaves = p.nb * p.wpp;
+    const int nthreads = 64 * p.nwaves;
+    const int seg_cap = kPfSlots * nthreads < kMaxSeg ? kPfSlots * nthreads : kMaxSeg;
+    const int qp_last = (int)((16ull * (nb - 1) * M) / L);
+    const int unit = 2 * p.wpp;                              // every wave runs chains in pairs
+    int G = 0;
+    for (int cand = unit; (int64_t)(cand - 1) * p.S + qp_last + 4 * p.NK <= seg_cap; cand += unit) G = cand;
+    if (!G) return p;
+    p.G = G;
+    p.seg_len = (G - 1) * p.S + qp_last + 4 * p.NK;
+    p.seg_stride = p.seg_len | 1;
+    p.out_per_tile = (int64_t)256 * G * p.nb;
+    p.smem = (size_t)kCols * p.seg_stride * sizeof(float);
+    p.ok = true;
+    return p;
+}
+
+af_status build_afrag(const Plan& p, const float* proto_dev, float* afrag_dev, hipStream_t stream)
+{
+    const int n = (int)p.afrag_floats();
+    hipLaunchKernelGGL(build_afrag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, proto_dev,
+                       afrag_dev, p.L, p.M, p.T, p.nb, p.NK);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int64_t x_abs0,
+                 int64_t x_len, int64_t x_stride, float* y_dev, int64_t y_stride, int64_t m0,
+                 int64_t n_out, int64_t n_clips, hipStream_t stream)
+{
+    if (n_out <= 0 || n_clips <= 0) return AF_OK;
+    if (!p.ok) return fail(AF_ERR_UNSUPPORTED, "banded::launch without a plan");
+    Geom g{};
+    g.x = x_dev;
+    g.y = y_dev;
+    g.afrag = afrag_dev;
+    g.x_abs0 = x_abs0;
+    g.x_len = x_len;
+    g.x_stride = x_stride;
+    g.y_stride = y_stride;
+    g.m0 = m0;
+    g.n_out = n_out;
+    g.tile0 = m0 / p.out_per_tile;
+    g.tiles_per_clip = (m0 + n_out - 1) / p.out_per_tile - g.tile0 + 1;
+    g.n_tiles = g.tiles_per_clip * n_clips;
+    g.L = p.L;
+    g.M = p.M;
+    g.lo_off = p.c - (p.T - 1);
+    g.nb = p.nb;
+    g.S = p.S;
+    g.G = p.G;
+    g.wpp = p.wpp;
+    g.gpw = p.G / p.wpp;
+    g.seg_len = p.seg_len;
+    g.seg_stride = p.seg_stride;
+    const int wg_per_cu = (2 * 64 * p.nwaves <= 2048 && 2 * p.smem <= 150 * 1024) ? 2 : 1;
+    int64_t grid = g.n_tiles;
+    if (grid > 256 * wg_per_cu) grid = 256 * wg_per_cu;
+    const unsigned block = 64u * p.nwaves;
+    switch (p.NK) {
+    case 8: launch_nk<8>(g, (unsigned)grid, block, p.smem, stream); break;
+    case 12: launch_nk<12>(g, (unsigned)grid, block, p.smem, stream); break;
+    case 16: launch_nk<16>(g, (unsigned)grid, block, p.smem, stream); break;
+    case 20: launch_nk<20>(g, (unsigned)grid, block, p.smem, stream); break;
+    case 24: launch_nk<24>(g, (unsigned)grid, block, p.smem, stream); break;
+    case 28: launch_nk<28>(g, (unsigned)grid, block, p.smem, stream); break;
+    case 32: launch_nk<32>(g, (unsigned)grid, block, p.smem, stream); break;
+    case 36: launch_nk<36>(g, (unsigned)grid, block, p.smem, stream); break;
+    case 40: launch_nk<40>(g, (unsigned)grid, block, p.smem, stream); break;
+    case 48: launch_nk<48>(g, (unsigned)grid, block, p.smem, stream); break;
+    default: return fail(AF_ERR_UNSUPPORTED, "no banded kernel for NK=%d", p.NK);
+    }
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+}  // namespace banded
+}  // namespace af

@@ -5,15 +5,17 @@
 // and no implementation; the surface follows AudioResampler's style
 // (resampler.rs:32,:71): create / process(&mut self) / reset.
 //
-// Kernel: taps and the input tile (+ K-1 halo) live in LDS.  A lane produces 5
-// consecutive outputs from a 5-register sliding window, so each tap costs one
-// broadcast LDS read (h[k]), one LDS read (the next older sample; lane stride
-// 5 dwords is bank-conflict free) and 5 FMAs.
+// Device path: up to 177 taps run as a banded (Toeplitz) matrix product on MFMA
+// (banded.hpp).  Longer filters run the VALU kernel below: taps and the input tile
+// (+ K-1 halo) live in LDS; a lane produces 5 consecutive outputs from a 5-register
+// sliding window, so each tap costs one broadcast LDS read (h[k]), one LDS read (the
+// next older sample; lane stride 5 dwords is bank-conflict free) and 5 FMAs.
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "af_common.hpp"
+#include "banded.hpp"
 
 namespace af {
 namespace firk {
@@ -24,12 +26,11 @@ constexpr int kTileOut = kBlock * kR;          // 1280 outputs per tile
 constexpr int kMaxTaps = 1024;
 
 struct Geometry {
-    const float* x;       // clip 0
-    float* y;
+    const float* x;       // clip 0; x[0] has absolute stream index x_abs0
+    float* y;             // clip 0; y[0] is output m0
     const float* taps;    // [K]
-    const float* hist;    // optional [K-1] samples preceding x[0] (single clip), or null
-    int64_t n;            // samples per clip
-    int64_t stride;       // elements between clips
+    int64_t x_abs0, x_len, x_stride, y_stride;
+    int64_t m0, n_out;    // outputs per clip
     int64_t tiles_per_clip;
     int64_t n_tiles;
     int K;
@@ -47,23 +48,17 @@ __global__ __launch_bounds__(kBlock) void fir_kernel(const Geometry g)
 
     for (int64_t tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x) {
         const int64_t clip = tile / g.tiles_per_clip;
-        const int64_t n0 = (tile - clip * g.tiles_per_clip) * kTileOut;
-        const float* xc = g.x + clip * g.stride;
+        const int64_t n0 = (tile - clip * g.tiles_per_clip) * kTileOut;   // relative to m0
+        const float* xc = g.x + clip * g.x_stride;
         __syncthreads();
-        // xs[i] = x[n0 - halo + i], i in [0, halo + kTileOut)
+        // xs[i] = x[m0 + n0 - halo + i], i in [0, halo + kTileOut); zero outside the buffer
         for (int i = tid; i < halo + kTileOut; i += kBlock) {
-            const int64_t idx = n0 - halo + i;
-            float v = 0.0f;
-            if (idx >= 0) {
-                if (idx < g.n) v = xc[idx];
-            } else if (g.hist && idx + (g.K - 1) >= 0) {
-                v = g.hist[idx + (g.K - 1)];          // carried history (streaming)
-            }
-            xs[i] = v;
+            const int64_t rel = g.m0 + n0 - halo + i - g.x_abs0;
+            xs[i] = (rel >= 0 && rel < g.x_len) ? xc[rel] : 0.0f;
         }
         __syncthreads();
         const int o0 = tid * kR;                       // first output of this lane in the tile
-        const float* xp = xs + halo + o0;              // x[n], n = n0 + o0
+        const float* xp = xs + halo + o0;              // x[n], n = m0 + n0 + o0
         float win[kR], acc[kR];
 #pragma unroll
         for (int j = 0; j < kR; ++j) { win[j] = xp[j]; acc[j] = 0.0f; }
@@ -80,29 +75,36 @@ __global__ __launch_bounds__(kBlock) void fir_kernel(const Geometry g)
                 win[0] = xp[-(k + u) - 1];            // >= xs[0] because k+u <= Kpad-1 = halo
             }
         }
-        float* yc = g.y + clip * g.stride + n0 + o0;
+        float* yc = g.y + clip * g.y_stride + n0 + o0;
 #pragma unroll
         for (int j = 0; j < kR; ++j)
-            if (n0 + o0 + j < g.n) yc[j] = acc[j];
+            if (n0 + o0 + j < g.n_out) yc[j] = acc[j];
     }
 }
 
-af_status launch(const float* taps_dev, int K, const float* hist_dev, const float* x_dev, float* y_dev,
-                 int64_t n, int64_t n_clips, hipStream_t stream)
+// `plan`/`afrag_dev`: the MFMA path when plan.ok (afrag built from the same taps).
+af_status launch(const banded::Plan& plan, const float* afrag_dev, const float* taps_dev, int K,
+                 const float* x_dev, int64_t x_abs0, int64_t x_len, int64_t x_stride, float* y_dev,
+                 int64_t y_stride, int64_t m0, int64_t n_out, int64_t n_clips, hipStream_t stream)
 {
-    if (n <= 0 || n_clips <= 0) return AF_OK;
+    if (n_out <= 0 || n_clips <= 0) return AF_OK;
+    if (plan.ok)
+        return banded::launch(plan, afrag_dev, x_dev, x_abs0, x_len, x_stride, y_dev, y_stride, m0,
+                              n_out, n_clips, stream);
     Geometry g{};
     g.x = x_dev;
     g.y = y_dev;
     g.taps = taps_dev;
-    g.hist = hist_dev;
-    g.n = n;
-    g.stride = n;
-    g.tiles_per_clip = (n + kTileOut - 1) / kTileOut;
+    g.x_abs0 = x_abs0;
+    g.x_len = x_len;
+    g.x_stride = x_stride;
+    g.y_stride = y_stride;
+    g.m0 = m0;
+    g.n_out = n_out;
+    g.tiles_per_clip = (n_out + kTileOut - 1) / kTileOut;
     g.n_tiles = g.tiles_per_clip * n_clips;
     g.K = K;
     g.Kpad = (K + 3) & ~3;
-    // one extra float: the last shift reads xs[-1 + ...] up to index halo - Kpad = -1 + ... guard
     const size_t smem = sizeof(float) * ((size_t)g.Kpad + (size_t)(g.Kpad - 1) + kTileOut + 4);
     int64_t grid = g.n_tiles;
     if (grid > 2048) grid = 2048;
@@ -119,8 +121,39 @@ using namespace af;
 struct af_fir {
     std::vector<float> taps;
     std::vector<float> hist;     // K-1 most recent input samples (zeros initially)
-    DevBuf d_taps, d_hist, d_x, d_y;
+    int64_t n_total = 0;         // samples consumed so far (anchors the MFMA tile grid)
+    banded::Plan plan;
+    DevBuf d_taps, d_afrag, d_x, d_y;
 };
+
+namespace {
+
+// A fragments for af_fir_batch_device(), whose taps arrive as a device pointer: rebuilt on the
+// caller's stream before every launch, one scratch buffer per (thread, stream).
+struct Scratch {
+    hipStream_t stream;
+    DevBuf buf;
+};
+af_status scratch_afrag(hipStream_t stream, size_t floats, float** out)
+{
+    static thread_local std::vector<Scratch*> pool;
+    for (Scratch* s : pool)
+        if (s->stream == stream) {
+            AF_TRY(s->buf.reserve(floats * sizeof(float)));
+            *out = s->buf.as<float>();
+            return AF_OK;
+        }
+    Scratch* s = new (std::nothrow) Scratch();
+    if (!s) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
+    s->stream = stream;
+    af_status st = s->buf.reserve((floats > 48 * 64 ? floats : 48 * 64) * sizeof(float));
+    if (st != AF_OK) { delete s; return st; }
+    pool.push_back(s);
+    *out = s->buf.as<float>();
+    return AF_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -135,10 +168,16 @@ af_status af_fir_create(const float* taps, size_t n_taps, af_fir** out)
     if (!f) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
     f->taps.assign(taps, taps + n_taps);
     f->hist.assign(n_taps - 1, 0.0f);
+    f->plan = banded::make_plan(1, 1, (int)n_taps, 0);
     af_status st = f->d_taps.reserve(n_taps * sizeof(float));
     if (st == AF_OK && hipMemcpy(f->d_taps.p, taps, n_taps * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         st = fail(AF_ERR_HIP, "uploading FIR taps failed");
-    if (st == AF_OK) st = f->d_hist.reserve((n_taps > 1 ? n_taps - 1 : 1) * sizeof(float));
+    if (st == AF_OK && f->plan.ok) {
+        st = f->d_afrag.reserve(f->plan.afrag_floats() * sizeof(float));
+        if (st == AF_OK) st = banded::build_afrag(f->plan, f->d_taps.as<float>(), f->d_afrag.as<float>(), nullptr);
+        if (st == AF_OK && hipStreamSynchronize(nullptr) != hipSuccess)
+            st = fail(AF_ERR_HIP, "building the FIR fragments failed");
+    }
     if (st != AF_OK) { delete f; return st; }
     *out = f;
     return AF_OK;
@@ -148,7 +187,9 @@ void af_fir_destroy(af_fir* f) { delete f; }
 
 void af_fir_reset(af_fir* f)
 {
-    if (f) std::fill(f->hist.begin(), f->hist.end(), 0.0f);
+    if (!f) return;
+    std::fill(f->hist.begin(), f->hist.end(), 0.0f);
+    f->n_total = 0;
 }
 
 af_status af_fir_process(af_fir* f, const float* in, size_t n, float* out)
@@ -156,25 +197,25 @@ af_status af_fir_process(af_fir* f, const float* in, size_t n, float* out)
     AF_REQUIRE(f, "af_fir_process: null handle");
     if (n == 0) return AF_OK;
     AF_REQUIRE(in && out, "af_fir_process: null buffer");
-    const size_t K = f->taps.size();
-    AF_TRY(f->d_x.reserve(n * sizeof(float)));
+    const size_t K = f->taps.size(), h = K - 1;
+    AF_TRY(f->d_x.reserve((h + n) * sizeof(float)));
     AF_TRY(f->d_y.reserve(n * sizeof(float)));
-    AF_HIP(hipMemcpy(f->d_x.p, in, n * sizeof(float), hipMemcpyHostToDevice));
-    if (K > 1)
-        AF_HIP(hipMemcpy(f->d_hist.p, f->hist.data(), (K - 1) * sizeof(float), hipMemcpyHostToDevice));
-    AF_TRY(firk::launch(f->d_taps.as<float>(), (int)K, K > 1 ? f->d_hist.as<float>() : nullptr,
-                        f->d_x.as<float>(), f->d_y.as<float>(), (int64_t)n, 1, nullptr));
+    if (h) AF_HIP(hipMemcpy(f->d_x.p, f->hist.data(), h * sizeof(float), hipMemcpyHostToDevice));
+    AF_HIP(hipMemcpy(f->d_x.as<float>() + h, in, n * sizeof(float), hipMemcpyHostToDevice));
+    AF_TRY(firk::launch(f->plan, f->d_afrag.as<float>(), f->d_taps.as<float>(), (int)K, f->d_x.as<float>(),
+                        f->n_total - (int64_t)h, (int64_t)(h + n), 0, f->d_y.as<float>(), 0, f->n_total,
+                        (int64_t)n, 1, nullptr));
     AF_HIP(hipMemcpy(out, f->d_y.p, n * sizeof(float), hipMemcpyDeviceToHost));
     // carry the K-1 most recent samples
-    if (K > 1) {
-        const size_t keep = K - 1;
-        if (n >= keep) {
-            f->hist.assign(in + (n - keep), in + n);
+    if (h) {
+        if (n >= h) {
+            f->hist.assign(in + (n - h), in + n);
         } else {
             f->hist.erase(f->hist.begin(), f->hist.begin() + n);
             f->hist.insert(f->hist.end(), in, in + n);
         }
     }
+    f->n_total += (int64_t)n;
     return AF_OK;
 }
 
@@ -185,8 +226,14 @@ af_status af_fir_batch_device(const float* taps_dev, size_t n_taps, const float*
                firk::kMaxTaps, n_taps);
     if (n_clips == 0 || n == 0) return AF_OK;
     AF_REQUIRE(taps_dev && in_dev && out_dev, "af_fir_batch_device: null buffer");
-    return firk::launch(taps_dev, (int)n_taps, nullptr, in_dev, out_dev, (int64_t)n, (int64_t)n_clips,
-                        as_stream(stream));
+    const banded::Plan plan = banded::make_plan(1, 1, (int)n_taps, 0);
+    float* afrag = nullptr;
+    if (plan.ok) {
+        AF_TRY(scratch_afrag(as_stream(stream), plan.afrag_floats(), &afrag));
+        AF_TRY(banded::build_afrag(plan, taps_dev, afrag, as_stream(stream)));
+    }
+    return firk::launch(plan, afrag, taps_dev, (int)n_taps, in_dev, 0, (int64_t)n, (int64_t)n, out_dev,
+                        (int64_t)n, 0, (int64_t)n, (int64_t)n_clips, as_stream(stream));
 }
 
 af_status af_fir_batch(const float* taps, size_t n_taps, const float* in, size_t n_clips, size_t n,

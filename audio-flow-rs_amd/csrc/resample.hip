@@ -12,11 +12,11 @@
 //
 //   y[m] = sum_{k<T} h[(m*M mod L) + k*L] * x[floor(m*M/L) - k + T/2]
 //
-// Device layout: the prototype is stored phase-major ([L][T], rows padded to
-// T+4 floats so that 16 lanes reading 16 different rows with ds_read_b128 hit
-// 16 different bank groups) and staged in LDS once per workgroup; the input
-// span of a 1024-output tile is staged in LDS with coalesced loads, so HBM
-// sees each input sample once per tile (+ the T-sample halo).
+// Device path: ratios whose 16-output blocks repeat with a short period (every
+// ratio on BASELINE's list) run as a banded matrix product on MFMA (banded.hpp).
+// Any other ratio runs the VALU kernel below: prototype phase-major ([L][T], rows
+// padded to T+4 floats) in LDS, the input span of a 1024-output tile staged in LDS
+// with coalesced loads, one thread per output.
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "af_common.hpp"
+#include "banded.hpp"
 
 namespace af {
 namespace rs {
@@ -114,6 +115,8 @@ struct Design {
     uint32_t in_hz = 0, out_hz = 0, L = 1, M = 1;
     std::vector<float> proto;        // h[L*T] in prototype order (f32)
     DevBuf d_taps;                   // [L][kRow]
+    banded::Plan plan;               // MFMA path when plan.ok
+    DevBuf d_afrag;
     int x_tile_cap = 0;
     size_t smem = 0;
     int taps_in_lds = 0;
@@ -157,6 +160,18 @@ af_status make_design(uint32_t in_hz, uint32_t out_hz, Design& d, bool upload)
     design_prototype(d.L, d.M, h);
     d.proto.resize(h.size());
     for (size_t i = 0; i < h.size(); ++i) d.proto[i] = (float)h[i];
+    d.plan = banded::make_plan(d.L, d.M, kT, kT / 2);
+    if (d.plan.ok) {
+        if (upload) {
+            DevBuf d_proto;
+            AF_TRY(d_proto.reserve(d.proto.size() * sizeof(float)));
+            AF_TRY(d.d_afrag.reserve(d.plan.afrag_floats() * sizeof(float)));
+            AF_HIP(hipMemcpy(d_proto.p, d.proto.data(), d.proto.size() * sizeof(float), hipMemcpyHostToDevice));
+            AF_TRY(banded::build_afrag(d.plan, d_proto.as<float>(), d.d_afrag.as<float>(), nullptr));
+            AF_HIP(hipStreamSynchronize(nullptr));
+        }
+        return AF_OK;
+    }
     // input span of one tile: ceil(kTileOut*M/L) + T + 2
     d.x_tile_cap = (int)(((uint64_t)kTileOut * d.M + d.L - 1) / d.L) + kT + 4;
     d.x_tile_cap = (d.x_tile_cap + 3) & ~3;
@@ -182,6 +197,9 @@ af_status launch(const Design& d, const float* x_dev, int64_t x_abs0, int64_t x_
                  hipStream_t stream)
 {
     if (n_out <= 0 || n_clips <= 0) return AF_OK;
+    if (d.plan.ok)
+        return banded::launch(d.plan, d.d_afrag.as<float>(), x_dev, x_abs0, x_len, x_stride, y_dev,
+                              y_stride, m0, n_out, n_clips, stream);
     Geometry g{};
     g.x = x_dev;
     g.y = y_dev;
