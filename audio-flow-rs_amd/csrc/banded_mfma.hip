@@ -11,6 +11,7 @@
 // column stride).  The A fragments are gathered with the same mapping (build_afrag_kernel).
 #include <cstdlib>
 #include <numeric>
+#include <type_traits>
 
 #include "banded.hpp"
 
@@ -22,7 +23,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCols = 16;
 constexpr int kPfSlots = 2;          // x prefetch registers per column and thread
-constexpr int kMaxSeg = 1000;        // floats per column segment (16 segments <= 64 KB)
+constexpr int kMaxSeg = 1000;
+constexpr int64_t kMaxClip = (1ll << 30) - (1ll << 20);   // byte offsets of a clip + one tile < 2^32        // floats per column segment (16 segments <= 64 KB)
 
 struct Geom {
     const float* x;
@@ -66,8 +68,10 @@ __device__ __forceinline__ int opaque_zero()
     return z;
 }
 
-template <int NK>
-__global__ __launch_bounds__(1024) void banded_kernel(const Geom g)
+// WPE = waves per SIMD the register budget is cut for: 5 when two workgroups of 9-10 waves
+// share a CU (96 VGPRs), 4 otherwise (128).
+template <int NK, int WPE>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void banded_kernel(const Geom g)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     constexpr int FULL = NK / 16, TAILQ = NK % 16;
@@ -88,105 +92,129 @@ __global__ __launch_bounds__(1024) void banded_kernel(const Geom g)
     // this lane's outputs: rows 4 g4 .. 4 g4 + 3 of block (p, column col, period g)
     const int out_lane = 16 * (p + g.nb * (col * g.G + gsub * g.gpw)) + 4 * g4;
     const int out_step = 16 * g.nb;                             // per block period
-    const int64_t out_per_tile = (int64_t)256 * g.G * g.nb;
+    const int out_per_tile = 256 * g.G * g.nb;
     const int col_span = g.G * g.S;
+    const bool second = tid + nthreads < g.seg_len;             // this thread fills two samples per segment
+    const uint32_t tpc = (uint32_t)g.tiles_per_clip, n_tiles = (uint32_t)g.n_tiles;
 
+    // x comes through a buffer resource over the clip: samples before / after the clip read as
+    // zero in hardware, the byte offset wraps modulo 2^32 (launch() bounds x_len for that).
+    // The 32 loads of the next tile are issued one by one between the MFMAs of the first chain
+    // pair, so no wave sits in a burst of address work while the matrix pipe idles.
+    constexpr uint32_t kOob = 0xFFF00000u;                      // + 16 col_span * 4 stays out of range
     float pf[kCols * kPfSlots];
-    auto load_tile = [&](int64_t tile) {
-        const int64_t clip = tile / g.tiles_per_clip;
-        const int64_t t_abs = g.tile0 + (tile - clip * g.tiles_per_clip);
-        // absolute x index of segment 0, sample 0, relative to the clip buffer
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[kPfSlots];
+    auto prep_tile = [&](uint32_t tile, bool live) {
+        const uint32_t clip = tile / tpc;
+        const int64_t t_abs = g.tile0 + (tile - clip * tpc);
         const int64_t base = t_abs * (16 * (int64_t)col_span) + g.lo_off - g.x_abs0;
-        const float* xc = g.x + clip * g.x_stride + base;
-        const int64_t lo64 = base < 0 ? -base : 0;
-        int64_t hi64 = g.x_len - base;
-        if (hi64 < 0) hi64 = 0;
-        const int lo = lo64 > (1 << 30) ? (1 << 30) : (int)lo64;
-        const int hi = hi64 > (1 << 30) ? (1 << 30) : (int)hi64;
-        const int u0 = tid + opaque_zero();                     // keeps the 32 offsets out of registers
-#pragma unroll
-        for (int cc = 0; cc < kCols; ++cc) {
-            const float* xcc = xc + cc * col_span;              // uniform
-            const int lo_c = lo - cc * col_span, hi_c = hi - cc * col_span;
-#pragma unroll
-            for (int h = 0; h < kPfSlots; ++h) {
-                const int u = u0 + h * nthreads;
-                float v = 0.0f;
-                if (u < g.seg_len && u >= lo_c && u < hi_c) v = xcc[u];
-                pf[cc * kPfSlots + h] = v;
-            }
-        }
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride), 0,
+                                                 (int)(uint32_t)(g.x_len * 4), 0x00020000);
+        const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * 4u;
+        voff[0] = live ? v0 : kOob;
+        voff[1] = live && second ? v0 + (uint32_t)nthreads * 4u : kOob;
     };
+    auto issue_load = [&](int s) {                              // s = h * 16 + cc
+        const int cc = s % kCols, h = s / kCols;
+        pf[cc * kPfSlots + h] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
+    };
+    constexpr int kLoads = kCols * kPfSlots;
 
-    int64_t tile = blockIdx.x;
-    if (tile < g.n_tiles) load_tile(tile);
-    for (; tile < g.n_tiles; tile += gridDim.x) {
+    uint32_t tile = blockIdx.x;
+    if (tile < n_tiles) {
+        prep_tile(tile, true);
+#pragma unroll
+        for (int s2 = 0; s2 < kLoads; ++s2) issue_load(s2);
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();                                        // readers of the previous tile done
         {
-            const int u0 = tid + opaque_zero();
+            float* dst = xs + tid + opaque_zero();
 #pragma unroll
-            for (int cc = 0; cc < kCols; ++cc) {
+            for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = pf[cc * kPfSlots];
+            if (second) {
 #pragma unroll
-                for (int h = 0; h < kPfSlots; ++h) {
-                    const int u = u0 + h * nthreads;
-                    if (u < g.seg_len) xs[cc * g.seg_stride + u] = pf[cc * kPfSlots + h];
-                }
+                for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = pf[cc * kPfSlots + 1];
             }
         }
         __syncthreads();
-        const int64_t clip = tile / g.tiles_per_clip;
-        const int64_t t_abs = g.tile0 + (tile - clip * g.tiles_per_clip);
-        if (tile + gridDim.x < g.n_tiles) load_tile(tile + gridDim.x);   // in flight during the MFMAs
+        const uint32_t clip = tile / tpc;
+        const int64_t t_abs = g.tile0 + (tile - clip * tpc);
+        {
+            const bool live = tile + gridDim.x < n_tiles;
+            prep_tile(live ? tile + gridDim.x : tile, live);
+        }
 
         const int64_t mbase = t_abs * out_per_tile - g.m0;      // output index of the tile - m0
-        float* yc = g.y + clip * g.y_stride + mbase;
-        const int64_t lo64 = mbase < 0 ? -mbase : 0;
-        int64_t hi64 = g.n_out - mbase;
-        if (hi64 < 0) hi64 = 0;
-        const int lo = lo64 > (1 << 30) ? (1 << 30) : (int)lo64;
-        const int hi = hi64 > (1 << 30) ? (1 << 30) : (int)hi64;
-        const bool vec_ok = ((reinterpret_cast<uintptr_t>(yc) >> 2) & 3) == 0;
+        float* yc = g.y + (int64_t)clip * g.y_stride + mbase;
+        const bool whole = mbase >= 0 && mbase + out_per_tile <= g.n_out &&
+                           ((reinterpret_cast<uintptr_t>(yc) >> 2) & 3) == 0;
+        const int lo = mbase >= 0 ? 0 : -mbase > out_per_tile ? out_per_tile : (int)-mbase;
+        const int64_t left = g.n_out - mbase;
+        const int hi = left < 0 ? 0 : left > out_per_tile ? out_per_tile : (int)left;
 
-        for (int gi = 0; gi < g.gpw; gi += 2) {
+        auto chain_pair = [&](int gi, auto with_loads) {
+            constexpr bool LOADS = decltype(with_loads)::value;
             const int off0 = gi * g.S;
             const float* b0p = xs + base_full + off0;
             const float* b1p = b0p + g.S;
             const float* t0p = xs + base_tail + off0;
             const float* t1p = t0p + g.S;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            // hand-pipelined: the window samples of step t + kAhead are read before the MFMAs of
+            // step t, one prefetch load goes out per step; sched_barrier keeps hipcc from
+            // clustering the loads at the end of the chain
+            constexpr int kAhead = 3;
+            float w0[kAhead + 1], w1[kAhead + 1];            // rotating operand registers
+            auto read_b = [&](int t) {
+                w0[t % (kAhead + 1)] = t < 16 * FULL ? b0p[64 * (t / 16) + (t % 16)] : t0p[t - 16 * FULL];
+                w1[t % (kAhead + 1)] = t < 16 * FULL ? b1p[64 * (t / 16) + (t % 16)] : t1p[t - 16 * FULL];
+            };
 #pragma unroll
-            for (int t = 0; t < 16 * FULL; ++t) {
-                const int o = 64 * (t / 16) + (t % 16);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b0p[o], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b1p[o], acc1, 0, 0, 0);
+            for (int t = 0; t < kAhead && t < NK; ++t) read_b(t);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NK; ++t) {
+                if (t + kAhead < NK) read_b(t + kAhead);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w0[t % (kAhead + 1)], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w1[t % (kAhead + 1)], acc1, 0, 0, 0);
+                if (LOADS) {
+#pragma unroll
+                    for (int s2 = (kLoads * t) / NK; s2 < (kLoads * (t + 1)) / NK; ++s2) issue_load(s2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            const int o0 = out_lane + gi * out_step, o1 = o0 + out_step;
+            if (whole) {
+                *reinterpret_cast<f32x4*>(yc + o0) = acc0;
+                *reinterpret_cast<f32x4*>(yc + o1) = acc1;
+            } else {                                            // clip edges, unaligned streams
 #pragma unroll
-            for (int t = 0; t < TAILQ; ++t) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[16 * FULL + t], t0p[t], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[16 * FULL + t], t1p[t], acc1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const f32x4 acc = e ? acc1 : acc0;
-                const int o = out_lane + (gi + e) * out_step;
-                if (vec_ok && o >= lo && o + 3 < hi) {
-                    *reinterpret_cast<f32x4*>(yc + o) = acc;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (o + j >= lo && o + j < hi) yc[o + j] = acc[j];
+                for (int j = 0; j < 4; ++j) {
+                    if (o0 + j >= lo && o0 + j < hi) yc[o0 + j] = acc0[j];
+                    if (o1 + j >= lo && o1 + j < hi) yc[o1 + j] = acc1[j];
                 }
             }
-        }
+        };
+        chain_pair(0, std::true_type{});
+        for (int gi = 2; gi < g.gpw; gi += 2) chain_pair(gi, std::false_type{});
     }
 }
 
 const int kNkInstances[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 48};
 
 template <int NK>
-void launch_nk(const Geom& g, unsigned grid, unsigned block, size_t smem, hipStream_t s)
+void launch_nk(const Geom& g, bool five, unsigned grid, unsigned block, size_t smem, hipStream_t s)
 {
-    hipLaunchKernelGGL(banded_kernel<NK>, dim3(grid), dim3(block), smem, s, g);
+    if constexpr (NK <= 32) {
+        if (five) {
+            hipLaunchKernelGGL((banded_kernel<NK, 5>), dim3(grid), dim3(block), smem, s, g);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((banded_kernel<NK, 4>), dim3(grid), dim3(block), smem, s, g);
 }
 
 }  // namespace
@@ -250,6 +278,9 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
 {
     if (n_out <= 0 || n_clips <= 0) return AF_OK;
     if (!p.ok) return fail(AF_ERR_UNSUPPORTED, "banded::launch without a plan");
+    if (x_len >= (int64_t)kMaxClip)
+        return fail(AF_ERR_UNSUPPORTED, "clips of %lld samples are beyond the banded kernel's 32-bit offsets",
+                    (long long)x_len);
     Geom g{};
     g.x = x_dev;
     g.y = y_dev;
@@ -263,6 +294,7 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
     g.tile0 = m0 / p.out_per_tile;
     g.tiles_per_clip = (m0 + n_out - 1) / p.out_per_tile - g.tile0 + 1;
     g.n_tiles = g.tiles_per_clip * n_clips;
+    if (g.n_tiles >= (1ll << 31)) return fail(AF_ERR_UNSUPPORTED, "banded::launch: too many tiles");
     g.L = p.L;
     g.M = p.M;
     g.lo_off = p.c - (p.T - 1);
@@ -277,17 +309,18 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
     int64_t grid = g.n_tiles;
     if (grid > 256 * wg_per_cu) grid = 256 * wg_per_cu;
     const unsigned block = 64u * p.nwaves;
+    const bool five = wg_per_cu == 2 && 2 * p.nwaves > 16;
     switch (p.NK) {
-    case 8: launch_nk<8>(g, (unsigned)grid, block, p.smem, stream); break;
-    case 12: launch_nk<12>(g, (unsigned)grid, block, p.smem, stream); break;
-    case 16: launch_nk<16>(g, (unsigned)grid, block, p.smem, stream); break;
-    case 20: launch_nk<20>(g, (unsigned)grid, block, p.smem, stream); break;
-    case 24: launch_nk<24>(g, (unsigned)grid, block, p.smem, stream); break;
-    case 28: launch_nk<28>(g, (unsigned)grid, block, p.smem, stream); break;
-    case 32: launch_nk<32>(g, (unsigned)grid, block, p.smem, stream); break;
-    case 36: launch_nk<36>(g, (unsigned)grid, block, p.smem, stream); break;
-    case 40: launch_nk<40>(g, (unsigned)grid, block, p.smem, stream); break;
-    case 48: launch_nk<48>(g, (unsigned)grid, block, p.smem, stream); break;
+    case 8: launch_nk<8>(g, five, (unsigned)grid, block, p.smem, stream); break;
+    case 12: launch_nk<12>(g, five, (unsigned)grid, block, p.smem, stream); break;
+    case 16: launch_nk<16>(g, five, (unsigned)grid, block, p.smem, stream); break;
+    case 20: launch_nk<20>(g, five, (unsigned)grid, block, p.smem, stream); break;
+    case 24: launch_nk<24>(g, five, (unsigned)grid, block, p.smem, stream); break;
+    case 28: launch_nk<28>(g, five, (unsigned)grid, block, p.smem, stream); break;
+    case 32: launch_nk<32>(g, five, (unsigned)grid, block, p.smem, stream); break;
+    case 36: launch_nk<36>(g, five, (unsigned)grid, block, p.smem, stream); break;
+    case 40: launch_nk<40>(g, five, (unsigned)grid, block, p.smem, stream); break;
+    case 48: launch_nk<48>(g, five, (unsigned)grid, block, p.smem, stream); break;
     default: return fail(AF_ERR_UNSUPPORTED, "no banded kernel for NK=%d", p.NK);
     }
     AF_HIP(hipGetLastError());
