@@ -69,6 +69,12 @@ void build_mel(const af_features_config& c, double f_max, std::vector<float>& W)
 // Dynamic programming picks the groups and deals them, in order, to the 4
 // waves so that the largest per-wave step count is minimal (ties: fewest
 // steps in total).
+int flush_cost()
+{
+    if (const char* e = std::getenv("AF_FEATURES_FLUSH_COST")) return std::atoi(e);   // tuning only
+    return 8;
+}
+
 af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
                      std::vector<float>& wfrag, std::vector<int>& meta)
 {
@@ -93,7 +99,10 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
         if (b0 + 4 * steps > kBins) b0 = kBins - 4 * steps; // never read past bin 512
     };
     const int INF = 1 << 28;
-    // g[i][j]: fewest steps covering units [i, j) with groups of <= 4 units
+    // What a group costs its wave besides its K-steps: combining the two accumulators and the
+    // (up to 16-byte) stores of 16 frames, measured at about kFlushCost MFMA steps.
+    const int kFlushCost = flush_cost();
+    // g[i][j]: cheapest cover of units [i, j) with groups of <= 4 units (steps + flushes)
     std::vector<std::vector<int>> g(U + 1, std::vector<int>(U + 1, INF)), gcut = g;
     for (int i = 0; i <= U; ++i) g[i][i] = 0;
     for (int len = 1; len <= U; ++len)
@@ -103,6 +112,7 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
                 int b0, st;
                 band(k, j, b0, st);
                 st = (st + kSlotSteps - 1) / kSlotSteps * kSlotSteps;   // groups occupy whole slots
+                st += kFlushCost;
                 if (g[i][k] + st < g[i][j]) { g[i][j] = g[i][k] + st; gcut[i][j] = k; }
             }
         }
@@ -119,9 +129,6 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
                 const Cost c{std::max(f[w - 1][i].mx, g[i][j]), f[w - 1][i].tot + g[i][j]};
                 if (better(c, f[w][j])) { f[w][j] = c; fcut[w][j] = i; }
             }
-    if (f[kWaves][U].mx > kMaxSteps)
-        return fail(AF_ERR_UNSUPPORTED, "mel plan needs %d K-steps on one wave (limit %d)",
-                    f[kWaves][U].mx, kMaxSteps);
     int wave_lo[kWaves + 1];
     wave_lo[kWaves] = U;
     for (int w = kWaves; w >= 1; --w) wave_lo[w - 1] = fcut[w][wave_lo[w]];
@@ -136,6 +143,15 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
             groups.push_back({k, j});
             j = k;
         }
+        int need = 0;
+        for (const auto& gr : groups) {
+            int b0, st;
+            band(gr.first, gr.second, b0, st);
+            need += (st + kSlotSteps - 1) / kSlotSteps * kSlotSteps;
+        }
+        if (need > kMaxSteps)
+            return fail(AF_ERR_UNSUPPORTED, "mel plan needs %d K-steps on one wave (limit %d)", need,
+                        kMaxSteps);
         int s = 0;
         for (auto it = groups.rbegin(); it != groups.rend(); ++it) {
             int b0, st;
