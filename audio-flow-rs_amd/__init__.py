@@ -16,8 +16,9 @@ Names, argument meaning and error behaviour follow the reference
 ``VoiceActivityDetector``
 ``MessageBuilder``         network/websocket.rs:333-363 (audio quantiser)
 ``AudioError``             error.rs:96-111
-``FirFilter`` /            build-defined siblings in the same style
-``FeaturePipeline``        (docs/OPS.md)
+``FirFilter`` / ``Stft`` / build-defined siblings in the same style
+``MelFilterbank`` /        (docs/OPS.md)
+``FeaturePipeline``
 =========================  ===================================================
 
 All arithmetic runs in hand-written HIP kernels on gfx950; there is no CPU
@@ -28,12 +29,12 @@ from .errors import AudioError
 from .audio import (AudioFrame, AudioResampler, BatchResampler, ChainPipeline, FeaturePipeline, FirFilter,
                     MelSpectrogram, MessageBuilder, RingBuffer, VadConfig, VadLevel, VadState,
                     VoiceActivityDetector, device_count, library, quantize_pcm16, to_mono,
-                    vad_energy, resample_batch, fir_batch, AudioLevel, level_meter)
+                    vad_energy, resample_batch, fir_batch, AudioLevel, level_meter, Stft, MelFilterbank)
 
 __all__ = [
     "AudioError", "AudioFrame", "AudioResampler", "BatchResampler", "ChainPipeline", "FeaturePipeline",
     "FirFilter",
     "MelSpectrogram", "MessageBuilder", "RingBuffer", "VadConfig", "VadLevel", "VadState",
     "VoiceActivityDetector", "device_count", "library", "quantize_pcm16", "to_mono", "vad_energy",
-    "resample_batch", "fir_batch", "AudioLevel", "level_meter",
+    "resample_batch", "fir_batch", "AudioLevel", "level_meter", "Stft", "MelFilterbank",
 ]

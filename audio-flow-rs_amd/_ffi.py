@@ -27,7 +27,26 @@ AF_PCM_I16 = 1
 class FeaturesConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_uint32), ("channels", C.c_uint32), ("n_fft", C.c_uint32),
                 ("hop", C.c_uint32), ("n_mels", C.c_uint32), ("f_min", C.c_float),
-                ("f_max", C.c_float), ("sample_format", C.c_uint32), ("device", C.c_int32)]
+                ("f_max", C.c_float), ("sample_format", C.c_uint32), ("device", C.c_int32),
+                ("output", C.c_uint32), ("log_mel", C.c_uint32), ("mel_scale", C.c_uint32),
+                ("mel_norm", C.c_uint32), ("channel_mode", C.c_uint32)]
+
+
+class StftConfig(C.Structure):
+    _fields_ = [("channels", C.c_uint32), ("n_fft", C.c_uint32), ("hop", C.c_uint32),
+                ("sample_format", C.c_uint32), ("device", C.c_int32)]
+
+
+class MelConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint32), ("n_fft", C.c_uint32), ("n_mels", C.c_uint32),
+                ("f_min", C.c_float), ("f_max", C.c_float), ("mel_scale", C.c_uint32),
+                ("mel_norm", C.c_uint32), ("log_mel", C.c_uint32), ("device", C.c_int32)]
+
+
+AF_OUT_MEL, AF_OUT_POWER = 0, 1
+AF_MEL_HTK, AF_MEL_SLANEY = 0, 1
+AF_MEL_NORM_NONE, AF_MEL_NORM_SLANEY = 0, 1
+AF_CH_DOWNMIX, AF_CH_SEPARATE = 0, 1
 
 
 class ChainConfig(C.Structure):
@@ -112,6 +131,7 @@ SIGNATURES = {
     "af_features_create": (_st, [C.POINTER(FeaturesConfig), C.POINTER(_vp)]),
     "af_features_destroy": (None, [_vp]),
     "af_features_n_frames": (_sz, [_vp, _sz]),
+    "af_features_row_len": (_sz, [_vp]),
     "af_features_set_batch": (_st, [_vp, _vp, _sz, _szp]),
     "af_features_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp]),
     "af_features_set_batch_spans": (_st, [_vp, _vp, _vp, _sz, _szp]),
@@ -121,6 +141,21 @@ SIGNATURES = {
     "af_features_kernel_name": (C.c_char_p, []),
     "af_features_debug_stamps": (_st, [_vp, C.c_int, _vp]),
     # full chain
+    "af_stft_default_config": (None, [C.POINTER(StftConfig)]),
+    "af_stft_create": (_st, [C.POINTER(StftConfig), C.POINTER(_vp)]),
+    "af_stft_destroy": (None, [_vp]),
+    "af_stft_n_frames": (_sz, [_vp, _sz]),
+    "af_stft_n_bins": (_sz, [_vp]),
+    "af_stft_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp]),
+    "af_stft_set_batch": (_st, [_vp, _vp, _sz, _szp]),
+    "af_stft_power_device": (_st, [_vp, _vp, _vp, _vp]),
+    "af_stft_power": (_st, [_vp, _vp, _vp, _sz]),
+    "af_mel_default_config": (None, [C.POINTER(MelConfig)]),
+    "af_mel_create": (_st, [C.POINTER(MelConfig), C.POINTER(_vp)]),
+    "af_mel_destroy": (None, [_vp]),
+    "af_mel_weights": (_st, [_vp, _vp, _sz]),
+    "af_mel_apply_device": (_st, [_vp, _vp, _sz, _vp, _vp]),
+    "af_mel_apply": (_st, [_vp, _vp, _sz, _vp, _sz]),
     "af_chain_default_config": (None, [C.POINTER(ChainConfig)]),
     "af_chain_create": (_st, [C.POINTER(ChainConfig), C.POINTER(_vp)]),
     "af_chain_destroy": (None, [_vp]),

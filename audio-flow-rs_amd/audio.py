@@ -438,10 +438,14 @@ class FeaturePipeline:
 
     def __init__(self, sample_rate: int = 48000, channels: int = 2, n_fft: int = 1024,
                  hop: int = 256, n_mels: int = 80, f_min: float = 0.0, f_max: float = 0.0,
-                 sample_format: int = _ffi.AF_PCM_F32, device: int = -1):
+                 sample_format: int = _ffi.AF_PCM_F32, device: int = -1, *,
+                 output: int = _ffi.AF_OUT_MEL, log_mel: bool = False,
+                 mel_scale: int = _ffi.AF_MEL_HTK, mel_norm: int = _ffi.AF_MEL_NORM_NONE,
+                 channel_mode: int = _ffi.AF_CH_DOWNMIX):
         self._lib = library()
         self.cfg = _ffi.FeaturesConfig(sample_rate, channels, n_fft, hop, n_mels, f_min, f_max,
-                                       sample_format, device)
+                                       sample_format, device, output, int(log_mel), mel_scale,
+                                       mel_norm, channel_mode)
         h = C.c_void_p()
         _check(self._lib.af_features_create(C.byref(self.cfg), C.byref(h)))
         self._h = h
@@ -455,6 +459,10 @@ class FeaturePipeline:
     # -- geometry
     def n_frames(self, n_pcm_frames: int) -> int:
         return int(self._lib.af_features_n_frames(self._h, n_pcm_frames))
+
+    def row_len(self) -> int:
+        """floats per output row: n_mels, or n_fft/2+1 with ``output=AF_OUT_POWER``"""
+        return int(self._lib.af_features_row_len(self._h))
 
     def mel_weights(self) -> np.ndarray:
         W = np.empty((self.cfg.n_mels, self.cfg.n_fft // 2 + 1), np.float32)
@@ -512,7 +520,7 @@ class FeaturePipeline:
         """Host buffers: ``pcm`` is the batch's interleaved PCM back to back."""
         dt = np.int16 if self.cfg.sample_format == _ffi.AF_PCM_I16 else np.float32
         x = np.ascontiguousarray(pcm, dt).reshape(-1)
-        mel = np.empty((self.total_frames, self.cfg.n_mels), np.float32)
+        mel = np.empty((self.total_frames, self.row_len()), np.float32)
         _check(self._lib.af_features_run(self._h, _ptr(x), _ptr(mel), mel.size))
         return mel
 
@@ -537,6 +545,93 @@ class FeaturePipeline:
             out.append(MelSpectrogram(mel[row:row + nf], self.cfg.sample_rate, self.cfg.hop))
             row += nf
         return out
+
+
+class Stft:
+    """``Stft::new(n_fft, hop)`` [B]: power spectrogram rows ``[frame][n_fft/2+1]``
+    (docs/OPS.md "STFT"; BASELINE config 1 is ``Stft().power(x)`` on 160 000 samples)."""
+
+    def __init__(self, n_fft: int = 1024, hop: int = 256, channels: int = 1,
+                 sample_format: int = _ffi.AF_PCM_F32, device: int = -1):
+        self._lib = library()
+        self.cfg = _ffi.StftConfig(channels, n_fft, hop, sample_format, device)
+        h = C.c_void_p()
+        _check(self._lib.af_stft_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h
+        self.total_frames = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_stft_destroy(h)
+
+    def n_frames(self, n_pcm_frames: int) -> int:
+        return int(self._lib.af_stft_n_frames(self._h, n_pcm_frames))
+
+    def n_bins(self) -> int:
+        return int(self._lib.af_stft_n_bins(self._h))
+
+    def set_batch_uniform(self, n_clips: int, frames_per_clip: int) -> int:
+        tot = C.c_size_t()
+        _check(self._lib.af_stft_set_batch_uniform(self._h, n_clips, frames_per_clip, C.byref(tot)))
+        self.total_frames = tot.value
+        return self.total_frames
+
+    def set_batch(self, clip_frame_offsets: Sequence[int]) -> int:
+        off = np.ascontiguousarray(clip_frame_offsets, np.int64)
+        tot = C.c_size_t()
+        _check(self._lib.af_stft_set_batch(self._h, _ptr(off), off.size - 1, C.byref(tot)))
+        self.total_frames = tot.value
+        return self.total_frames
+
+    def power_device(self, pcm_ptr: int, power_ptr: int, stream: int = 0) -> None:
+        _check(self._lib.af_stft_power_device(self._h, C.c_void_p(pcm_ptr), C.c_void_p(power_ptr),
+                                              C.c_void_p(stream)))
+
+    def power(self, pcm: np.ndarray) -> np.ndarray:
+        """One clip (or the batch set before): rows of |X[k]|^2."""
+        dt = np.int16 if self.cfg.sample_format == _ffi.AF_PCM_I16 else np.float32
+        x = np.ascontiguousarray(pcm, dt).reshape(-1)
+        if self.total_frames == 0:
+            self.set_batch_uniform(1, x.size // self.cfg.channels)
+        out = np.empty((self.total_frames, self.n_bins()), np.float32)
+        _check(self._lib.af_stft_power(self._h, _ptr(x), _ptr(out), out.size))
+        return out
+
+
+class MelFilterbank:
+    """``MelFilterbank::new(sr, n_fft, n_mels)`` [B]: weights and ``mel = power @ W.T`` on MFMA."""
+
+    def __init__(self, sample_rate: int = 16000, n_fft: int = 1024, n_mels: int = 80,
+                 f_min: float = 0.0, f_max: float = 0.0, mel_scale: int = _ffi.AF_MEL_HTK,
+                 mel_norm: int = _ffi.AF_MEL_NORM_NONE, log_mel: bool = False, device: int = -1):
+        self._lib = library()
+        self.cfg = _ffi.MelConfig(sample_rate, n_fft, n_mels, f_min, f_max, mel_scale, mel_norm,
+                                  int(log_mel), device)
+        h = C.c_void_p()
+        _check(self._lib.af_mel_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_mel_destroy(h)
+
+    def weights(self) -> np.ndarray:
+        W = np.empty((self.cfg.n_mels, self.cfg.n_fft // 2 + 1), np.float32)
+        _check(self._lib.af_mel_weights(self._h, _ptr(W), W.size))
+        return W
+
+    def apply_device(self, power_ptr: int, n_frames: int, mel_ptr: int, stream: int = 0) -> None:
+        _check(self._lib.af_mel_apply_device(self._h, C.c_void_p(power_ptr), n_frames,
+                                             C.c_void_p(mel_ptr), C.c_void_p(stream)))
+
+    def apply(self, power: np.ndarray) -> np.ndarray:
+        p = np.ascontiguousarray(power, np.float32)
+        n = p.shape[0] if p.ndim == 2 else p.size // (self.cfg.n_fft // 2 + 1)
+        mel = np.empty((n, self.cfg.n_mels), np.float32)
+        _check(self._lib.af_mel_apply(self._h, _ptr(p), n, _ptr(mel), mel.size))
+        return mel
 
 
 class ChainPipeline:

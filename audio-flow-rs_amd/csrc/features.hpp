@@ -42,7 +42,7 @@ struct Plan {
 
 struct Params {
     const void* pcm;          // interleaved PCM (f32 or i16)
-    float* mel;               // [total_frames][n_mels]
+    float* mel;               // [total_frames][n_mels]  (or [total_frames][513] power rows)
     const float* wintab;      // [32][kWinRow]: row n2 holds 0.5 * hann[32 n1 + n2], n1 = 0..31
     const float* twtab;       // [32][kTwRow]: row n2 holds (cos, sin)(2 pi k1 n2 / 1024), k1 = 0..31
     const float* wfrag;       // [4][kMaxSlotsW][64][4] MFMA A fragments: one float4 per lane and slot
@@ -56,6 +56,9 @@ struct Params {
     int n_clips;
     int hop;
     int aligned16;            // every clip base and every staging unit is 16-B aligned
+    int out_power;            // 1: write |X|^2 rows [frame][513] instead of mel rows
+    int log_mel;              // 1: mel rows hold log10(max(mel, 1e-10))
+    int separate;             // 1 (stereo only): table entry e is channel e & 1 of clip e / 2
     unsigned long long* stamps;  // diagnostics only: [4 waves][8] summed phase cycles, or null
 };
 
@@ -63,6 +66,18 @@ struct Params {
 af_status launch_features(const Params& p, int channels, bool i16, int grid, size_t smem_bytes,
                           hipStream_t stream);
 size_t features_smem_bytes(int hop);
+
+// stand-alone mel contraction: power rows [n_frames][513] -> mel rows [n_frames][n_mels]
+struct MelApplyParams {
+    const float* power;
+    float* mel;
+    const float* wfrag;
+    const int* meta;
+    Plan plan;
+    int64_t n_frames;
+    int log_mel;
+};
+af_status launch_mel_apply(const MelApplyParams& p, int grid, hipStream_t stream);
 
 }  // namespace feat
 }  // namespace af

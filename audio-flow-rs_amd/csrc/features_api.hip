@@ -40,24 +40,40 @@ namespace {
 
 constexpr double kPi = 3.14159265358979323846;
 
-double hz_to_mel(double hz) { return 2595.0 * std::log10(1.0 + hz / 700.0); }
-double mel_to_hz(double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); }
+// docs/OPS.md "Mel filterbank": HTK 2595 log10(1 + f/700); Slaney: linear (200/3 Hz per mel)
+// below 1 kHz, logarithmic (27 mels per factor 6.4) above
+double hz_to_mel(double hz, bool slaney)
+{
+    if (!slaney) return 2595.0 * std::log10(1.0 + hz / 700.0);
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    return hz >= min_log_hz ? min_log_mel + std::log(hz / min_log_hz) / logstep : hz / f_sp;
+}
+double mel_to_hz(double m, bool slaney)
+{
+    if (!slaney) return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
 
-// docs/OPS.md "Mel": HTK scale, triangular, no area normalisation
+// docs/OPS.md "Mel filterbank": triangular; optional Slaney area normalisation 2/(e[m+2]-e[m])
 void build_mel(const af_features_config& c, double f_max, std::vector<float>& W)
 {
     const int nm = (int)c.n_mels;
+    const bool sl = c.mel_scale == AF_MEL_SLANEY;
     std::vector<double> edges(nm + 2);
-    const double m_lo = hz_to_mel(c.f_min), m_hi = hz_to_mel(f_max);
+    const double m_lo = hz_to_mel(c.f_min, sl), m_hi = hz_to_mel(f_max, sl);
     for (int i = 0; i < nm + 2; ++i)
-        edges[i] = mel_to_hz(m_lo + (m_hi - m_lo) * (double)i / (double)(nm + 1));
+        edges[i] = mel_to_hz(m_lo + (m_hi - m_lo) * (double)i / (double)(nm + 1), sl);
     W.assign((size_t)nm * kBins, 0.0f);
     for (int m = 0; m < nm; ++m) {
         const double lo = edges[m], ce = edges[m + 1], hi = edges[m + 2];
         for (int k = 0; k < kBins; ++k) {
             const double f = (double)k * (double)c.sample_rate / (double)kNfft;
             const double up = (f - lo) / (ce - lo), dn = (hi - f) / (hi - ce);
-            const double v = up < dn ? up : dn;
+            double v = up < dn ? up : dn;
+            if (c.mel_norm == AF_MEL_NORM_SLANEY) v *= 2.0 / (hi - lo);
             W[(size_t)m * kBins + k] = v > 0.0 ? (float)v : 0.0f;
         }
     }
@@ -183,9 +199,19 @@ size_t bytes_per_frame(const af_features_config& c)
 }
 
 // spans: clip c = PCM frames [start[c], start[c] + len[c]) of the buffer (may overlap)
-af_status upload_tables(af_features* p, const std::vector<int64_t>& start,
-                        const std::vector<int64_t>& len)
+af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
+                        const std::vector<int64_t>& len_in)
 {
+    // AF_CH_SEPARATE: table entry 2c + ch is channel ch of clip c (same PCM span twice)
+    std::vector<int64_t> start, len;
+    if (p->cfg.channel_mode == AF_CH_SEPARATE) {
+        for (size_t c = 0; c < start_in.size(); ++c)
+            for (int ch = 0; ch < 2; ++ch) { start.push_back(start_in[c]); len.push_back(len_in[c]); }
+    } else {
+        start = start_in;
+        len = len_in;
+    }
+    p->n_clips = start.size();
     const size_t n = p->n_clips;
     // start[n] | len[n] | out_off[n+1] | unit_off[n+1]
     std::vector<int64_t> tab(2 * n + 2 * (n + 1));
@@ -233,6 +259,11 @@ void af_features_default_config(af_features_config* cfg)
     cfg->f_max = 0.0f;
     cfg->sample_format = AF_PCM_F32;
     cfg->device = -1;
+    cfg->output = AF_OUT_MEL;
+    cfg->log_mel = 0;
+    cfg->mel_scale = AF_MEL_HTK;
+    cfg->mel_norm = AF_MEL_NORM_NONE;
+    cfg->channel_mode = AF_CH_DOWNMIX;
 }
 
 af_status af_features_create(const af_features_config* cfg, af_features** out)
@@ -249,6 +280,11 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     AF_REQUIRE(cfg->sample_rate > 0, "sample_rate must be positive");
     AF_REQUIRE(cfg->sample_format == AF_PCM_F32 || cfg->sample_format == AF_PCM_I16,
                "unknown sample_format %u", cfg->sample_format);
+    AF_REQUIRE(cfg->output <= AF_OUT_POWER && cfg->log_mel <= 1 && cfg->mel_scale <= AF_MEL_SLANEY &&
+                   cfg->mel_norm <= AF_MEL_NORM_SLANEY && cfg->channel_mode <= AF_CH_SEPARATE,
+               "unknown output / mel / channel option");
+    AF_REQUIRE(cfg->channel_mode == AF_CH_DOWNMIX || cfg->channels == 2,
+               "AF_CH_SEPARATE needs interleaved stereo");
     const double f_max = cfg->f_max > 0.0f ? (double)cfg->f_max : 0.5 * (double)cfg->sample_rate;
     AF_REQUIRE((double)cfg->f_min >= 0.0 && (double)cfg->f_min < f_max, "need 0 <= f_min < f_max");
 
@@ -311,6 +347,12 @@ size_t af_features_n_frames(const af_features* p, size_t n_pcm_frames)
 {
     if (!p || n_pcm_frames < p->cfg.n_fft) return 0;
     return 1 + (n_pcm_frames - p->cfg.n_fft) / p->cfg.hop;
+}
+
+size_t af_features_row_len(const af_features* p)
+{
+    if (!p) return 0;
+    return p->cfg.output == AF_OUT_POWER ? (size_t)kBins : (size_t)p->cfg.n_mels;
 }
 
 af_status af_features_set_batch(af_features* p, const int64_t* clip_offsets, size_t n_clips,
@@ -377,6 +419,9 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     prm.n_clips = (int)p->n_clips;
     prm.hop = (int)p->cfg.hop;
     prm.stamps = p->d_stamps.as<unsigned long long>();
+    prm.out_power = p->cfg.output == AF_OUT_POWER;
+    prm.log_mel = (int)p->cfg.log_mel;
+    prm.separate = p->cfg.channel_mode == AF_CH_SEPARATE;
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
     const size_t smem = features_smem_bytes(prm.hop);
     AF_REQUIRE(smem <= 160 * 1024, "hop %d needs %zu bytes of LDS", prm.hop, smem);
@@ -397,7 +442,7 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
 af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t mel_cap)
 {
     AF_REQUIRE(p, "af_features_run: null handle");
-    const size_t n_out = (size_t)p->total_frames * p->cfg.n_mels;
+    const size_t n_out = (size_t)p->total_frames * af_features_row_len(p);
     if (mel_cap < n_out)
         return fail(AF_ERR_BUFFER_TOO_SMALL, "mel buffer holds %zu floats, need %zu", mel_cap, n_out);
     if (n_out == 0) return AF_OK;
@@ -437,6 +482,170 @@ af_status af_features_debug_stamps(af_features* p, int enable, unsigned long lon
     } else {
         p->d_stamps.release();
     }
+    return AF_OK;
+}
+
+// ---- Stft: the fused kernel with AF_OUT_POWER -----------------------------------------------
+struct af_stft {
+    af_features* f = nullptr;
+};
+
+void af_stft_default_config(af_stft_config* cfg)
+{
+    if (!cfg) return;
+    cfg->channels = 1;
+    cfg->n_fft = kNfft;
+    cfg->hop = 256;
+    cfg->sample_format = AF_PCM_F32;
+    cfg->device = -1;
+}
+
+af_status af_stft_create(const af_stft_config* cfg, af_stft** out)
+{
+    AF_REQUIRE(cfg && out, "af_stft_create: null argument");
+    *out = nullptr;
+    af_features_config fc;
+    af_features_default_config(&fc);
+    fc.sample_rate = 16000;                 // only shapes the (unused) filterbank
+    fc.channels = cfg->channels;
+    fc.n_fft = cfg->n_fft;
+    fc.hop = cfg->hop;
+    fc.sample_format = cfg->sample_format;
+    fc.device = cfg->device;
+    fc.output = AF_OUT_POWER;
+    af_stft* s = new (std::nothrow) af_stft();
+    if (!s) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
+    const af_status st = af_features_create(&fc, &s->f);
+    if (st != AF_OK) { delete s; return st; }
+    *out = s;
+    return AF_OK;
+}
+
+void af_stft_destroy(af_stft* s)
+{
+    if (!s) return;
+    af_features_destroy(s->f);
+    delete s;
+}
+
+size_t af_stft_n_frames(const af_stft* s, size_t n_pcm_frames)
+{
+    return s ? af_features_n_frames(s->f, n_pcm_frames) : 0;
+}
+size_t af_stft_n_bins(const af_stft* s) { return s ? (size_t)kBins : 0; }
+
+af_status af_stft_set_batch_uniform(af_stft* s, size_t n_clips, size_t frames_per_clip,
+                                    size_t* total_frames_out)
+{
+    AF_REQUIRE(s, "af_stft_set_batch_uniform: null handle");
+    return af_features_set_batch_uniform(s->f, n_clips, frames_per_clip, total_frames_out);
+}
+af_status af_stft_set_batch(af_stft* s, const int64_t* clip_offsets, size_t n_clips,
+                            size_t* total_frames_out)
+{
+    AF_REQUIRE(s, "af_stft_set_batch: null handle");
+    return af_features_set_batch(s->f, clip_offsets, n_clips, total_frames_out);
+}
+af_status af_stft_power_device(af_stft* s, const void* pcm_dev, float* power_dev, void* stream)
+{
+    AF_REQUIRE(s, "af_stft_power_device: null handle");
+    return af_features_run_device(s->f, pcm_dev, power_dev, stream);
+}
+af_status af_stft_power(af_stft* s, const void* pcm, float* power, size_t power_cap)
+{
+    AF_REQUIRE(s, "af_stft_power: null handle");
+    return af_features_run(s->f, pcm, power, power_cap);
+}
+
+// ---- MelFilterbank: weights + the stand-alone contraction ------------------------------------
+struct af_mel {
+    af_features* f = nullptr;            // owns W, the MFMA plan and its device tables
+    DevBuf d_in, d_out;
+};
+
+void af_mel_default_config(af_mel_config* cfg)
+{
+    if (!cfg) return;
+    cfg->sample_rate = 16000;
+    cfg->n_fft = kNfft;
+    cfg->n_mels = 80;
+    cfg->f_min = 0.0f;
+    cfg->f_max = 0.0f;
+    cfg->mel_scale = AF_MEL_HTK;
+    cfg->mel_norm = AF_MEL_NORM_NONE;
+    cfg->log_mel = 0;
+    cfg->device = -1;
+}
+
+af_status af_mel_create(const af_mel_config* cfg, af_mel** out)
+{
+    AF_REQUIRE(cfg && out, "af_mel_create: null argument");
+    *out = nullptr;
+    af_features_config fc;
+    af_features_default_config(&fc);
+    fc.sample_rate = cfg->sample_rate;
+    fc.channels = 1;
+    fc.n_fft = cfg->n_fft;
+    fc.n_mels = cfg->n_mels;
+    fc.f_min = cfg->f_min;
+    fc.f_max = cfg->f_max;
+    fc.mel_scale = cfg->mel_scale;
+    fc.mel_norm = cfg->mel_norm;
+    fc.log_mel = cfg->log_mel;
+    fc.device = cfg->device;
+    af_mel* m = new (std::nothrow) af_mel();
+    if (!m) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
+    const af_status st = af_features_create(&fc, &m->f);
+    if (st != AF_OK) { delete m; return st; }
+    *out = m;
+    return AF_OK;
+}
+
+void af_mel_destroy(af_mel* m)
+{
+    if (!m) return;
+    af_features_destroy(m->f);
+    delete m;
+}
+
+af_status af_mel_weights(const af_mel* m, float* W, size_t cap)
+{
+    AF_REQUIRE(m, "af_mel_weights: null handle");
+    return af_features_mel_weights(m->f, W, cap);
+}
+
+af_status af_mel_apply_device(af_mel* m, const float* power_dev, size_t n_frames, float* mel_dev,
+                              void* stream)
+{
+    AF_REQUIRE(m, "af_mel_apply_device: null handle");
+    if (n_frames == 0) return AF_OK;
+    AF_REQUIRE(power_dev && mel_dev, "af_mel_apply_device: null buffer");
+    MelApplyParams prm{};
+    prm.power = power_dev;
+    prm.mel = mel_dev;
+    prm.wfrag = m->f->d_wfrag;
+    prm.meta = m->f->d_meta;
+    prm.plan = m->f->plan;
+    prm.n_frames = (int64_t)n_frames;
+    prm.log_mel = (int)m->f->cfg.log_mel;
+    const int64_t units = ((int64_t)n_frames + kFramesPerIter - 1) / kFramesPerIter;
+    int64_t grid = (int64_t)m->f->n_cus * 2;
+    if (grid > units) grid = units;
+    return launch_mel_apply(prm, (int)grid, as_stream(stream));
+}
+
+af_status af_mel_apply(af_mel* m, const float* power, size_t n_frames, float* mel, size_t mel_cap)
+{
+    AF_REQUIRE(m, "af_mel_apply: null handle");
+    const size_t n_out = n_frames * m->f->cfg.n_mels;
+    if (mel_cap < n_out) return fail(AF_ERR_BUFFER_TOO_SMALL, "mel buffer holds %zu floats, need %zu", mel_cap, n_out);
+    if (n_frames == 0) return AF_OK;
+    AF_REQUIRE(power && mel, "af_mel_apply: null buffer");
+    AF_TRY(m->d_in.reserve(n_frames * kBins * sizeof(float)));
+    AF_TRY(m->d_out.reserve(n_out * sizeof(float)));
+    AF_HIP(hipMemcpy(m->d_in.p, power, n_frames * kBins * sizeof(float), hipMemcpyHostToDevice));
+    AF_TRY(af_mel_apply_device(m, m->d_in.as<float>(), n_frames, m->d_out.as<float>(), nullptr));
+    AF_HIP(hipMemcpy(mel, m->d_out.p, n_out * sizeof(float), hipMemcpyDeviceToHost));
     return AF_OK;
 }
 

@@ -141,8 +141,9 @@ struct Stage {
         return uint4{r[0], r[1], r[2], r[3]};
     }
 
-    // raw bytes -> mono samples
-    __device__ static __forceinline__ void convert(const uint4 raw, float (&m)[MS])
+    // raw bytes -> mono samples.  sel < 0: to_mono downmix; sel = 0 / 1 (stereo only): that
+    // channel alone ("separate channels" mode, wave-uniform).
+    __device__ static __forceinline__ void convert(const uint4 raw, float (&m)[MS], int sel)
     {
         const uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
         if constexpr (!I16) {
@@ -152,9 +153,12 @@ struct Stage {
             if constexpr (CH == 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) m[i] = f[i];
-            } else {
+            } else if (sel < 0) {
                 m[0] = (f[0] + f[1]) * 0.5f;
                 m[1] = (f[2] + f[3]) * 0.5f;
+            } else {
+                m[0] = sel ? f[1] : f[0];
+                m[1] = sel ? f[3] : f[2];
             }
         } else {
             float f[8];
@@ -166,17 +170,20 @@ struct Stage {
             if constexpr (CH == 1) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) m[i] = f[i];
-            } else {
+            } else if (sel < 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) m[i] = (f[2 * i] + f[2 * i + 1]) * 0.5f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i] = sel ? f[2 * i + 1] : f[2 * i];
             }
         }
     }
 
     __device__ static __forceinline__ void load(const void* pcm, int64_t base, int64_t pos,
-                                                int64_t n, bool aligned, float (&m)[MS])
+                                                int64_t n, bool aligned, float (&m)[MS], int sel)
     {
-        convert(load_raw(pcm, base, pos, n, aligned), m);
+        convert(load_raw(pcm, base, pos, n, aligned), m, sel);
     }
 
     __device__ static __forceinline__ void store(float* dst, const float (&m)[MS])
@@ -333,7 +340,7 @@ __device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restr
                                           const float (&wf)[kMaxSteps], int n_slots,
                                           const int (&slot_end)[kMaxSlotsW],
                                           float* __restrict__ orow, bool fvalid, bool vec_ok,
-                                          int lane, unsigned long long (&acc_t)[8],
+                                          bool log_out, int lane, unsigned long long (&acc_t)[8],
                                           unsigned long long& t_prev)
 {
     const int f = lane & 15, kq = lane >> 4;
@@ -368,7 +375,11 @@ __device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restr
             }
             const int e = slot_end[q];            // wave-uniform (kernarg)
             if (e != 0) {
-                const f32x4 r = acc0 + acc1;
+                f32x4 r = acc0 + acc1;
+                if (log_out) {                    // wave-uniform: log10(max(mel, 1e-10))
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = __log10f(fmaxf(r[i], 1e-10f));
+                }
                 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
                 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int m0 = e & 255, cnt = (e >> 8) & 31;
@@ -470,13 +481,14 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         const int64_t c_frames = p.out_off[c + 1] - c_out0;
         const int64_t c_u1 = p.unit_off[c + 1];
         const int64_t F0 = (u - p.unit_off[c]) * kFramesPerIter;
+        const int sel = (CH == 2 && p.separate) ? (c & 1) : -1;   // entry 2 clip + channel
 
         if (fresh) {
             __syncthreads();                      // nobody still reads the old tile
             const int64_t pos0 = F0 * hop;
             for (int v = tid; v * MS < tile_alloc; v += kThreads) {
                 float m[MS];
-                St::load(p.pcm, c_pcm0, pos0 + (int64_t)v * MS, c_n, aligned, m);
+                St::load(p.pcm, c_pcm0, pos0 + (int64_t)v * MS, c_n, aligned, m, sel);
                 St::store(tile + v * MS, m);
             }
         }
@@ -526,7 +538,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
                 const float4* wp = reinterpret_cast<const float4*>(wfrag_w) + opaque_zero;
 #pragma unroll
                 for (int q4 = 0; q4 < kMaxSlotsW; q4 += 4) {
-                    if (q4 < n_slots_w) {         // wave-uniform: skip unused slots
+                    if (q4 < n_slots_w && !p.out_power) {   // wave-uniform: skip unused slots
 #pragma unroll
                         for (int q = q4; q < q4 + 4; ++q) {
                             const float4 v = wp[q * 64];
@@ -556,13 +568,13 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
                 for (int i = 0; i < PFU; ++i) {
                     const int v = tid + i * kThreads;
                     float m[MS];
-                    St::convert(pf[i], m);
+                    St::convert(pf[i], m, sel);
                     St::store(tile + tail_len + v * MS, m);
                 }
             } else {
                 for (int v = tid; v * MS < 16 * hop; v += kThreads) {
                     float m[MS];
-                    St::load(p.pcm, c_pcm0, next_pos0 + (int64_t)v * MS, c_n, aligned, m);
+                    St::load(p.pcm, c_pcm0, next_pos0 + (int64_t)v * MS, c_n, aligned, m, sel);
                     St::store(tile + tail_len + v * MS, m);
                 }
             }
@@ -572,8 +584,22 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         {
             const int j = lane & 15;
             float* orow = p.mel + (c_out0 + F0 + j) * n_mels;
-            mel_phase<STAMPS>(wbufs, lmeta + w * kMaxSteps, wf, n_slots_w, slot_end_w, orow, F0 + j < c_frames,
-                              vec_ok, lane, acc_t, t_prev);
+            if (!p.out_power) {
+                mel_phase<STAMPS>(wbufs, lmeta + w * kMaxSteps, wf, n_slots_w, slot_end_w, orow,
+                                  F0 + j < c_frames, vec_ok, p.log_mel != 0, lane, acc_t, t_prev);
+            } else {
+                // power output: this wave's four rows [frame][513], consecutive lanes on
+                // consecutive bins
+                const float* rows = wbufs + w * kWbuf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t f = F0 + 4 * w + r;
+                    if (f < c_frames) {
+                        float* o = p.mel + (c_out0 + f) * kBins;
+                        for (int k = lane; k < kBins; k += 64) o[k] = rows[r * kProw + k];
+                    }
+                }
+            }
         }
         AF_STAMP(6);
         AF_STAMP(7);
@@ -582,6 +608,56 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
     }
     if (STAMPS && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(p.stamps + w * 8 + i, acc_t[i]);
+}
+
+// ---------------------------------------------------------------------------
+// Stand-alone mel contraction (af_mel_apply): 16 power rows per iteration are staged in the
+// layout the fused kernel's FFT leaves them in, then the same mel phase runs.  The filterbank
+// fragments stay in registers for the whole launch.
+__global__ __launch_bounds__(kThreads, 2) void af_mel_apply_kernel(const MelApplyParams p)
+{
+    __shared__ __attribute__((aligned(16))) float wbufs[kWaves * kWbuf];
+    __shared__ int lmeta[kWaves * kMaxSteps];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < kWaves * kMaxSteps; i += kThreads) lmeta[i] = p.meta[i];
+    const float4* wp = reinterpret_cast<const float4*>(p.wfrag + (((size_t)w * kMaxSlotsW) * 64 + lane) * 4);
+    float wf[kMaxSteps];
+#pragma unroll
+    for (int q = 0; q < kMaxSlotsW; ++q) {
+        const float4 v = wp[q * 64];
+        wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+    }
+    const int n_slots_w = p.plan.wave_nslots[w];
+    int slot_end_w[kMaxSlotsW];
+#pragma unroll
+    for (int q = 0; q < kMaxSlotsW; ++q) slot_end_w[q] = p.plan.slot_end[w][q];
+    const int n_mels = p.plan.n_mels;
+    const bool vec_ok = (n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(p.mel) % 16 == 0);
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    const int64_t n_units = (p.n_frames + kFramesPerIter - 1) / kFramesPerIter;
+    for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int64_t F0 = u * kFramesPerIter;
+        __syncthreads();                              // the previous unit's operands are read
+        for (int i = tid; i < kFramesPerIter * kBins; i += kThreads) {
+            const int f = i / kBins, k = i - f * kBins;
+            wbufs[(f >> 2) * kWbuf + (f & 3) * kProw + k] =
+                (F0 + f < p.n_frames) ? p.power[(F0 + f) * kBins + k] : 0.0f;
+        }
+        __syncthreads();
+        const int j = lane & 15;
+        float* orow = p.mel + (F0 + j) * n_mels;
+        mel_phase<false>(wbufs, lmeta + w * kMaxSteps, wf, n_slots_w, slot_end_w, orow,
+                         F0 + j < p.n_frames, vec_ok, p.log_mel != 0, lane, acc_t, t_prev);
+    }
+}
+
+af_status launch_mel_apply(const MelApplyParams& p, int grid, hipStream_t stream)
+{
+    if (grid <= 0) return AF_OK;
+    hipLaunchKernelGGL(af_mel_apply_kernel, dim3(grid), dim3(kThreads), 0, stream, p);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
 }
 
 size_t features_smem_bytes(int hop)

@@ -237,6 +237,70 @@ struct MelSpectrogram {
     size_t n_frames = 0, n_mels = 0;
 };
 
+// Stft::new(n_fft, hop) [B]: power spectrogram rows [frame][n_fft/2+1]
+class Stft {
+public:
+    explicit Stft(uint32_t hop = 256, uint32_t channels = 1)
+    {
+        af_stft_config c;
+        af_stft_default_config(&c);
+        c.hop = hop;
+        c.channels = channels;
+        detail::check(af_stft_create(&c, &h_));
+    }
+    Stft(const Stft&) = delete;
+    Stft& operator=(const Stft&) = delete;
+    ~Stft() { af_stft_destroy(h_); }
+    size_t n_frames(size_t n_pcm_frames) const { return af_stft_n_frames(h_, n_pcm_frames); }
+    size_t n_bins() const { return af_stft_n_bins(h_); }
+    // one clip of interleaved PCM -> [n_frames][n_bins]
+    std::vector<float> power(const std::vector<float>& pcm, uint32_t channels = 1)
+    {
+        size_t total = 0;
+        detail::check(af_stft_set_batch_uniform(h_, 1, pcm.size() / channels, &total));
+        std::vector<float> out(total * n_bins());
+        detail::check(af_stft_power(h_, pcm.data(), out.data(), out.size()));
+        return out;
+    }
+
+private:
+    af_stft* h_ = nullptr;
+};
+
+// MelFilterbank::new(sr, n_fft, n_mels) [B]
+class MelFilterbank {
+public:
+    explicit MelFilterbank(uint32_t sample_rate = 16000, uint32_t n_mels = 80)
+    {
+        af_mel_default_config(&cfg_);
+        cfg_.sample_rate = sample_rate;
+        cfg_.n_mels = n_mels;
+        detail::check(af_mel_create(&cfg_, &h_));
+    }
+    explicit MelFilterbank(const af_mel_config& cfg) : cfg_(cfg) { detail::check(af_mel_create(&cfg_, &h_)); }
+    MelFilterbank(const MelFilterbank&) = delete;
+    MelFilterbank& operator=(const MelFilterbank&) = delete;
+    ~MelFilterbank() { af_mel_destroy(h_); }
+    std::vector<float> weights() const
+    {
+        std::vector<float> W((size_t)cfg_.n_mels * (cfg_.n_fft / 2 + 1));
+        detail::check(af_mel_weights(h_, W.data(), W.size()));
+        return W;
+    }
+    // power rows [n_frames][n_fft/2+1] -> mel rows [n_frames][n_mels]
+    std::vector<float> apply(const std::vector<float>& power)
+    {
+        const size_t n = power.size() / (cfg_.n_fft / 2 + 1);
+        std::vector<float> mel(n * cfg_.n_mels);
+        detail::check(af_mel_apply(h_, power.data(), n, mel.data(), mel.size()));
+        return mel;
+    }
+
+private:
+    af_mel_config cfg_;
+    af_mel* h_ = nullptr;
+};
+
 class FeaturePipeline {
 public:
     explicit FeaturePipeline(const af_features_config& cfg) : cfg_(cfg)

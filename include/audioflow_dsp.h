@@ -201,12 +201,26 @@ typedef struct {
     float    f_max;          /* Hz; 0 => sample_rate/2 */
     uint32_t sample_format;  /* AF_PCM_F32 or AF_PCM_I16 */
     int32_t  device;         /* HIP device ordinal, -1 = current */
+    uint32_t output;         /* AF_OUT_MEL: rows of n_mels values; AF_OUT_POWER: rows of the
+                                n_fft/2+1 = 513 values |X[k]|^2 */
+    uint32_t log_mel;        /* 1: mel rows hold log10(max(mel, 1e-10)) */
+    uint32_t mel_scale;      /* AF_MEL_HTK (default) or AF_MEL_SLANEY */
+    uint32_t mel_norm;       /* AF_MEL_NORM_NONE (default) or AF_MEL_NORM_SLANEY (2/(f[m+2]-f[m])) */
+    uint32_t channel_mode;   /* AF_CH_DOWNMIX: to_mono first (capture.rs:30-42);
+                                AF_CH_SEPARATE (stereo): one spectrogram per channel, rows laid
+                                out [clip][channel][frame] */
 } af_features_config;
+enum { AF_OUT_MEL = 0, AF_OUT_POWER = 1 };
+enum { AF_MEL_HTK = 0, AF_MEL_SLANEY = 1 };
+enum { AF_MEL_NORM_NONE = 0, AF_MEL_NORM_SLANEY = 1 };
+enum { AF_CH_DOWNMIX = 0, AF_CH_SEPARATE = 1 };
 void      af_features_default_config(af_features_config* cfg); /* 48 kHz stereo, 1024/256, 80 mels */
 af_status af_features_create(const af_features_config* cfg, af_features** out);
 void      af_features_destroy(af_features* p);
 /* 1 + floor((n_pcm_frames - n_fft)/hop), 0 if shorter than n_fft */
 size_t    af_features_n_frames(const af_features* p, size_t n_pcm_frames);
+/* floats per output row: n_mels, or 513 with AF_OUT_POWER */
+size_t    af_features_row_len(const af_features* p);
 /* Describe the batch once (uploads small per-clip tables):
  * clip c occupies PCM frames [clip_offsets[c], clip_offsets[c+1]) of the
  * buffer (n_clips+1 monotone offsets, in frames).  Output rows are the
@@ -237,6 +251,48 @@ const char* af_features_kernel_name(void);
 /* diagnostics: enable/disable in-kernel phase stamps; out[32] (optional) receives the
  * [wave][phase] shader-cycle sums recorded since they were enabled */
 af_status af_features_debug_stamps(af_features* p, int enable, unsigned long long* out);
+
+/* Stft (docs/OPS.md "STFT"): the power spectrogram alone, rows [frame][n_fft/2+1] -- the
+ * fused kernel with AF_OUT_POWER behind the Stft::new(n_fft, hop) shape of SURVEY.md
+ * section 8(b).  BASELINE config 1 (160 000 mono samples -> 622 x 513) is this call. */
+typedef struct af_stft af_stft;
+typedef struct {
+    uint32_t channels;       /* 1 or 2 (interleaved; 2 is downmixed first) */
+    uint32_t n_fft;          /* 1024 */
+    uint32_t hop;
+    uint32_t sample_format;
+    int32_t  device;
+} af_stft_config;
+void      af_stft_default_config(af_stft_config* cfg);         /* mono f32, 1024/256 */
+af_status af_stft_create(const af_stft_config* cfg, af_stft** out);
+void      af_stft_destroy(af_stft* s);
+size_t    af_stft_n_frames(const af_stft* s, size_t n_pcm_frames);
+size_t    af_stft_n_bins(const af_stft* s);                    /* n_fft/2 + 1 */
+af_status af_stft_set_batch_uniform(af_stft* s, size_t n_clips, size_t frames_per_clip,
+                                    size_t* total_frames_out);
+af_status af_stft_set_batch(af_stft* s, const int64_t* clip_offsets, size_t n_clips,
+                            size_t* total_frames_out);
+af_status af_stft_power_device(af_stft* s, const void* pcm_dev, float* power_dev, void* stream);
+af_status af_stft_power(af_stft* s, const void* pcm, float* power, size_t power_cap);
+
+/* MelFilterbank (docs/OPS.md "Mel filterbank"): weights and the stand-alone contraction
+ * mel[f][m] = sum_k W[m][k] power[f][k] on MFMA, for callers that keep the power spectrum. */
+typedef struct af_mel af_mel;
+typedef struct {
+    uint32_t sample_rate;
+    uint32_t n_fft;          /* 1024 */
+    uint32_t n_mels;
+    float    f_min, f_max;   /* f_max 0 => sample_rate/2 */
+    uint32_t mel_scale, mel_norm, log_mel;
+    int32_t  device;
+} af_mel_config;
+void      af_mel_default_config(af_mel_config* cfg);           /* 16 kHz, 1024, 80 HTK mels */
+af_status af_mel_create(const af_mel_config* cfg, af_mel** out);
+void      af_mel_destroy(af_mel* m);
+af_status af_mel_weights(const af_mel* m, float* W, size_t cap);   /* [n_mels][n_fft/2+1] */
+af_status af_mel_apply_device(af_mel* m, const float* power_dev, size_t n_frames,
+                              float* mel_dev, void* stream);
+af_status af_mel_apply(af_mel* m, const float* power, size_t n_frames, float* mel, size_t mel_cap);
 
 /* The whole chain of BASELINE config 4 behind one handle:
  * interleaved PCM -> to_mono (capture.rs:30-42) -> polyphase resample -> FIR -> STFT -> mel,

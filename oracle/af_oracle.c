@@ -412,14 +412,29 @@ void afo_level_meter_f64(const float* x, size_t n, double* rms, double* peak, do
 double afo_hz_to_mel_htk(double hz) { return 2595.0 * log10(1.0 + hz / 700.0); }
 double afo_mel_to_hz_htk(double mel) { return 700.0 * (pow(10.0, mel / 2595.0) - 1.0); }
 
-void afo_mel_weights(double sample_rate, size_t n_fft, size_t n_mels,
-                     double f_min, double f_max, double* W)
+/* docs/OPS.md "Mel filterbank": the Slaney scale is linear (200/3 Hz per mel) below 1 kHz and
+ * logarithmic (27 mels per factor 6.4) above. */
+static double hz_to_mel_any(double hz, int slaney)
+{
+    if (!slaney) return afo_hz_to_mel_htk(hz);
+    const double f_sp = 200.0 / 3.0, brk = 1000.0, logstep = log(6.4) / 27.0;
+    return hz >= brk ? brk / f_sp + log(hz / brk) / logstep : hz / f_sp;
+}
+static double mel_to_hz_any(double mel, int slaney)
+{
+    if (!slaney) return afo_mel_to_hz_htk(mel);
+    const double f_sp = 200.0 / 3.0, brk = 1000.0, logstep = log(6.4) / 27.0;
+    return mel >= brk / f_sp ? brk * exp(logstep * (mel - brk / f_sp)) : f_sp * mel;
+}
+
+void afo_mel_weights_ex(double sample_rate, size_t n_fft, size_t n_mels, double f_min,
+                        double f_max, int scale, int norm, double* W)
 {
     size_t nb = n_fft / 2 + 1;
     double* edges = (double*)malloc((n_mels + 2) * sizeof(double));
-    double m_lo = afo_hz_to_mel_htk(f_min), m_hi = afo_hz_to_mel_htk(f_max);
+    double m_lo = hz_to_mel_any(f_min, scale), m_hi = hz_to_mel_any(f_max, scale);
     for (size_t i = 0; i < n_mels + 2; ++i)
-        edges[i] = afo_mel_to_hz_htk(m_lo + (m_hi - m_lo) * (double)i / (double)(n_mels + 1));
+        edges[i] = mel_to_hz_any(m_lo + (m_hi - m_lo) * (double)i / (double)(n_mels + 1), scale);
     for (size_t m = 0; m < n_mels; ++m) {
         double lo = edges[m], ce = edges[m + 1], hi = edges[m + 2];
         for (size_t k = 0; k < nb; ++k) {
@@ -427,10 +442,17 @@ void afo_mel_weights(double sample_rate, size_t n_fft, size_t n_mels,
             double up = (f - lo) / (ce - lo);
             double dn = (hi - f) / (hi - ce);
             double v = up < dn ? up : dn;
+            if (norm) v *= 2.0 / (hi - lo);
             W[m * nb + k] = v > 0.0 ? v : 0.0;
         }
     }
     free(edges);
+}
+
+void afo_mel_weights(double sample_rate, size_t n_fft, size_t n_mels,
+                     double f_min, double f_max, double* W)
+{
+    afo_mel_weights_ex(sample_rate, n_fft, n_mels, f_min, f_max, 0, 0, W);
 }
 
 void afo_mel_apply_f64(const double* power, size_t n_frames, size_t n_bins,

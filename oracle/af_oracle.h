@@ -143,6 +143,10 @@ double afo_hz_to_mel_htk(double hz);
 double afo_mel_to_hz_htk(double mel);
 void   afo_mel_weights(double sample_rate, size_t n_fft, size_t n_mels,
                        double f_min, double f_max, double* W);
+/* scale 0 = HTK, 1 = Slaney (linear 200/3 Hz per mel below 1 kHz, 27 mels per factor 6.4 above);
+ * norm 1 = Slaney area normalisation 2 / (e[m+2] - e[m]) */
+void   afo_mel_weights_ex(double sample_rate, size_t n_fft, size_t n_mels, double f_min,
+                          double f_max, int scale, int norm, double* W);
 void   afo_mel_apply_f64(const double* power, size_t n_frames, size_t n_bins,
                          const double* W, size_t n_mels, double* mel);
 

@@ -101,6 +101,8 @@ _hz2mel = _sig("afo_hz_to_mel_htk", C.c_double, C.c_double)
 _mel2hz = _sig("afo_mel_to_hz_htk", C.c_double, C.c_double)
 _melw = _sig("afo_mel_weights", None, C.c_double, C.c_size_t, C.c_size_t, C.c_double,
              C.c_double, _f64p)
+_melw_ex = _sig("afo_mel_weights_ex", None, C.c_double, C.c_size_t, C.c_size_t, C.c_double,
+                C.c_double, C.c_int, C.c_int, _f64p)
 _melapply = _sig("afo_mel_apply_f64", None, _f64p, C.c_size_t, C.c_size_t, _f64p,
                  C.c_size_t, _f64p)
 _feat64 = _sig("afo_features_f64", C.c_size_t, _f32p, C.c_size_t, C.c_uint, C.c_double,
@@ -316,11 +318,12 @@ def mel_to_hz(mel: float) -> float:
 
 
 def mel_weights(sample_rate: float, n_fft: int = 1024, n_mels: int = 80,
-                f_min: float = 0.0, f_max=None) -> np.ndarray:
+                f_min: float = 0.0, f_max=None, scale: int = 0, norm: int = 0) -> np.ndarray:
+    """scale 0 HTK / 1 Slaney; norm 1 = Slaney area normalisation (docs/OPS.md)."""
     if f_max is None:
         f_max = sample_rate / 2.0
     W = np.empty((n_mels, n_fft // 2 + 1), np.float64)
-    _melw(sample_rate, n_fft, n_mels, f_min, f_max, W)
+    _melw_ex(sample_rate, n_fft, n_mels, f_min, f_max, scale, norm, W)
     return W
 
 

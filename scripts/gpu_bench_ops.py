@@ -52,6 +52,20 @@ del x, y, z, q, b64, en
 s = torch.rand(256 * 1440000, 2, device=dev); m = torch.empty(256 * 1440000, device=dev)
 ms = timeit(lambda: lib.af_to_mono_device(P(s.data_ptr()), s.numel(), 2, P(m.data_ptr()), None))
 out["to_mono_cfg2"] = dict(ms=ms, alg_GBps=s.numel() * 6 / ms / 1e6, frac_hbm=s.numel() * 6 / ms / 1e6 / 8000)
+# fused kernel, power-spectrogram output (AF_OUT_POWER): 256 x 30 s stereo -> [1439232][513]
+pp = af.FeaturePipeline(output=af._ffi.AF_OUT_POWER)
+tot = pp.set_batch_uniform(256, 1440000)
+pw = torch.empty(tot, 513, device=dev)
+ms = timeit(lambda: pp.run_device(s.data_ptr(), pw.data_ptr(), torch.cuda.current_stream().cuda_stream), k=5)
+bb = s.numel() * 4 + pw.numel() * 4
+out["stft_power_cfg2"] = dict(ms=ms, alg_GBps=bb / ms / 1e6, frac_hbm=bb / ms / 1e6 / 8000, frames_per_s=tot / ms * 1e3)
+# stand-alone mel contraction on those rows
+fb = af.MelFilterbank(sample_rate=48000)
+ml = torch.empty(tot, 80, device=dev)
+ms = timeit(lambda: fb.apply_device(pw.data_ptr(), tot, ml.data_ptr(), torch.cuda.current_stream().cuda_stream), k=5)
+bb = pw.numel() * 4 + ml.numel() * 4
+out["mel_apply_cfg2"] = dict(ms=ms, alg_GBps=bb / ms / 1e6, frac_hbm=bb / ms / 1e6 / 8000)
+del pw, ml
 # PCIe-inclusive fused features (host buffers), 64 clips
 k = 64
 pipe = af.FeaturePipeline(); pipe.set_batch_uniform(k, 1440000)

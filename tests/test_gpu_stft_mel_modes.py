@@ -1,0 +1,121 @@
+"""GPU parity of the other output modes of the fused path, through the C ABI: the power
+spectrogram (BASELINE config 1), separate channels, log-mel, the
+Slaney filterbank, and the stand-alone MelFilterbank contraction.  Tolerances as in
+test_gpu_features.py: per frame ||got - ref||_2 / ||ref||_2 <= 1e-5 against float64.
+"""
+import numpy as np
+import pytest
+
+from util import frame_rel_err, synth_clip
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def test_config1_power_spectrogram(af, po):
+    # BASELINE config 1: one 10 s mono clip at 16 kHz -> 622 frames x 513 bins
+    x = synth_clip(1, 160000, 1, 16000)
+    st = af.Stft()
+    assert st.n_frames(160000) == 622 and st.n_bins() == 513
+    P = st.power(x)
+    assert P.shape == (622, 513)
+    ref = po.stft_power(x)
+    assert frame_rel_err(P, ref) < TOL
+
+
+@pytest.mark.parametrize("ch,hop", [(2, 256), (1, 160), (2, 512)])
+def test_power_output_ragged_batch(af, po, ch, hop):
+    lens = [1024, 5000, 1023, 16 * hop + 1024, 40000]
+    clips = [synth_clip(10 + i, n, ch, 48000) for i, n in enumerate(lens)]
+    pipe = af.FeaturePipeline(sample_rate=48000, channels=ch, hop=hop, output=af._ffi.AF_OUT_POWER)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    total = pipe.set_batch(offs)
+    assert pipe.row_len() == 513
+    got = pipe.run(np.concatenate(clips))
+    assert got.shape == (total, 513)
+    row = 0
+    for c in clips:
+        ref = po.stft_power(po.to_mono(c, ch), hop=hop)
+        assert frame_rel_err(got[row:row + ref.shape[0]], ref) < TOL
+        row += ref.shape[0]
+    assert row == total
+
+
+def test_power_output_i16(af, po):
+    x = (synth_clip(3, 30000, 2, 48000) * 32767).astype(np.int16)
+    pipe = af.FeaturePipeline(channels=2, sample_format=af._ffi.AF_PCM_I16, output=af._ffi.AF_OUT_POWER)
+    pipe.set_batch_uniform(1, 30000)
+    got = pipe.run(x)
+    xf = x.astype(np.float32) * np.float32(1.0 / 32768.0)
+    assert frame_rel_err(got, po.stft_power(po.to_mono(xf, 2))) < TOL
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_separate_channels(af, po, fmt):
+    # rows [clip][channel][frame]: each channel is its own mono clip
+    lens = [20000, 1024, 7000]
+    clips = [synth_clip(20 + i, n, 2, 48000) for i, n in enumerate(lens)]
+    if fmt:
+        clips = [(c * 32767).astype(np.int16) for c in clips]
+    pipe = af.FeaturePipeline(channels=2, sample_format=fmt, channel_mode=af._ffi.AF_CH_SEPARATE)
+    total = pipe.set_batch(np.concatenate([[0], np.cumsum(lens)]))
+    got = pipe.run(np.concatenate(clips))
+    row = 0
+    for c in clips:
+        cf = c.astype(np.float32) * np.float32(1.0 / 32768.0) if fmt else c
+        for chan in range(2):
+            ref = po.features(np.ascontiguousarray(cf[chan::2]), 1, 48000.0)
+            assert frame_rel_err(got[row:row + ref.shape[0]], ref) < TOL
+            row += ref.shape[0]
+    assert row == total == 2 * sum(pipe.n_frames(n) for n in lens)
+
+
+def test_separate_needs_stereo(af):
+    with pytest.raises(af.AudioError):
+        af.FeaturePipeline(channels=1, channel_mode=af._ffi.AF_CH_SEPARATE)
+
+
+def test_log_mel(af, po):
+    x = synth_clip(5, 30000, 2, 48000)
+    x[:6000] = 0.0                                       # silent frames hit the 1e-10 floor
+    pipe = af.FeaturePipeline(log_mel=True)
+    pipe.set_batch_uniform(1, 30000)
+    got = pipe.run(x)
+    ref = np.maximum(po.features(x, 2, 48000.0), 1e-10)
+    # judged where the tolerance is defined: on the mel values (per-frame norm); an f32 log10
+    # value near -10 carries 1e-6 of rounding = 2.3e-6 relative on mel
+    assert frame_rel_err(10.0 ** got.astype(np.float64), ref) < TOL
+    assert np.max(np.abs(got[0] + 10.0)) < 2e-6          # silent frame: the 1e-10 floor
+
+
+@pytest.mark.parametrize("scale,norm", [(1, 0), (1, 1), (0, 1)])
+def test_slaney_filterbank(af, po, scale, norm):
+    x = synth_clip(6, 20000, 1, 16000)
+    pipe = af.FeaturePipeline(sample_rate=16000, channels=1, mel_scale=scale, mel_norm=norm)
+    pipe.set_batch_uniform(1, 20000)
+    W = po.mel_weights(16000.0, scale=scale, norm=norm)
+    assert np.array_equal(pipe.mel_weights(), W.astype(np.float32))
+    ref = po.mel_apply(po.stft_power(x), W)
+    assert frame_rel_err(pipe.run(x), ref) < TOL
+
+
+@pytest.mark.parametrize("n_frames", [1, 15, 16, 17, 1000])
+def test_mel_filterbank_apply(af, po, n_frames):
+    rng = np.random.default_rng(n_frames)
+    P = (rng.random((n_frames, 513)) ** 4).astype(np.float32) * 100.0
+    fb = af.MelFilterbank(sample_rate=16000, n_mels=80)
+    W = po.mel_weights(16000.0)
+    assert np.array_equal(fb.weights(), W.astype(np.float32))
+    got = fb.apply(P)
+    assert got.shape == (n_frames, 80)
+    assert frame_rel_err(got, po.mel_apply(P, W)) < TOL
+
+
+def test_stft_then_mel_equals_fused(af):
+    # the two stand-alone stages reproduce the fused kernel's rows within f32 rounding
+    x = synth_clip(8, 48000, 1, 16000)
+    P = af.Stft().power(x)
+    mel2 = af.MelFilterbank(sample_rate=16000).apply(P)
+    pipe = af.FeaturePipeline(sample_rate=16000, channels=1)
+    pipe.set_batch_uniform(1, 48000)
+    assert frame_rel_err(mel2, pipe.run(x).astype(np.float64)) < 1e-6

@@ -162,3 +162,25 @@ def test_level_meter_oracle(po):
     x = np.array([0.1, -0.9, 0.3], np.float32)
     r, p, d = po.level_meter(x)
     assert abs(r - np.sqrt(np.mean(x.astype(np.float64) ** 2))) < 1e-15 and p == float(np.float32(0.9))
+
+
+def test_slaney_mel_weights_against_numpy(po):
+    # independent restatement of docs/OPS.md "Mel filterbank" (Slaney scale + area norm)
+    def hz2mel(f):
+        f = np.asarray(f, float)
+        return np.where(f >= 1000, 15 + np.log(np.maximum(f, 1e-30) / 1000) / (np.log(6.4) / 27), f / (200 / 3))
+
+    def mel2hz(m):
+        m = np.asarray(m, float)
+        return np.where(m >= 15, 1000 * np.exp((np.log(6.4) / 27) * (m - 15)), (200 / 3) * m)
+
+    e = mel2hz(np.linspace(hz2mel(0.0), hz2mel(8000.0), 82))
+    f = np.arange(513) * 16000 / 1024
+    Wn = np.zeros((80, 513))
+    for m in range(80):
+        up = (f - e[m]) / (e[m + 1] - e[m])
+        dn = (e[m + 2] - f) / (e[m + 2] - e[m + 1])
+        Wn[m] = np.maximum(0, np.minimum(up, dn)) * 2 / (e[m + 2] - e[m])
+    assert np.max(np.abs(po.mel_weights(16000.0, scale=1, norm=1) - Wn)) < 1e-15
+    # HTK default unchanged by the new entry point
+    assert np.array_equal(po.mel_weights(16000.0), po.mel_weights(16000.0, scale=0, norm=0))
