@@ -636,15 +636,34 @@ __global__ __launch_bounds__(kThreads, 2) void af_mel_apply_kernel(const MelAppl
     const bool vec_ok = (n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(p.mel) % 16 == 0);
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
     const int64_t n_units = (p.n_frames + kFramesPerIter - 1) / kFramesPerIter;
-    for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+    // wave w stages rows 4w .. 4w+3 of a unit: lane + 64 j walks the 513 bins (j = 8 is bin 512,
+    // lane 0 only); the next unit's rows are fetched into registers under the MFMAs
+    constexpr int kPer = 9;
+    float pf[4 * kPer];
+    float* my_rows = wbufs + w * kWbuf;
+    auto fetch = [&](int64_t unit) {
+        const int64_t F0 = unit * kFramesPerIter + 4 * w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = F0 + r < p.n_frames;
+            const float* src = p.power + (F0 + r) * kBins + lane;
+#pragma unroll
+            for (int j = 0; j < kPer; ++j)
+                pf[r * kPer + j] = (ok && (j < 8 || lane == 0)) ? src[64 * j] : 0.0f;
+        }
+    };
+    int64_t u = blockIdx.x;
+    if (u < n_units) fetch(u);
+    for (; u < n_units; u += gridDim.x) {
         const int64_t F0 = u * kFramesPerIter;
         __syncthreads();                              // the previous unit's operands are read
-        for (int i = tid; i < kFramesPerIter * kBins; i += kThreads) {
-            const int f = i / kBins, k = i - f * kBins;
-            wbufs[(f >> 2) * kWbuf + (f & 3) * kProw + k] =
-                (F0 + f < p.n_frames) ? p.power[(F0 + f) * kBins + k] : 0.0f;
-        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < kPer; ++j)
+                if (j < 8 || lane == 0) my_rows[r * kProw + lane + 64 * j] = pf[r * kPer + j];
         __syncthreads();
+        if (u + gridDim.x < n_units) fetch(u + gridDim.x);
         const int j = lane & 15;
         float* orow = p.mel + (F0 + j) * n_mels;
         mel_phase<false>(wbufs, lmeta + w * kMaxSteps, wf, n_slots_w, slot_end_w, orow,
