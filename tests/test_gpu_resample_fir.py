@@ -181,3 +181,44 @@ def test_fir_rejects_bad_tap_counts(af):
         af.FirFilter.new(np.zeros(0, np.float32))
     with pytest.raises(af.AudioError):
         af.FirFilter.new(np.zeros(1025, np.float32))
+
+
+# ---- banded-MFMA path specifics (audio-flow-rs_amd/csrc/banded_mfma.hip) -----------------------
+@pytest.mark.parametrize("K", [40, 161, 177, 178, 200])
+def test_fir_mfma_boundary(af, po, K):
+    # <= 177 taps run on the MFMA kernel (NK <= 48), 178 and up on the VALU kernel
+    rng = np.random.default_rng(K)
+    taps = (rng.standard_normal(K) / K).astype(np.float32)
+    x = synth_clip(K, 30011, 1, 16000)
+    y = af.fir_batch(x.reshape(1, -1), taps)[0]
+    assert rel_err(y, po.fir(x, taps)) < 1e-5
+
+
+@pytest.mark.parametrize("fi,fo", [(44100, 16000), (48000, 16000), (44100, 48000), (8000, 16000)])
+def test_resample_many_ragged_tiles(af, po, fi, fo):
+    # several clips whose lengths leave partial tiles, partial blocks and an unaligned row pitch
+    n = 50021
+    clips = np.stack([synth_clip(100 + i, n, 1, fi) for i in range(5)])
+    out = af.resample_batch(clips, fi, fo)
+    for i in range(5):
+        ref = po.resample(clips[i], fi, fo)
+        assert out[i].size == ref.size
+        assert rel_err(out[i], ref) < 1e-5
+
+
+def test_fir_streaming_chunk_invariance_mfma(af, po):
+    # the MFMA tile grid is anchored at absolute sample 0: any chunking gives the same bits
+    rng = np.random.default_rng(7)
+    taps = (rng.standard_normal(129) / 129).astype(np.float32)
+    x = synth_clip(77, 40000, 1, 16000)
+    whole = af.FirFilter.new(taps).process(x)
+    f = af.FirFilter.new(taps)
+    parts, pos = [], 0
+    for step in [1, 15, 16, 17, 4095, 4096, 4097, 9000, 40000]:
+        parts.append(f.process(x[pos:pos + step]))
+        pos += step
+        if pos >= x.size:
+            break
+    got = np.concatenate(parts)
+    assert np.array_equal(got, whole[:got.size])
+    assert rel_err(whole, po.fir(x, taps)) < 1e-5
