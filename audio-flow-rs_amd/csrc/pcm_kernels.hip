@@ -23,17 +23,41 @@ inline int grid_for(size_t work_items)
 }
 
 // ---- to_mono ---------------------------------------------------------------
-// stereo fast path: one float4 (two frames) per lane per step
+// stereo fast path: one float4 (two frames) per lane and load, four loads in flight per lane
+// (a lane that keeps a single 16-byte load in flight leaves HBM a third idle)
+constexpr int kUnroll = 4;
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
+typedef unsigned vu2 __attribute__((ext_vector_type(2)));
+
 __global__ void to_mono2_kernel(const float* __restrict__ in, size_t n_pairs /* = n_frames/2 */,
                                 float* __restrict__ out)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += stride) {
-        const float4 v = reinterpret_cast<const float4*>(in)[i];
-        float2 o;
-        o.x = (v.x + v.y) / 2.0f;          // capture.rs:37-38: sum, then / channels
+    // every workgroup walks its own contiguous range, kUnroll * 4 KB at a time
+    const vf4* src = reinterpret_cast<const vf4*>(in);
+    vf2* dst = reinterpret_cast<vf2*>(out);
+    const size_t per = (n_pairs + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per;
+    const size_t hi = lo + per < n_pairs ? lo + per : n_pairs;
+    size_t i = lo + threadIdx.x;
+    for (; i + (kUnroll - 1) * kBlock < hi; i += kUnroll * kBlock) {
+        vf4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * kBlock);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            vf2 o;
+            o.x = (v[u].x + v[u].y) / 2.0f;    // capture.rs:37-38: sum, then / channels
+            o.y = (v[u].z + v[u].w) / 2.0f;
+            __builtin_nontemporal_store(o, dst + i + u * kBlock);
+        }
+    }
+    for (; i < hi; i += kBlock) {
+        const vf4 v = src[i];
+        vf2 o;
+        o.x = (v.x + v.y) / 2.0f;
         o.y = (v.z + v.w) / 2.0f;
-        reinterpret_cast<float2*>(out)[i] = o;
+        dst[i] = o;
     }
 }
 
@@ -62,22 +86,34 @@ __device__ __forceinline__ int quant1(float x)
     return (int)(x * 32767.0f);             // f32 product, truncation toward zero
 }
 
+__device__ __forceinline__ vu2 quant4(const vf4 v)
+{
+    const unsigned a = (unsigned)quant1(v.x) & 0xffffu, b = (unsigned)quant1(v.y) & 0xffffu;
+    const unsigned c = (unsigned)quant1(v.z) & 0xffffu, d = (unsigned)quant1(v.w) & 0xffffu;
+    vu2 o;
+    o.x = a | (b << 16);                    // little-endian, websocket.rs:249
+    o.y = c | (d << 16);
+    return o;
+}
+
 __global__ void quantize_kernel(const float* __restrict__ in, size_t n, int16_t* __restrict__ out,
                                 int vec_ok)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t n4 = vec_ok ? n / 4 : 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const float4 v = reinterpret_cast<const float4*>(in)[i];
-        const unsigned a = (unsigned)quant1(v.x) & 0xffffu, b = (unsigned)quant1(v.y) & 0xffffu;
-        const unsigned c = (unsigned)quant1(v.z) & 0xffffu, d = (unsigned)quant1(v.w) & 0xffffu;
-        uint2 o;
-        o.x = a | (b << 16);                // little-endian, websocket.rs:249
-        o.y = c | (d << 16);
-        reinterpret_cast<uint2*>(out)[i] = o;
+    const vf4* src = reinterpret_cast<const vf4*>(in);
+    vu2* dst = reinterpret_cast<vu2*>(out);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (kUnroll - 1) * stride < n4; i += kUnroll * stride) {
+        vf4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) __builtin_nontemporal_store(quant4(v[u]), dst + i + u * stride);
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = (int16_t)quant1(in[i]);
+    for (; i < n4; i += stride) dst[i] = quant4(src[i]);
+    for (size_t j = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
+        out[j] = (int16_t)quant1(in[j]);
 }
 
 // ---- quantise + base64 ---------------------------------------------------------
@@ -88,34 +124,58 @@ __device__ __forceinline__ unsigned b64c(unsigned v)
     return v < 26 ? 'A' + v : v < 52 ? 'a' + (v - 26) : v < 62 ? '0' + (v - 52) : v == 62 ? '+' : '/';
 }
 
-// one lane = 6 samples = 12 bytes -> 16 characters (one 16-byte store)
-__global__ void pcm16_base64_kernel(const float* __restrict__ in, size_t n,
-                                    char* __restrict__ out, int vec_store_ok)
+// one lane = 6 samples = 12 bytes -> 16 characters (one 16-byte store).  The 6-sample groups
+// of a workgroup are 1536 consecutive floats: they are fetched with coalesced 16-byte loads
+// into LDS and picked up from there (a lane reading its own 24 bytes from global memory
+// touches every cache line six times).
+constexpr int kB64Tile = kBlock * 6;             // samples per workgroup step
+
+__device__ __forceinline__ void b64_encode16(const float (&x)[6], unsigned char (&ch)[16])
 {
-    const size_t n_groups = (n + 5) / 6;
+    unsigned char by[12];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int q = quant1(x[j]);
+        by[2 * j] = (unsigned char)(q & 0xff);
+        by[2 * j + 1] = (unsigned char)((q >> 8) & 0xff);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const unsigned v = ((unsigned)by[3 * t] << 16) | ((unsigned)by[3 * t + 1] << 8) | by[3 * t + 2];
+        ch[4 * t] = (unsigned char)b64c(v >> 18);
+        ch[4 * t + 1] = (unsigned char)b64c(v >> 12);
+        ch[4 * t + 2] = (unsigned char)b64c(v >> 6);
+        ch[4 * t + 3] = (unsigned char)b64c(v);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void pcm16_base64_kernel(const float* __restrict__ in, size_t n,
+                                                              char* __restrict__ out, int vec_ok)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kB64Tile];
     const size_t n_bytes = 2 * n;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
-        unsigned char by[12];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const size_t i = g * 6 + j;
-            const int q = i < n ? quant1(in[i]) : 0;
-            by[2 * j] = (unsigned char)(q & 0xff);
-            by[2 * j + 1] = (unsigned char)((q >> 8) & 0xff);
+    const size_t n_tiles = (n + kB64Tile - 1) / kB64Tile;
+    const int tid = threadIdx.x;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const size_t s0 = t * kB64Tile;
+        __syncthreads();                                  // the previous tile has been read
+        if (vec_ok && s0 + kB64Tile <= n) {
+            const float4* src = reinterpret_cast<const float4*>(in + s0);
+            for (int i = tid; i < kB64Tile / 4; i += kBlock) reinterpret_cast<float4*>(tile)[i] = src[i];
+        } else {
+            for (int i = tid; i < kB64Tile; i += kBlock) tile[i] = s0 + i < n ? in[s0 + i] : 0.0f;
         }
-        unsigned char ch[16];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const unsigned v = ((unsigned)by[3 * t] << 16) | ((unsigned)by[3 * t + 1] << 8) | by[3 * t + 2];
-            ch[4 * t] = (unsigned char)b64c(v >> 18);
-            ch[4 * t + 1] = (unsigned char)b64c(v >> 12);
-            ch[4 * t + 2] = (unsigned char)b64c(v >> 6);
-            ch[4 * t + 3] = (unsigned char)b64c(v);
-        }
+        __syncthreads();
+        const size_t g = t * kBlock + tid;                // 6-sample group of this lane
         const size_t byte0 = g * 12;
+        if (byte0 >= n_bytes) continue;
+        float x[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x[j] = tile[tid * 6 + j];
+        unsigned char ch[16];
+        b64_encode16(x, ch);
         if (byte0 + 12 <= n_bytes) {
-            if (vec_store_ok) {
+            if (vec_ok) {
                 uint4 o;
                 o.x = ch[0] | (ch[1] << 8) | (ch[2] << 16) | ((unsigned)ch[3] << 24);
                 o.y = ch[4] | (ch[5] << 8) | (ch[6] << 16) | ((unsigned)ch[7] << 24);
@@ -124,17 +184,17 @@ __global__ void pcm16_base64_kernel(const float* __restrict__ in, size_t n,
                 reinterpret_cast<uint4*>(out)[g] = o;
             } else {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) out[g * 16 + t] = (char)ch[t];
+                for (int c = 0; c < 16; ++c) out[g * 16 + c] = (char)ch[c];
             }
         } else {
             // last, partial group: whole 3-byte triples, then '=' padding
             const size_t rem = n_bytes - byte0;          // 2,4,6,8,10
             const size_t full = rem / 3, tail = rem % 3;
-            for (size_t t = 0; t < full * 4; ++t) out[g * 16 + t] = (char)ch[t];
+            for (size_t c = 0; c < full * 4; ++c) out[g * 16 + c] = (char)ch[c];
             if (tail) {
                 char* o = out + g * 16 + full * 4;
                 o[0] = (char)ch[full * 4];
-                o[1] = (char)ch[full * 4 + 1];       // low bits already zero (bytes beyond are 0)
+                o[1] = (char)ch[full * 4 + 1];       // low bits already zero (samples beyond are 0)
                 o[2] = tail == 2 ? (char)ch[full * 4 + 2] : '=';
                 o[3] = '=';
             }
@@ -143,20 +203,33 @@ __global__ void pcm16_base64_kernel(const float* __restrict__ in, size_t n,
 }
 
 // ---- VAD energy ----------------------------------------------------------------
-// one wave64 per frame: lanes stride the frame, wavefront-shuffle tree sum.
+// one wave64 per frame: lanes stride the frame (16-byte loads when the frames are 16-byte
+// aligned), wavefront-shuffle tree sum.
+template <class F>
+__device__ __forceinline__ void frame_sweep(const float* __restrict__ x, size_t len, int lane, bool vec, F&& f)
+{
+    size_t done = 0;
+    if (vec) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const size_t n4 = len / 4;
+        for (size_t i = lane; i < n4; i += 64) {
+            const float4 v = x4[i];
+            f(v.x); f(v.y); f(v.z); f(v.w);
+        }
+        done = n4 * 4;
+    }
+    for (size_t i = done + lane; i < len; i += 64) f(x[i]);
+}
+
 __global__ void vad_energy_kernel(const float* __restrict__ in, size_t n_frames, size_t frame_len,
-                                  float* __restrict__ energy)
+                                  float* __restrict__ energy, int vec)
 {
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     for (size_t f = wave; f < n_frames; f += n_waves) {
-        const float* x = in + f * frame_len;
         float s = 0.0f;
-        for (size_t i = lane; i < frame_len; i += 64) {
-            const float v = x[i];
-            s += v * v;
-        }
+        frame_sweep(in + f * frame_len, frame_len, lane, vec != 0, [&](float v) { s += v * v; });
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
         if (lane == 0) energy[f] = frame_len ? s / (float)frame_len : 0.0f;   // vad.rs:158,167
@@ -168,19 +241,17 @@ __global__ void vad_energy_kernel(const float* __restrict__ in, size_t n_frames,
 // audio_level event, events/mod.rs:73-75,112-115).  One wave64 per window.
 __global__ void level_meter_kernel(const float* __restrict__ in, size_t n_windows, size_t window_len,
                                    float* __restrict__ rms, float* __restrict__ peak,
-                                   float* __restrict__ dbfs)
+                                   float* __restrict__ dbfs, int vec)
 {
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     for (size_t f = wave; f < n_windows; f += n_waves) {
-        const float* x = in + f * window_len;
         float s = 0.0f, m = 0.0f;
-        for (size_t i = lane; i < window_len; i += 64) {
-            const float v = x[i];
+        frame_sweep(in + f * window_len, window_len, lane, vec != 0, [&](float v) {
             s += v * v;
             m = fmaxf(m, fabsf(v));
-        }
+        });
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             s += __shfl_xor(s, off, 64);
@@ -289,9 +360,12 @@ af_status af_pcm16_base64_device(const float* in_dev, size_t n, char* out_dev, v
 {
     if (n == 0) return AF_OK;
     AF_REQUIRE(in_dev && out_dev, "pcm16_base64: null buffer");
-    const int vec_ok = reinterpret_cast<uintptr_t>(out_dev) % 16 == 0;
-    hipLaunchKernelGGL(pcm16_base64_kernel, dim3(grid_for((n + 5) / 6)), dim3(kBlock), 0,
-                       as_stream(stream), in_dev, n, out_dev, vec_ok);
+    const int vec_ok = reinterpret_cast<uintptr_t>(out_dev) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(in_dev) % 16 == 0;
+    size_t tiles = (n + kB64Tile - 1) / kB64Tile;
+    if (tiles > 2048) tiles = 2048;
+    hipLaunchKernelGGL(pcm16_base64_kernel, dim3((int)tiles), dim3(kBlock), 0, as_stream(stream), in_dev,
+                       n, out_dev, vec_ok);
     AF_HIP(hipGetLastError());
     return AF_OK;
 }
@@ -320,8 +394,9 @@ af_status af_vad_energy_device(const float* in_dev, size_t n_frames, size_t fram
     AF_REQUIRE(energy_dev && (in_dev || frame_len == 0), "vad_energy: null buffer");
     size_t g = (n_frames * 64 + kBlock - 1) / kBlock;
     if (g > 4096) g = 4096;
+    const int vec = frame_len % 4 == 0 && reinterpret_cast<uintptr_t>(in_dev) % 16 == 0;
     hipLaunchKernelGGL(vad_energy_kernel, dim3((int)g), dim3(kBlock), 0, as_stream(stream), in_dev,
-                       n_frames, frame_len, energy_dev);
+                       n_frames, frame_len, energy_dev, vec);
     AF_HIP(hipGetLastError());
     return AF_OK;
 }
@@ -352,8 +427,9 @@ af_status af_level_meter_device(const float* in_dev, size_t n_windows, size_t wi
     AF_REQUIRE(rms_dev && peak_dev && dbfs_dev && (in_dev || window_len == 0), "level_meter: null buffer");
     size_t g = (n_windows * 64 + kBlock - 1) / kBlock;
     if (g > 4096) g = 4096;
+    const int vec = window_len % 4 == 0 && reinterpret_cast<uintptr_t>(in_dev) % 16 == 0;
     hipLaunchKernelGGL(level_meter_kernel, dim3((int)g), dim3(kBlock), 0, as_stream(stream), in_dev,
-                       n_windows, window_len, rms_dev, peak_dev, dbfs_dev);
+                       n_windows, window_len, rms_dev, peak_dev, dbfs_dev, vec);
     AF_HIP(hipGetLastError());
     return AF_OK;
 }
