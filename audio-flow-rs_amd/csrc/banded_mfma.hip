@@ -181,8 +181,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w0[t % (kAhead + 1)], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w1[t % (kAhead + 1)], acc1, 0, 0, 0);
                 if (LOADS) {
+                    // all of them in the first half of the chain: the later a load goes out, the
+                    // less of the chain is left to cover its latency
+                    constexpr int kSpan = (NK + 1) / 2;
+                    if (t < kSpan) {
 #pragma unroll
-                    for (int s2 = (kLoads * t) / NK; s2 < (kLoads * (t + 1)) / NK; ++s2) issue_load(s2);
+                        for (int s2 = (kLoads * t) / kSpan; s2 < (kLoads * (t + 1)) / kSpan; ++s2) issue_load(s2);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

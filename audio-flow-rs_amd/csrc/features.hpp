@@ -46,7 +46,7 @@ struct Params {
     const float* wintab;      // [32][kWinRow]: row n2 holds 0.5 * hann[32 n1 + n2], n1 = 0..31
     const float* twtab;       // [32][kTwRow]: row n2 holds (cos, sin)(2 pi k1 n2 / 1024), k1 = 0..31
     const float* wfrag;       // [4][kMaxSlotsW][64][4] MFMA A fragments: one float4 per lane and slot
-    const int* meta;          // [4][kMaxSteps] first bin of every step (0 for padding)
+    const int* meta;          // [4][kMaxSlotsW] first bin of every slot; its 4 steps are 4 bins apart
     Plan plan;                // by value: lives in the kernarg segment -> scalar (SMEM) loads
     const int64_t* pcm_off;   // [n_clips] first PCM frame of each clip (spans may overlap)
     const int64_t* pcm_len;   // [n_clips] PCM frames in each clip

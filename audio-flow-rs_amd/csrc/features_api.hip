@@ -112,7 +112,10 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
         if (h < l) { l = 0; h = 0; }                        // all-zero group: one harmless step
         steps = (h - l + 1 + 3) / 4;
         b0 = l;
-        if (b0 + 4 * steps > kBins) b0 = kBins - 4 * steps; // never read past bin 512
+        // the group's steps, padding included, walk consecutive bins: never read past bin 512
+        const int padded = (steps + kSlotSteps - 1) / kSlotSteps * kSlotSteps;
+        if (b0 + 4 * padded > kBins) b0 = kBins - 4 * padded;
+        if (b0 < 0) b0 = 0;
     };
     const int INF = 1 << 28;
     // What a group costs its wave besides its K-steps: combining the two accumulators and the
@@ -150,7 +153,7 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
     for (int w = kWaves; w >= 1; --w) wave_lo[w - 1] = fcut[w][wave_lo[w]];
 
     wfrag.assign((size_t)kWaves * kMaxSteps * 64, 0.0f);
-    meta.assign((size_t)kWaves * kMaxSteps, 0);
+    meta.assign((size_t)kWaves * kMaxSlotsW, 0);
     for (int w = 0; w < kWaves; ++w) {
         // groups of this wave, recovered from gcut
         std::vector<std::pair<int, int>> groups;
@@ -174,17 +177,18 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
             band(it->first, it->second, b0, st);
             const int m0 = 4 * it->first;
             const int cnt = std::min(4 * it->second, n_mels) - m0;
-            for (int i = 0; i < st; ++i, ++s) {
+            const int padded = (st + kSlotSteps - 1) / kSlotSteps * kSlotSteps;
+            for (int i = 0; i < padded; ++i, ++s) {
                 const int bin = b0 + 4 * i;
-                meta[(size_t)w * kMaxSteps + s] = bin;
+                if (s % kSlotSteps == 0) meta[(size_t)w * kMaxSlotsW + s / kSlotSteps] = bin;
                 for (int lane = 0; lane < 64; ++lane) {
                     const int r = lane & 15, k = bin + (lane >> 4);
                     wfrag[(((size_t)w * kMaxSlotsW + s / kSlotSteps) * 64 + lane) * kSlotSteps +
-                          s % kSlotSteps] = (r < cnt) ? W[(size_t)(m0 + r) * kBins + k] : 0.0f;
+                          s % kSlotSteps] =
+                        (r < cnt && k < kBins) ? W[(size_t)(m0 + r) * kBins + k] : 0.0f;   // zero off the band
                 }
             }
             plan.n_steps += st;
-            s = (s + kSlotSteps - 1) / kSlotSteps * kSlotSteps;   // pad the group to a slot boundary
             plan.slot_end[w][s / kSlotSteps - 1] = 0x10000 | (cnt << 8) | m0;
             plan.n_groups += 1;
         }

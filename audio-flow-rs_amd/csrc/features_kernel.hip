@@ -345,15 +345,20 @@ __device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restr
 {
     const int f = lane & 15, kq = lane >> 4;
     const float* pbase = wbufs + (f >> 2) * kWbuf + (f & 3) * kProw + kq;
-    // Branch-free on purpose: one batch of broadcast reads for the bin offsets, one
-    // batch of operand reads (padding steps read bin 0 and multiply it by zero weights).
+    // Branch-free on purpose.  The 4 steps of a slot read consecutive bins (4 apart), so one
+    // broadcast read per slot gives its first bin and the operands follow at fixed offsets
+    // (padding steps read real bins of the same frame and multiply them by zero weights).
     float b[kMaxSteps];
     {
-        int meta[kMaxSteps];
+        int meta[kMaxSlotsW];
 #pragma unroll
-        for (int s = 0; s < kMaxSteps; ++s) meta[s] = lmeta[s];
+        for (int q = 0; q < kMaxSlotsW; ++q) meta[q] = lmeta[q];
 #pragma unroll
-        for (int s = 0; s < kMaxSteps; ++s) b[s] = pbase[meta[s]];
+        for (int q = 0; q < kMaxSlotsW; ++q) {
+            const float* bq = pbase + meta[q];
+#pragma unroll
+            for (int i = 0; i < kSlotSteps; ++i) b[q * kSlotSteps + i] = bq[4 * i];
+        }
     }
     if constexpr (STAMPS) {                       // diagnostics: operands landed
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -413,7 +418,8 @@ __device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restr
     } while (0)
 
 // ---------------------------------------------------------------------------
-template <int HOP_T, int CH, bool I16, bool STAMPS>
+// SEP (stereo only): no downmix, table entry e is channel e & 1 of clip e / 2
+template <int HOP_T, int CH, bool I16, bool STAMPS, bool SEP>
 __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p)
 {
     using St = Stage<CH, I16>;
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
     float* wbufs = smem + tile_alloc;
     float* wtab = wbufs + kWaves * kWbuf;                     // [32][kWinRow]
     float* ttab = wtab + 32 * kWinRow;                        // [32][kTwRow]
-    int* lmeta = reinterpret_cast<int*>(ttab + 32 * kTwRow);  // [4][kMaxSteps]
+    int* lmeta = reinterpret_cast<int*>(ttab + 32 * kTwRow);  // [4][kMaxSlotsW]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         reinterpret_cast<float4*>(wtab)[i] = reinterpret_cast<const float4*>(p.wintab)[i];
     for (int i = tid; i < 32 * kTwRow / 4; i += kThreads)
         reinterpret_cast<float4*>(ttab)[i] = reinterpret_cast<const float4*>(p.twtab)[i];
-    for (int i = tid; i < kWaves * kMaxSteps; i += kThreads) lmeta[i] = p.meta[i];
+    for (int i = tid; i < kWaves * kMaxSlotsW; i += kThreads) lmeta[i] = p.meta[i];
     // this wave's share of the mel plan
     const float* __restrict__ wfrag_w = p.wfrag + (((size_t)w * kMaxSlotsW) * 64 + lane) * 4;
     const int n_slots_w = p.plan.wave_nslots[w];
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         const int64_t c_frames = p.out_off[c + 1] - c_out0;
         const int64_t c_u1 = p.unit_off[c + 1];
         const int64_t F0 = (u - p.unit_off[c]) * kFramesPerIter;
-        const int sel = (CH == 2 && p.separate) ? (c & 1) : -1;   // entry 2 clip + channel
+        const int sel = SEP ? (c & 1) : -1;       // entry = 2 clip + channel
 
         if (fresh) {
             __syncthreads();                      // nobody still reads the old tile
@@ -585,7 +591,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
             const int j = lane & 15;
             float* orow = p.mel + (c_out0 + F0 + j) * n_mels;
             if (!p.out_power) {
-                mel_phase<STAMPS>(wbufs, lmeta + w * kMaxSteps, wf, n_slots_w, slot_end_w, orow,
+                mel_phase<STAMPS>(wbufs, lmeta + w * kMaxSlotsW, wf, n_slots_w, slot_end_w, orow,
                                   F0 + j < c_frames, vec_ok, p.log_mel != 0, lane, acc_t, t_prev);
             } else {
                 // power output: this wave's four rows [frame][513], consecutive lanes on
@@ -617,10 +623,10 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
 __global__ __launch_bounds__(kThreads, 2) void af_mel_apply_kernel(const MelApplyParams p)
 {
     __shared__ __attribute__((aligned(16))) float wbufs[kWaves * kWbuf];
-    __shared__ int lmeta[kWaves * kMaxSteps];
+    __shared__ int lmeta[kWaves * kMaxSlotsW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < kWaves * kMaxSteps; i += kThreads) lmeta[i] = p.meta[i];
+    for (int i = tid; i < kWaves * kMaxSlotsW; i += kThreads) lmeta[i] = p.meta[i];
     const float4* wp = reinterpret_cast<const float4*>(p.wfrag + (((size_t)w * kMaxSlotsW) * 64 + lane) * 4);
     float wf[kMaxSteps];
 #pragma unroll
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_mel_apply_kernel(const MelAppl
         if (u + gridDim.x < n_units) fetch(u + gridDim.x);
         const int j = lane & 15;
         float* orow = p.mel + (F0 + j) * n_mels;
-        mel_phase<false>(wbufs, lmeta + w * kMaxSteps, wf, n_slots_w, slot_end_w, orow,
+        mel_phase<false>(wbufs, lmeta + w * kMaxSlotsW, wf, n_slots_w, slot_end_w, orow,
                          F0 + j < p.n_frames, vec_ok, p.log_mel != 0, lane, acc_t, t_prev);
     }
 }
@@ -684,13 +690,13 @@ size_t features_smem_bytes(int hop)
     const int tile_len = 15 * hop + kNfft;
     const int tile_alloc = (tile_len + 7) & ~7;
     return sizeof(float) * ((size_t)tile_alloc + kWaves * kWbuf + 32 * kWinRow + 32 * kTwRow +
-                            kWaves * kMaxSteps);
+                            kWaves * kMaxSlotsW);
 }
 
-template <int HOP_T, int CH, bool I16, bool STAMPS>
+template <int HOP_T, int CH, bool I16, bool STAMPS, bool SEP>
 static af_status launch_k(const Params& p, int grid, size_t smem, hipStream_t stream)
 {
-    auto kern = af_features_kernel<HOP_T, CH, I16, STAMPS>;
+    auto kern = af_features_kernel<HOP_T, CH, I16, STAMPS, SEP>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -705,8 +711,11 @@ static af_status launch_k(const Params& p, int grid, size_t smem, hipStream_t st
 template <int HOP_T, int CH, bool I16>
 static af_status launch_one(const Params& p, int grid, size_t smem, hipStream_t stream)
 {
-    return p.stamps ? launch_k<HOP_T, CH, I16, true>(p, grid, smem, stream)
-                    : launch_k<HOP_T, CH, I16, false>(p, grid, smem, stream);
+    if constexpr (CH == 2) {
+        if (p.separate) return launch_k<HOP_T, CH, I16, false, true>(p, grid, smem, stream);
+    }
+    return p.stamps ? launch_k<HOP_T, CH, I16, true, false>(p, grid, smem, stream)
+                    : launch_k<HOP_T, CH, I16, false, false>(p, grid, smem, stream);
 }
 
 af_status launch_features(const Params& p, int channels, bool i16, int grid, size_t smem,

@@ -4,7 +4,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("ffi", os.path.join(ROOT, "audio-flow-rs_amd", "_ffi.py"))
 ffi = importlib.util.module_from_spec(spec); spec.loader.exec_module(ffi)
-lib = C.CDLL(ffi.LIB_PATH)
+lib = C.CDLL(os.environ.get("AF_LIB", ffi.LIB_PATH))
 for name in ["af_last_error", "af_features_default_config", "af_features_create", "af_features_destroy",
              "af_features_n_frames", "af_features_set_batch", "af_features_set_batch_uniform",
              "af_features_run", "af_features_run_device"]:
