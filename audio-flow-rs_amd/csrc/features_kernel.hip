@@ -417,6 +417,38 @@ __device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restr
         }                                                                   \
     } while (0)
 
+// Table entries of clip c with scalar loads (the tables are read-only for the kernel and c is
+// wave-uniform).  The wait is inside: hipcc does not track loads issued from inline asm.
+struct ClipEntry {
+    int64_t pcm0, n, out0, out1, u0, u1;
+};
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ClipEntry load_clip_entry(const int64_t* pcm_off, const int64_t* pcm_len,
+                                                     const int64_t* out_off, const int64_t* unit_off,
+                                                     int c)
+{
+    const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(c) * 8u;
+    unsigned long long a, b;
+    u32x4 o, u;
+    asm volatile(
+        "s_load_dwordx2 %0, %4, %8\n\t"
+        "s_load_dwordx2 %1, %5, %8\n\t"
+        "s_load_dwordx4 %2, %6, %8\n\t"
+        "s_load_dwordx4 %3, %7, %8\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(a), "=&s"(b), "=&s"(o), "=&s"(u)
+        : "s"(pcm_off), "s"(pcm_len), "s"(out_off), "s"(unit_off), "s"(off)
+        : "memory");
+    ClipEntry e;
+    e.pcm0 = (int64_t)a;
+    e.n = (int64_t)b;
+    e.out0 = (int64_t)(((unsigned long long)o.y << 32) | o.x);
+    e.out1 = (int64_t)(((unsigned long long)o.w << 32) | o.z);
+    e.u0 = (int64_t)(((unsigned long long)u.y << 32) | u.x);
+    e.u1 = (int64_t)(((unsigned long long)u.w << 32) | u.z);
+    return e;
+}
+
 // ---------------------------------------------------------------------------
 // SEP (stereo only): no downmix, table entry e is channel e & 1 of clip e / 2
 template <int HOP_T, int CH, bool I16, bool STAMPS, bool SEP>
@@ -480,13 +512,20 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
     unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memtime() : 0;
 
     while (u < u_end) {
-        while (p.unit_off[c + 1] <= u) ++c;       // skip clips without frames
-        const int64_t c_pcm0 = p.pcm_off[c];
-        const int64_t c_n = p.pcm_len[c];
-        const int64_t c_out0 = p.out_off[c];
-        const int64_t c_frames = p.out_off[c + 1] - c_out0;
-        const int64_t c_u1 = p.unit_off[c + 1];
-        const int64_t F0 = (u - p.unit_off[c]) * kFramesPerIter;
+        // The clip's table entries come through the scalar cache: as vector loads they would make
+        // every unit wait for vmcnt(0), i.e. for the previous unit's mel stores to reach memory.
+        ClipEntry ce;
+        for (;;) {
+            ce = load_clip_entry(p.pcm_off, p.pcm_len, p.out_off, p.unit_off, c);
+            if (ce.u1 > u) break;                 // skip clips without frames
+            ++c;
+        }
+        const int64_t c_pcm0 = ce.pcm0;
+        const int64_t c_n = ce.n;
+        const int64_t c_out0 = ce.out0;
+        const int64_t c_frames = ce.out1 - ce.out0;
+        const int64_t c_u1 = ce.u1;
+        const int64_t F0 = (u - ce.u0) * kFramesPerIter;
         const int sel = SEP ? (c & 1) : -1;       // entry = 2 clip + channel
 
         if (fresh) {
