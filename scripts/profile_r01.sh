@@ -16,3 +16,8 @@ timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex to_mono --output-format csv -d "$O/cal_fetch" -- python3 scripts/pmc_calibrate.py > "$O/cal_fetch.log" 2>&1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex to_mono --output-format csv -d "$O/cal_write" -- python3 scripts/pmc_calibrate.py > "$O/cal_write.log" 2>&1
 ls "$O"
+# secondary kernels (banded MFMA resampler / FIR, streaming ops, power mode, mel_apply)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ops_kt" -- python3 scripts/gpu_bench_ops.py > "$O/ops.json" 2> "$O/ops_kt.log"
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex banded_kernel --output-format csv -d "$O/banded_fetch" -- python3 scripts/gpu_bench_banded.py r441 > "$O/banded_fetch.log" 2>&1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex banded_kernel --output-format csv -d "$O/banded_write" -- python3 scripts/gpu_bench_banded.py r441 > "$O/banded_write.log" 2>&1
+ls "$O"

@@ -27,7 +27,7 @@ def kernel_stats(d, out, rx):
         f.write("name,calls,total_ns,average_ns,min_ns,max_ns,stddev,percent_of_all_gpu_time\n")
         for r in rows:
             if re.search(rx, r["Name"]):
-                name = r["Name"].split("(")[0].replace("void ", "")
+                name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
                 f.write(f'{name},{r["Calls"]},{r["TotalDurationNs"]},{r["AverageNs"]},{r["MinNs"]},'
                         f'{r["MaxNs"]},{r["StdDev"]},{r["Percentage"]}\n')
     print(open(out).read())
@@ -38,7 +38,7 @@ def pmc(d, out, rx):
     acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(path)):
         if re.search(rx, r["Kernel_Name"]):
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     with open(out, "w") as f:
         f.write("# rocprofv3 --pmc summary: per-dispatch mean of each counter\n")
