@@ -26,6 +26,24 @@ def all_shards(n_items: int, world_size: int) -> List[Tuple[int, int]]:
     return [shard_range(n_items, world_size, r) for r in range(world_size)]
 
 
+def stream_shards(n_total: int, world_size: int, chunk: int, n_fft: int = 1024,
+                  hop: int = 256) -> List[List[Tuple[int, int]]]:
+    """Long-form stream (BASELINE config 5): the stream of ``n_total``
+    PCM frames is cut into chunks of ``chunk`` frames (a multiple of 16*hop) that each carry a
+    read-only right halo of ``n_fft - hop`` frames, and contiguous runs of chunks go to the
+    ranks.  Returns, per rank, its ``(start, length)`` spans for
+    ``FeaturePipeline.set_batch_spans``; spectrogram frame ``f`` is produced by the chunk that
+    holds sample ``f*hop``, so the ranks' outputs, in rank order, are the one-shot framing.  No
+    halo is exchanged: every rank reads its halo from the source like the rest of its span."""
+    if chunk <= 0 or chunk % (16 * hop) != 0:
+        raise ValueError("chunk must be a positive multiple of 16*hop")
+    spans, pos = [], 0
+    while pos < n_total:
+        spans.append((pos, min(chunk + n_fft - hop, n_total - pos)))
+        pos += chunk
+    return [spans[b:e] for b, e in all_shards(len(spans), world_size)]
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """MAX all-reduce of a python float (identity when not distributed)."""
     import torch

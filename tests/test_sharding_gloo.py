@@ -29,6 +29,25 @@ def test_shard_range_is_a_balanced_partition(af):
         shard_range(10, 2, 2)
 
 
+def test_stream_shards_reproduce_one_shot_framing(af, po):
+    # config 5 in miniature: a stream cut into haloed chunks, chunks dealt to 3 ranks; the
+    # checker computes every span on its own and the concatenation must be the one-shot result
+    from audio_flow_rs_amd.shard import stream_shards
+    from util import synth_clip
+    hop, chunk = 256, 16 * 256
+    for n_total in (chunk * 5 + 1234, chunk * 2, 1023, chunk + 767, chunk + 768):
+        x = synth_clip(123, n_total, 1, 16000)
+        one = po.features(x, 1, 16000.0)
+        shards = stream_shards(n_total, 3, chunk)
+        assert sum(len(s) for s in shards) == -(-n_total // chunk)
+        rows = [po.features(x[s:s + n], 1, 16000.0) for spans in shards for s, n in spans]
+        got = np.concatenate(rows) if rows else np.zeros((0, 80))
+        assert got.shape == one.shape
+        assert np.array_equal(got, one)
+    with pytest.raises(ValueError):
+        stream_shards(1000, 2, 1000)
+
+
 def _worker(rank, world, port, n_clips, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
