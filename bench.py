@@ -101,6 +101,7 @@ def cpu_baseline(pcm_host, n_clips: int, n_frames: int) -> dict:
 
 
 def main() -> None:
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -122,12 +123,19 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # AF_BENCH_REHEARSE=1: rehearse the N > 1 control flow on a one-GPU box (every rank on
+    # device 0, gloo instead of RCCL); the numbers of such a run mean nothing
+    rehearse = os.environ.get("AF_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_frames_pcm = CLIP_SECONDS * SR
     n_clips = args.clips
