@@ -29,12 +29,12 @@ from .errors import AudioError
 from .audio import (AudioFrame, AudioResampler, BatchResampler, ChainPipeline, FeaturePipeline, FirFilter,
                     MelSpectrogram, MessageBuilder, RingBuffer, VadConfig, VadLevel, VadState,
                     VoiceActivityDetector, device_count, library, quantize_pcm16, to_mono,
-                    vad_energy, resample_batch, fir_batch, AudioLevel, level_meter, Stft, MelFilterbank)
+                    vad_energy, resample_batch, fir_batch, AudioLevel, level_meter, Stft, MelFilterbank, resample_stereo_batch)
 
 __all__ = [
     "AudioError", "AudioFrame", "AudioResampler", "BatchResampler", "ChainPipeline", "FeaturePipeline",
     "FirFilter",
     "MelSpectrogram", "MessageBuilder", "RingBuffer", "VadConfig", "VadLevel", "VadState",
     "VoiceActivityDetector", "device_count", "library", "quantize_pcm16", "to_mono", "vad_energy",
-    "resample_batch", "fir_batch", "AudioLevel", "level_meter", "Stft", "MelFilterbank",
+    "resample_batch", "fir_batch", "AudioLevel", "level_meter", "Stft", "MelFilterbank", "resample_stereo_batch",
 ]

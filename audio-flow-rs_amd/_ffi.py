@@ -110,6 +110,8 @@ SIGNATURES = {
     "af_resample_out_len": (_sz, [_u32, _u32, _sz]),
     "af_resample_batch": (_st, [_u32, _u32, _vp, _sz, _sz, _vp, _sz]),
     "af_resample_batch_device": (_st, [_u32, _u32, _vp, _sz, _sz, _vp, _vp]),
+    "af_resample_batch_stereo_device": (_st, [_u32, _u32, _vp, _sz, _sz, _vp, _vp]),
+    "af_resample_has_stereo_path": (C.c_int, [_u32, _u32]),
     "af_resample_taps": (_st, [_u32, _u32, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32),
                                C.POINTER(_u32)]),
     # BatchResampler

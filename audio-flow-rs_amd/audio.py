@@ -103,6 +103,26 @@ def resample_batch(clips, input_rate: int, output_rate: int) -> np.ndarray:
     return out
 
 
+def resample_stereo_batch(clips, input_rate: int, output_rate: int) -> np.ndarray:
+    """``to_mono`` fused into the resampler (af_resample_batch_stereo_device): ``clips`` is
+    ``[n_clips, n_frames * 2]`` interleaved stereo; returns ``[n_clips, ceil(n_frames L / M)]``."""
+    import ctypes as _C
+    x = np.ascontiguousarray(clips, np.float32)
+    if x.ndim == 1:
+        x = x[None, :]
+    n_clips, n_frames = x.shape[0], x.shape[1] // 2
+    lib = library()
+    n_out = int(lib.af_resample_out_len(input_rate, output_rate, n_frames))
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xin = torch.from_numpy(x).to(dev)
+    out = torch.empty(n_clips, n_out, device=dev, dtype=torch.float32)
+    _check(lib.af_resample_batch_stereo_device(input_rate, output_rate, _C.c_void_p(xin.data_ptr()),
+                                               n_clips, n_frames, _C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
 def fir_batch(clips, taps) -> np.ndarray:
     x = np.ascontiguousarray(clips, np.float32)
     if x.ndim == 1:

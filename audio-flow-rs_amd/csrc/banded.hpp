@@ -30,6 +30,7 @@ struct Plan {
     int wpp = 0;              // waves sharing one block matrix
     int nwaves = 0;           // nb * wpp
     int G = 0;                // block periods per column and tile
+    int ch = 1;               // 2: x is interleaved stereo, downmixed while it is staged
     int seg_len = 0;          // floats of x per column segment
     int seg_stride = 0;       // odd, >= seg_len
     int64_t out_per_tile = 0; // 256 * G * nb
@@ -38,12 +39,13 @@ struct Plan {
 };
 
 // Decide whether (L, M, T) runs on the MFMA kernel and with which tile shape.
-Plan make_plan(uint32_t L, uint32_t M, int T, int c);
+Plan make_plan(uint32_t L, uint32_t M, int T, int c, int ch = 1);
 
 // Gather the A fragments [nb][NK][64] from the prototype (device, prototype order, L*T floats).
 af_status build_afrag(const Plan& p, const float* proto_dev, float* afrag_dev, hipStream_t stream);
 
-// Outputs m in [m0, m0 + n_out) of every clip; x[0] of a clip has absolute index x_abs0,
+// Outputs m in [m0, m0 + n_out) of every clip; x[0] of a clip has absolute index x_abs0
+// (x_abs0, x_len and x_stride count frames: with p.ch == 2 a frame is two floats),
 // samples outside [x_abs0, x_abs0 + x_len) read as zero.  The tile grid is anchored at
 // absolute output 0, so a sample's summation order does not depend on m0 / chunking.
 af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int64_t x_abs0,

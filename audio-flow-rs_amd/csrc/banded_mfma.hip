@@ -70,7 +70,9 @@ __device__ __forceinline__ int opaque_zero()
 
 // WPE = waves per SIMD the register budget is cut for: 5 when two workgroups of 9-10 waves
 // share a CU (96 VGPRs), 4 otherwise (128).
-template <int NK, int WPE>
+// CH = 2: x is interleaved stereo and is downmixed on its way into LDS ((L + R) * 0.5, the
+// to_mono of capture.rs:30-42): the staging registers hold (L, R) pairs.
+template <int NK, int WPE, int CH>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void banded_kernel(const Geom g)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -102,23 +104,33 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     // The 32 loads of the next tile are issued one by one between the MFMAs of the first chain
     // pair, so no wave sits in a burst of address work while the matrix pipe idles.
     constexpr uint32_t kOob = 0xFFF00000u;                      // + 16 col_span * 4 stays out of range
-    float pf[kCols * kPfSlots];
+    float pf[kCols * kPfSlots * CH];
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[kPfSlots];
     auto prep_tile = [&](uint32_t tile, bool live) {
         const uint32_t clip = tile / tpc;
         const int64_t t_abs = g.tile0 + (tile - clip * tpc);
         const int64_t base = t_abs * (16 * (int64_t)col_span) + g.lo_off - g.x_abs0;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride), 0,
-                                                 (int)(uint32_t)(g.x_len * 4), 0x00020000);
-        const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * 4u;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride * CH), 0,
+                                                 (int)(uint32_t)(g.x_len * 4 * CH), 0x00020000);
+        const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * (4u * CH);
         voff[0] = live ? v0 : kOob;
-        voff[1] = live && second ? v0 + (uint32_t)nthreads * 4u : kOob;
+        voff[1] = live && second ? v0 + (uint32_t)nthreads * (4u * CH) : kOob;
     };
     auto issue_load = [&](int s) {                              // s = h * 16 + cc
         const int cc = s % kCols, h = s / kCols;
-        pf[cc * kPfSlots + h] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
+        if constexpr (CH == 1) {
+            pf[cc * kPfSlots + h] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
+        } else {
+            // two dword loads: hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b64 to a single
+            // dword load and duplicates it
+            const int off = (int)(voff[h] + (uint32_t)(cc * col_span) * 8u);
+            pf[(cc * kPfSlots + h) * 2] =
+                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+            pf[(cc * kPfSlots + h) * 2 + 1] =
+                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0));
+        }
     };
     constexpr int kLoads = kCols * kPfSlots;
 
@@ -132,11 +144,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         __syncthreads();                                        // readers of the previous tile done
         {
             float* dst = xs + tid + opaque_zero();
+            auto staged = [&](int cc, int h) {                  // downmix: (L + R) * 0.5, exact
+                if constexpr (CH == 1) return pf[cc * kPfSlots + h];
+                else return (pf[(cc * kPfSlots + h) * 2] + pf[(cc * kPfSlots + h) * 2 + 1]) * 0.5f;
+            };
 #pragma unroll
-            for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = pf[cc * kPfSlots];
+            for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = staged(cc, 0);
             if (second) {
 #pragma unroll
-                for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = pf[cc * kPfSlots + 1];
+                for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = staged(cc, 1);
             }
         }
         __syncthreads();
@@ -211,22 +227,27 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 const int kNkInstances[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 48};
 
 template <int NK>
-void launch_nk(const Geom& g, bool five, unsigned grid, unsigned block, size_t smem, hipStream_t s)
+void launch_nk(const Geom& g, bool five, int ch, unsigned grid, unsigned block, size_t smem, hipStream_t s)
 {
     if constexpr (NK <= 32) {
+        if (ch == 2) {
+            hipLaunchKernelGGL((banded_kernel<NK, 4, 2>), dim3(grid), dim3(block), smem, s, g);
+            return;
+        }
         if (five) {
-            hipLaunchKernelGGL((banded_kernel<NK, 5>), dim3(grid), dim3(block), smem, s, g);
+            hipLaunchKernelGGL((banded_kernel<NK, 5, 1>), dim3(grid), dim3(block), smem, s, g);
             return;
         }
     }
-    hipLaunchKernelGGL((banded_kernel<NK, 4>), dim3(grid), dim3(block), smem, s, g);
+    hipLaunchKernelGGL((banded_kernel<NK, 4, 1>), dim3(grid), dim3(block), smem, s, g);
 }
 
 }  // namespace
 
-Plan make_plan(uint32_t L, uint32_t M, int T, int c)
+Plan make_plan(uint32_t L, uint32_t M, int T, int c, int ch)
 {
     Plan p;
+    p.ch = ch;
     p.L = L;
     p.M = M;
     p.T = T;
@@ -253,6 +274,7 @@ Plan make_plan(uint32_t L, uint32_t M, int T, int c)
     p.wpp = nb >= 5 ? 1 : nb == 1 ? 8 : nb == 2 ? 4 : 2;
     p.nwaves = p.nb * p.wpp;
     const int nthreads = 64 * p.nwaves;
+    if (ch == 2 && (p.nwaves > 8 || p.NK > 32)) return p;     // stereo staging: 8-wave shapes only
     const int seg_cap = kPfSlots * nthreads < kMaxSeg ? kPfSlots * nthreads : kMaxSeg;
     const int qp_last = (int)((16ull * (nb - 1) * M) / L);
     const int unit = 2 * p.wpp;                              // every wave runs chains in pairs
@@ -283,7 +305,7 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
 {
     if (n_out <= 0 || n_clips <= 0) return AF_OK;
     if (!p.ok) return fail(AF_ERR_UNSUPPORTED, "banded::launch without a plan");
-    if (x_len >= (int64_t)kMaxClip)
+    if (x_len * p.ch >= (int64_t)kMaxClip)
         return fail(AF_ERR_UNSUPPORTED, "clips of %lld samples are beyond the banded kernel's 32-bit offsets",
                     (long long)x_len);
     Geom g{};
@@ -316,16 +338,16 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
     const unsigned block = 64u * p.nwaves;
     const bool five = wg_per_cu == 2 && 2 * p.nwaves > 16;
     switch (p.NK) {
-    case 8: launch_nk<8>(g, five, (unsigned)grid, block, p.smem, stream); break;
-    case 12: launch_nk<12>(g, five, (unsigned)grid, block, p.smem, stream); break;
-    case 16: launch_nk<16>(g, five, (unsigned)grid, block, p.smem, stream); break;
-    case 20: launch_nk<20>(g, five, (unsigned)grid, block, p.smem, stream); break;
-    case 24: launch_nk<24>(g, five, (unsigned)grid, block, p.smem, stream); break;
-    case 28: launch_nk<28>(g, five, (unsigned)grid, block, p.smem, stream); break;
-    case 32: launch_nk<32>(g, five, (unsigned)grid, block, p.smem, stream); break;
-    case 36: launch_nk<36>(g, five, (unsigned)grid, block, p.smem, stream); break;
-    case 40: launch_nk<40>(g, five, (unsigned)grid, block, p.smem, stream); break;
-    case 48: launch_nk<48>(g, five, (unsigned)grid, block, p.smem, stream); break;
+    case 8: launch_nk<8>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
+    case 12: launch_nk<12>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
+    case 16: launch_nk<16>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
+    case 20: launch_nk<20>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
+    case 24: launch_nk<24>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
+    case 28: launch_nk<28>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
+    case 32: launch_nk<32>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
+    case 36: launch_nk<36>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
+    case 40: launch_nk<40>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
+    case 48: launch_nk<48>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
     default: return fail(AF_ERR_UNSUPPORTED, "no banded kernel for NK=%d", p.NK);
     }
     AF_HIP(hipGetLastError());

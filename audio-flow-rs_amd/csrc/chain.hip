@@ -107,14 +107,23 @@ af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev,
     if (c->n_clips == 0 || c->n_in == 0) return AF_OK;
     AF_REQUIRE(pcm_dev && (mel_dev || c->total_frames == 0), "af_chain_run_device: null buffer");
     const float* cur = pcm_dev;
+    const bool resample = c->cfg.input_rate != c->cfg.output_rate;
+    if (c->cfg.channels == 2 && resample &&
+        af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate)) {
+        // downmix fused into the resampler's loads: the mono signal never reaches HBM
+        AF_TRY(af_resample_batch_stereo_device(c->cfg.input_rate, c->cfg.output_rate, cur, c->n_clips,
+                                               c->n_in, c->d_res.as<float>(), stream));
+        cur = c->d_res.as<float>();
+    } else {
     if (c->cfg.channels == 2) {
         AF_TRY(af_to_mono_device(cur, c->n_clips * c->n_in * 2, 2, c->d_mono.as<float>(), stream));
         cur = c->d_mono.as<float>();
     }
-    if (c->cfg.input_rate != c->cfg.output_rate) {
+    if (resample) {
         AF_TRY(af_resample_batch_device(c->cfg.input_rate, c->cfg.output_rate, cur, c->n_clips, c->n_in,
                                         c->d_res.as<float>(), stream));
         cur = c->d_res.as<float>();
+    }
     }
     if (c->cfg.n_fir_taps) {
         AF_TRY(af_fir_batch_device(c->d_taps.as<float>(), c->cfg.n_fir_taps, cur, c->n_clips, c->n_res,

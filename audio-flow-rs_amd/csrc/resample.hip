@@ -116,6 +116,7 @@ struct Design {
     std::vector<float> proto;        // h[L*T] in prototype order (f32)
     DevBuf d_taps;                   // [L][kRow]
     banded::Plan plan;               // MFMA path when plan.ok
+    banded::Plan plan2;              // same, interleaved stereo input downmixed while staged
     DevBuf d_afrag;
     int x_tile_cap = 0;
     size_t smem = 0;
@@ -161,6 +162,7 @@ af_status make_design(uint32_t in_hz, uint32_t out_hz, Design& d, bool upload)
     d.proto.resize(h.size());
     for (size_t i = 0; i < h.size(); ++i) d.proto[i] = (float)h[i];
     d.plan = banded::make_plan(d.L, d.M, kT, kT / 2);
+    d.plan2 = banded::make_plan(d.L, d.M, kT, kT / 2, 2);
     if (d.plan.ok) {
         if (upload) {
             DevBuf d_proto;
@@ -415,6 +417,34 @@ af_status af_resample_batch_device(uint32_t input_rate, uint32_t output_rate, co
     const int64_t n_out = (int64_t)af_resample_out_len(input_rate, output_rate, n_in);
     return rs::launch(*d, in_dev, 0, (int64_t)n_in, (int64_t)n_in, out_dev, n_out, 0, n_out,
                       (int64_t)n_clips, as_stream(stream));
+}
+
+af_status af_resample_batch_stereo_device(uint32_t input_rate, uint32_t output_rate,
+                                          const float* in_dev, size_t n_clips, size_t n_frames,
+                                          float* out_dev, void* stream)
+{
+    AF_REQUIRE(input_rate > 0 && output_rate > 0, "sample rates must be positive");
+    if (n_clips == 0 || n_frames == 0) return AF_OK;
+    AF_REQUIRE(in_dev && out_dev, "af_resample_batch_stereo_device: null buffer");
+    if (input_rate == output_rate)
+        return af_to_mono_device(in_dev, n_clips * n_frames * 2, 2, out_dev, stream);
+    rs::Design* d = nullptr;
+    AF_TRY(cached_design(input_rate, output_rate, &d));
+    if (!d->plan2.ok)
+        return fail(AF_ERR_UNSUPPORTED,
+                    "%u -> %u Hz has no fused stereo path: call af_to_mono_device, then af_resample_batch_device",
+                    input_rate, output_rate);
+    const int64_t n_out = (int64_t)af_resample_out_len(input_rate, output_rate, n_frames);
+    return banded::launch(d->plan2, d->d_afrag.as<float>(), in_dev, 0, (int64_t)n_frames, (int64_t)n_frames,
+                          out_dev, n_out, 0, n_out, (int64_t)n_clips, as_stream(stream));
+}
+
+int af_resample_has_stereo_path(uint32_t input_rate, uint32_t output_rate)
+{
+    if (!input_rate || !output_rate) return 0;
+    if (input_rate == output_rate) return 1;
+    const uint32_t g = std::gcd(input_rate, output_rate);
+    return banded::make_plan(output_rate / g, input_rate / g, rs::kT, rs::kT / 2, 2).ok ? 1 : 0;
 }
 
 af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate, const float* in, size_t n_clips,

@@ -151,6 +151,15 @@ af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate,
 af_status af_resample_batch_device(uint32_t input_rate, uint32_t output_rate,
                                    const float* in_dev, size_t n_clips, size_t n_in,
                                    float* out_dev, void* stream);
+/* to_mono (capture.rs:30-42) fused into the resampler's loads: `in_dev` holds n_clips clips of
+ * n_frames interleaved stereo frames, the result equals af_to_mono_device followed by
+ * af_resample_batch_device without the mono intermediate ever reaching HBM (BASELINE config 4's
+ * first two stages).  Ratios without the fused path return AF_ERR_UNSUPPORTED;
+ * af_resample_has_stereo_path tells beforehand. */
+af_status af_resample_batch_stereo_device(uint32_t input_rate, uint32_t output_rate,
+                                          const float* in_dev, size_t n_clips, size_t n_frames,
+                                          float* out_dev, void* stream);
+int       af_resample_has_stereo_path(uint32_t input_rate, uint32_t output_rate);
 /* prototype filter taps h[L*T] as used by the device (f32), for inspection */
 af_status af_resample_taps(uint32_t input_rate, uint32_t output_rate,
                            float* taps, size_t cap, uint32_t* L, uint32_t* M, uint32_t* T);

@@ -66,6 +66,17 @@ ms = timeit(lambda: fb.apply_device(pw.data_ptr(), tot, ml.data_ptr(), torch.cud
 bb = pw.numel() * 4 + ml.numel() * 4
 out["mel_apply_cfg2"] = dict(ms=ms, alg_GBps=bb / ms / 1e6, frac_hbm=bb / ms / 1e6 / 8000)
 del pw, ml
+# config 4 chain (to_mono -> 48k->16k -> FIR 129 -> STFT -> 80 mel), 256 stereo 30 s clips
+import numpy as np
+taps_h = (np.hamming(129) * np.sinc((np.arange(129) - 64) * 0.9)).astype(np.float32); taps_h /= taps_h.sum()
+ch = af.ChainPipeline(input_rate=48000, channels=2, output_rate=16000, fir_taps=taps_h)
+totc = ch.set_batch_uniform(256, 1440000)
+melc = torch.empty(totc, 80, device=dev)
+ms = timeit(lambda: ch.run_device(s.data_ptr(), melc.data_ptr(), torch.cuda.current_stream().cuda_stream), k=5)
+bb = s.numel() * 4 + melc.numel() * 4
+out["chain_cfg4_256clips"] = dict(ms=ms, alg_GBps=bb / ms / 1e6, frac_hbm=bb / ms / 1e6 / 8000, rtf=256 * 30 / ms * 1e3,
+                                  note="5 kernels, intermediates stay in HBM; algorithmic bytes = PCM in + mel out")
+del melc
 # PCIe-inclusive fused features (host buffers), 64 clips
 k = 64
 pipe = af.FeaturePipeline(); pipe.set_batch_uniform(k, 1440000)

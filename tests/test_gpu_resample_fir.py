@@ -222,3 +222,23 @@ def test_fir_streaming_chunk_invariance_mfma(af, po):
     got = np.concatenate(parts)
     assert np.array_equal(got, whole[:got.size])
     assert rel_err(whole, po.fir(x, taps)) < 1e-5
+
+
+@pytest.mark.parametrize("fi,fo", [(48000, 16000), (16000, 48000), (8000, 16000), (16000, 16000)])
+@pytest.mark.parametrize("n", [1, 33, 1000, 30011])
+def test_fused_stereo_downmix_resample(af, po, fi, fo, n):
+    # to_mono (capture.rs:30-42) inside the resampler's loads == to_mono, then resample
+    clips = np.stack([synth_clip(300 + i, n, 2, fi) for i in range(3)])
+    assert af.library().af_resample_has_stereo_path(fi, fo) == 1
+    y = af.resample_stereo_batch(clips, fi, fo)
+    for i in range(3):
+        mono = po.to_mono(clips[i], 2)
+        ref = po.resample(mono, fi, fo) if fi != fo else mono
+        assert y[i].size == ref.size
+        assert np.linalg.norm(y[i] - ref) <= TOL * max(np.linalg.norm(ref), 1e-30) + 1e-12
+
+
+def test_fused_stereo_path_is_reported_per_ratio(af):
+    lib = af.library()
+    assert lib.af_resample_has_stereo_path(44100, 16000) == 0     # 10-wave shape: separate to_mono
+    assert lib.af_resample_has_stereo_path(48000, 44100) == 0     # VALU kernel ratio
