@@ -111,6 +111,31 @@ int main()
         y = fir.process({1.0f});
         CHECK(y == std::vector<float>({1.0f}));       // history carried
     }
+    // Stft / MelFilterbank / level meter (docs/OPS.md): shapes, a known tone, Parseval
+    {
+        Stft st;
+        std::vector<float> x(16000);
+        for (size_t i = 0; i < x.size(); ++i) x[i] = 0.5f * std::sin(2.0 * M_PI * 1000.0 * i / 16000.0);
+        CHECK(st.n_frames(x.size()) == 59 && st.n_bins() == 513);
+        auto P = st.power(x);
+        CHECK(P.size() == 59 * 513);
+        size_t arg = 0;                                // 1 kHz at 16 kHz / 1024 = bin 64
+        for (size_t k = 1; k < 513; ++k) if (P[k] > P[arg]) arg = k;
+        CHECK(arg == 64);
+        // periodic Hann: sum w^2 = 3N/8; a bin-centred tone of amplitude A has |X|^2 = (A N / 4)^2
+        CHECK(std::fabs(P[64] / (0.5 * 1024 / 4) / (0.5 * 1024 / 4) - 1.0) < 1e-3);
+        MelFilterbank fb(16000, 80);
+        auto W = fb.weights();
+        CHECK(W.size() == 80 * 513);
+        auto mel = fb.apply(P);
+        CHECK(mel.size() == 59 * 80);
+        double direct = 0.0;                           // filter 40 of frame 0 by hand
+        for (size_t k = 0; k < 513; ++k) direct += (double)W[40 * 513 + k] * P[k];
+        CHECK(std::fabs(mel[40] - direct) <= 1e-5 * std::fabs(direct) + 1e-12);
+        auto lv = level_meter(std::vector<float>(1600, 0.5f), 800);
+        CHECK(lv.size() == 2 && std::fabs(lv[0].rms - 0.5f) < 1e-6f && lv[1].peak == 0.5f);
+        CHECK(std::fabs(lv[0].dbfs - 20.0f * std::log10(0.5f)) < 1e-4f);
+    }
     std::printf(failures ? "%d check(s) failed\n" : "harness ok\n", failures);
     return failures ? 1 : 0;
 }
