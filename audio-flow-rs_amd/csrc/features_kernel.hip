@@ -20,9 +20,12 @@
 //     through the same LDS buffer.  Power is written to LDS ([frame][514]).
 //   * mel: P^T (bins x 16 frames) is the B operand and the banded filterbank
 //     the A operand of v_mfma_f32_16x16x4_f32 (exact f32 FMA chain).  Only the
-//     non-zero band of each 16-filter tile is multiplied (about 134 K-steps of 4 bins
-//     instead of 645 dense); the K-steps are split evenly over the 4 waves,
-//     partial 16x16 tiles meet in LDS and are written out coalesced.
+//     non-zero band of each group of <= 16 filters is multiplied (about 134 K-steps
+//     of 4 bins instead of 645 dense); whole groups are dealt to the 4 waves by the
+//     host (features_api.hip, build_plan), so every wave stores its own 16-byte quads
+//     of mel values straight to HBM and nothing is reduced across waves.
+//   * other outputs of the same kernel (Params flags / template SEP): the power rows
+//     themselves (AF_OUT_POWER), log10 of the mel values, one spectrogram per channel.
 #include "features.hpp"
 
 namespace af {
