@@ -75,10 +75,14 @@ def cpu_baseline(pcm_host, n_clips: int, n_frames: int) -> dict:
     from oracle import pyoracle as po
     flat = pcm_host.reshape(-1)
     nf = po.stft_n_frames(n_frames, N_FFT, HOP)
-    t0 = time.perf_counter()
-    po.features_f32_batch(flat, n_clips, n_frames, CHANNELS, float(SR), N_FFT, HOP, N_MELS, threads=1)
-    t_single = time.perf_counter() - t0
-    single = n_clips * nf / t_single
+    # whole passes over the sample until about 10 s of single-thread work have been timed
+    passes, t_single = 0, 0.0
+    while passes == 0 or (t_single < 10.0 and passes < 8):
+        t0 = time.perf_counter()
+        po.features_f32_batch(flat, n_clips, n_frames, CHANNELS, float(SR), N_FFT, HOP, N_MELS, threads=1)
+        t_single += time.perf_counter() - t0
+        passes += 1
+    single = passes * n_clips * nf / t_single
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -92,8 +96,8 @@ def cpu_baseline(pcm_host, n_clips: int, n_frames: int) -> dict:
     return {
         "value": single, "unit": "frames/s", "cores": 1, "kind": "port",
         "sample": f"{n_clips} of the {CLIPS_PER_GPU} clips ({n_clips * CLIP_SECONDS} s of stereo 48 kHz "
-                  f"audio), float32 port of the oracle, single thread as in the reference "
-                  f"({t_single:.2f} s of CPU work)",
+                  f"audio) x {passes} passes, float32 port of the oracle, single thread as in the "
+                  f"reference ({t_single:.2f} s of CPU work)",
         "rtf": single * HOP / SR,
         "all_cores": {"value": multi, "unit": "frames/s", "cores": threads,
                       "seconds": round(t_multi, 3)},
