@@ -20,7 +20,10 @@ constexpr int kHalfDw = 32 * kXStride;    // exchange region of one half-wave (1
 constexpr int kWbuf = 2 * kHalfDw + 8;    // per-wave LDS buffer (2120 dwords; == 8 mod 32)
 constexpr int kMaxSteps = 64;             // MFMA K-steps (4 bins each) per wave
 constexpr int kWinRow = 36;               // LDS window table row: 32 values + 4 pad
-constexpr int kTwRow = 68;                // LDS twiddle table row: 32 (cos,sin) + 4 pad
+// LDS twiddle table row: 32 (cos,sin) + 2 pad.  The kernel reads a row as 8-byte pairs
+// (ds_read2_b64, banked modulo 32 dwords): a stride = 2 mod 4 dwords spreads 16 lanes x 2
+// dwords over all 32 banks (68 = 4 mod 32 made lanes n2 and n2 + 8 collide).
+constexpr int kTwRow = 66;
 
 // Mel-phase plan (built on the host): the filterbank is cut into groups of at
 // most 16 consecutive filters (one MFMA row tile each); a group is multiplied

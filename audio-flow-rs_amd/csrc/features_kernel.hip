@@ -242,22 +242,23 @@ __device__ __forceinline__ void fft_phase_a(const float* __restrict__ tile, floa
     fft32(re, im);                                // over n1 -> Y[k1] at brev5(k1)
 
     // inter-stage twiddle e^{-2 pi i n2 k1 / 1024}; row n2 of the LDS table holds
-    // (cos, sin) for k1 = 0..31, two k1 per ds_read_b128
+    // (cos, sin) for k1 = 0..31, read as 8-byte pairs
     {
-        const float4* trow = reinterpret_cast<const float4*>(ttab + n2 * kTwRow);
+        const float2* trow = reinterpret_cast<const float2*>(ttab + n2 * kTwRow);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const float4 t = trow[j];
             if (j > 0) {
+                const float2 t = trow[2 * j];
                 const int r = brev5(2 * j);
                 const float xr = re[r], xi = im[r];
                 re[r] = xr * t.x + xi * t.y;
                 im[r] = xi * t.x - xr * t.y;
             }
+            const float2 t = trow[2 * j + 1];
             const int r = brev5(2 * j + 1);
             const float xr = re[r], xi = im[r];
-            re[r] = xr * t.z + xi * t.w;
-            im[r] = xi * t.z - xr * t.w;
+            re[r] = xr * t.x + xi * t.y;
+            im[r] = xi * t.x - xr * t.y;
         }
     }
 
