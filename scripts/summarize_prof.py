@@ -12,10 +12,10 @@ from collections import defaultdict
 
 
 def find(d, suffix):
-    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit(f"no *{suffix} under {d}")
-    return hits[0]
+    return hits[-1]                      # the newest run when several were merged into one directory
 
 
 def kernel_stats(d, out, rx):
