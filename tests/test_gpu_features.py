@@ -174,3 +174,25 @@ def test_full_size_properties(af, po):
     for c in (0, 31, 62):
         ref = po.features(pcm[c].cpu().numpy().reshape(-1), ch, 48000.0)
         assert frame_rel_err(m[c].cpu().numpy(), ref) < TOL
+
+
+def test_many_ragged_clips_stress(af, po):
+    # 3000 clips of random length (a third of them too short for a single frame), scalar-path
+    # offsets: placement and values of every clip's rows; a sample of clips against the oracle
+    rng = np.random.default_rng(2024)
+    lens = rng.integers(0, 5000, size=3000)
+    lens[rng.integers(0, 3000, size=50)] = 1024                     # exactly one frame
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pcm = (rng.standard_normal(int(offs[-1])) * 0.2).astype(np.float32)
+    pipe = af.FeaturePipeline(sample_rate=16000, channels=1)
+    total = pipe.set_batch(offs)
+    frames = np.array([po.stft_n_frames(int(n)) for n in lens])
+    assert total == int(frames.sum())
+    mel = pipe.run(pcm)
+    assert np.isfinite(mel).all()
+    rows = np.concatenate([[0], np.cumsum(frames)])
+    for c in rng.choice(3000, size=40, replace=False):
+        if frames[c] == 0:
+            continue
+        ref = po.features(pcm[offs[c]:offs[c + 1]], 1, 16000.0)
+        assert frame_rel_err(mel[rows[c]:rows[c + 1]], ref) < TOL
