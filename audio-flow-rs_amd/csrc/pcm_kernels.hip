@@ -117,86 +117,90 @@ __global__ void quantize_kernel(const float* __restrict__ in, size_t n, int16_t*
 }
 
 // ---- quantise + base64 ---------------------------------------------------------
-__device__ __forceinline__ unsigned b64c(unsigned v)
+// 6 samples = 12 bytes -> 16 characters (one 16-byte store)
+// Four 6-bit values, one per byte of v, to their RFC 4648 characters with byte-parallel
+// arithmetic: c = v + 'A' + 6 [v > 25] - 75 [v > 51] - 15 [v > 61] + 3 [v > 62].  v <= 63 keeps
+// every byte sum below 256, and the subtracted bytes never exceed the added ones, so no carry
+// or borrow crosses a byte.
+__device__ __forceinline__ unsigned b64_chars4(unsigned v)
 {
-    // RFC 4648 alphabet without a table: A-Z a-z 0-9 + /
-    v &= 63u;
-    return v < 26 ? 'A' + v : v < 52 ? 'a' + (v - 26) : v < 62 ? '0' + (v - 52) : v == 62 ? '+' : '/';
+    const unsigned m25 = (v + 0x66666666u) & 0x80808080u;   // 0x80 where v >= 26
+    const unsigned m51 = (v + 0x4C4C4C4Cu) & 0x80808080u;   //            v >= 52
+    const unsigned m61 = (v + 0x42424242u) & 0x80808080u;   //            v >= 62
+    const unsigned m62 = (v + 0x41414141u) & 0x80808080u;   //            v >= 63
+    const unsigned add = v + 0x41414141u + (m25 >> 5) + (m25 >> 6) + (m62 >> 6) + (m62 >> 7);   // +6, +3
+    const unsigned sub = (m51 >> 1) + (m51 >> 4) + (m51 >> 6) + (m51 >> 7)                      // 75
+                         + (m61 >> 3) - (m61 >> 7);                                             // 15
+    return add - sub;
 }
 
-// one lane = 6 samples = 12 bytes -> 16 characters (one 16-byte store).  The 6-sample groups
-// of a workgroup are 1536 consecutive floats: they are fetched with coalesced 16-byte loads
-// into LDS and picked up from there (a lane reading its own 24 bytes from global memory
-// touches every cache line six times).
-constexpr int kB64Tile = kBlock * 6;             // samples per workgroup step
-
-__device__ __forceinline__ void b64_encode16(const float (&x)[6], unsigned char (&ch)[16])
+// 6 samples -> 12 bytes (little-endian i16) -> 16 characters, packed 4 per dword
+__device__ __forceinline__ uint4 b64_encode16(const float (&x)[6])
 {
-    unsigned char by[12];
+    unsigned q[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int q = quant1(x[j]);
-        by[2 * j] = (unsigned char)(q & 0xff);
-        by[2 * j + 1] = (unsigned char)((q >> 8) & 0xff);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const unsigned v = ((unsigned)by[3 * t] << 16) | ((unsigned)by[3 * t + 1] << 8) | by[3 * t + 2];
-        ch[4 * t] = (unsigned char)b64c(v >> 18);
-        ch[4 * t + 1] = (unsigned char)b64c(v >> 12);
-        ch[4 * t + 2] = (unsigned char)b64c(v >> 6);
-        ch[4 * t + 3] = (unsigned char)b64c(v);
-    }
+    for (int j = 0; j < 6; ++j) q[j] = (unsigned)quant1(x[j]) & 0xffffu;
+    // byte stream b0..b11 = q0.lo q0.hi q1.lo q1.hi ...; triple t = bytes 3t, 3t+1, 3t+2
+    const unsigned w0 = q[0] | (q[1] << 16), w1 = q[2] | (q[3] << 16), w2 = q[4] | (q[5] << 16);
+    auto triple = [](unsigned b0, unsigned b1, unsigned b2) {
+        const unsigned t = (b0 << 16) | (b1 << 8) | b2;             // 24 bits, first byte on top
+        // characters in memory order: byte 0 = bits 23..18, byte 1 = 17..12, byte 2 = 11..6, byte 3 = 5..0
+        const unsigned v = ((t >> 18) & 63u) | (((t >> 12) & 63u) << 8) | (((t >> 6) & 63u) << 16) |
+                           ((t & 63u) << 24);
+        return b64_chars4(v);
+    };
+    uint4 o;
+    o.x = triple(w0 & 0xffu, (w0 >> 8) & 0xffu, (w0 >> 16) & 0xffu);
+    o.y = triple(w0 >> 24, w1 & 0xffu, (w1 >> 8) & 0xffu);
+    o.z = triple((w1 >> 16) & 0xffu, w1 >> 24, w2 & 0xffu);
+    o.w = triple((w2 >> 8) & 0xffu, (w2 >> 16) & 0xffu, w2 >> 24);
+    return o;
 }
 
+// Fast path: a lane takes 12 consecutive samples = three 16-byte loads (the three loads of a
+// wave cover one contiguous 3 KB span, every cache line is used whole) -> two 16-byte stores.
+// The last (n mod 12) samples, and everything when a pointer is not 16-byte aligned, go
+// through the 6-sample path below.
 __global__ __launch_bounds__(kBlock) void pcm16_base64_kernel(const float* __restrict__ in, size_t n,
                                                               char* __restrict__ out, int vec_ok)
 {
-    __shared__ __attribute__((aligned(16))) float tile[kB64Tile];
     const size_t n_bytes = 2 * n;
-    const size_t n_tiles = (n + kB64Tile - 1) / kB64Tile;
-    const int tid = threadIdx.x;
-    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const size_t s0 = t * kB64Tile;
-        __syncthreads();                                  // the previous tile has been read
-        if (vec_ok && s0 + kB64Tile <= n) {
-            const float4* src = reinterpret_cast<const float4*>(in + s0);
-            for (int i = tid; i < kB64Tile / 4; i += kBlock) reinterpret_cast<float4*>(tile)[i] = src[i];
-        } else {
-            for (int i = tid; i < kB64Tile; i += kBlock) tile[i] = s0 + i < n ? in[s0 + i] : 0.0f;
-        }
-        __syncthreads();
-        const size_t g = t * kBlock + tid;                // 6-sample group of this lane
-        const size_t byte0 = g * 12;
-        if (byte0 >= n_bytes) continue;
+    const size_t n12 = vec_ok ? n / 12 : 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = t0; i < n12; i += stride) {
+        const float4* src = reinterpret_cast<const float4*>(in) + 3 * i;
+        const float4 a = src[0], b = src[1], c = src[2];
+        const float x0[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+        const float x1[6] = {b.z, b.w, c.x, c.y, c.z, c.w};
+        uint4* dst = reinterpret_cast<uint4*>(out) + 2 * i;
+        dst[0] = b64_encode16(x0);
+        dst[1] = b64_encode16(x1);
+    }
+    // remaining 6-sample groups
+    const size_t g0 = n12 * 2, n_groups = (n + 5) / 6;
+    for (size_t g = g0 + t0; g < n_groups; g += stride) {
         float x[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) x[j] = tile[tid * 6 + j];
-        unsigned char ch[16];
-        b64_encode16(x, ch);
+        for (int j = 0; j < 6; ++j) x[j] = g * 6 + j < n ? in[g * 6 + j] : 0.0f;
+        const uint4 o = b64_encode16(x);
+        const unsigned w[4] = {o.x, o.y, o.z, o.w};
+        auto chr = [&](size_t c) { return (char)((w[c >> 2] >> (8 * (c & 3))) & 0xffu); };
+        const size_t byte0 = g * 12;
         if (byte0 + 12 <= n_bytes) {
-            if (vec_ok) {
-                uint4 o;
-                o.x = ch[0] | (ch[1] << 8) | (ch[2] << 16) | ((unsigned)ch[3] << 24);
-                o.y = ch[4] | (ch[5] << 8) | (ch[6] << 16) | ((unsigned)ch[7] << 24);
-                o.z = ch[8] | (ch[9] << 8) | (ch[10] << 16) | ((unsigned)ch[11] << 24);
-                o.w = ch[12] | (ch[13] << 8) | (ch[14] << 16) | ((unsigned)ch[15] << 24);
-                reinterpret_cast<uint4*>(out)[g] = o;
-            } else {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) out[g * 16 + c] = (char)ch[c];
-            }
+            for (int c = 0; c < 16; ++c) out[g * 16 + c] = chr(c);
         } else {
             // last, partial group: whole 3-byte triples, then '=' padding
             const size_t rem = n_bytes - byte0;          // 2,4,6,8,10
             const size_t full = rem / 3, tail = rem % 3;
-            for (size_t c = 0; c < full * 4; ++c) out[g * 16 + c] = (char)ch[c];
+            for (size_t c = 0; c < full * 4; ++c) out[g * 16 + c] = chr(c);
             if (tail) {
-                char* o = out + g * 16 + full * 4;
-                o[0] = (char)ch[full * 4];
-                o[1] = (char)ch[full * 4 + 1];       // low bits already zero (samples beyond are 0)
-                o[2] = tail == 2 ? (char)ch[full * 4 + 2] : '=';
-                o[3] = '=';
+                char* op = out + g * 16 + full * 4;
+                op[0] = chr(full * 4);
+                op[1] = chr(full * 4 + 1);           // low bits already zero (samples beyond are 0)
+                op[2] = tail == 2 ? chr(full * 4 + 2) : '=';
+                op[3] = '=';
             }
         }
     }
@@ -362,10 +366,8 @@ af_status af_pcm16_base64_device(const float* in_dev, size_t n, char* out_dev, v
     AF_REQUIRE(in_dev && out_dev, "pcm16_base64: null buffer");
     const int vec_ok = reinterpret_cast<uintptr_t>(out_dev) % 16 == 0 &&
                        reinterpret_cast<uintptr_t>(in_dev) % 16 == 0;
-    size_t tiles = (n + kB64Tile - 1) / kB64Tile;
-    if (tiles > 2048) tiles = 2048;
-    hipLaunchKernelGGL(pcm16_base64_kernel, dim3((int)tiles), dim3(kBlock), 0, as_stream(stream), in_dev,
-                       n, out_dev, vec_ok);
+    hipLaunchKernelGGL(pcm16_base64_kernel, dim3(grid_for((n + 11) / 12)), dim3(kBlock), 0,
+                       as_stream(stream), in_dev, n, out_dev, vec_ok);
     AF_HIP(hipGetLastError());
     return AF_OK;
 }
