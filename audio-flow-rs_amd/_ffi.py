@@ -112,6 +112,7 @@ SIGNATURES = {
     "af_resample_batch_device": (_st, [_u32, _u32, _vp, _sz, _sz, _vp, _vp]),
     "af_resample_batch_stereo_device": (_st, [_u32, _u32, _vp, _sz, _sz, _vp, _vp]),
     "af_resample_has_stereo_path": (C.c_int, [_u32, _u32]),
+    "af_resample_prepare": (_st, [_u32, _u32]),
     "af_resample_taps": (_st, [_u32, _u32, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32),
                                C.POINTER(_u32)]),
     # BatchResampler
@@ -127,6 +128,7 @@ SIGNATURES = {
     "af_fir_process": (_st, [_vp, _vp, _sz, _vp]),
     "af_fir_reset": (None, [_vp]),
     "af_fir_batch": (_st, [_vp, _sz, _vp, _sz, _sz, _vp]),
+    "af_fir_apply_batch_device": (_st, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "af_fir_batch_device": (_st, [_vp, _sz, _vp, _sz, _sz, _vp, _vp]),
     # FeaturePipeline
     "af_features_default_config": (None, [C.POINTER(FeaturesConfig)]),

@@ -15,7 +15,8 @@ using namespace af;
 struct af_chain {
     af_chain_config cfg{};
     af_features* feat = nullptr;
-    DevBuf d_taps, d_mono, d_res, d_fir, d_pcm, d_mel;
+    af_fir* fir = nullptr;           // taps + MFMA fragments, built once
+    DevBuf d_mono, d_res, d_fir, d_pcm, d_mel;
     size_t n_clips = 0, n_in = 0, n_res = 0, total_frames = 0;
 };
 
@@ -59,12 +60,9 @@ af_status af_chain_create(const af_chain_config* cfg, af_chain** out)
     fc.f_max = cfg->f_max;
     fc.device = -1;
     af_status st = af_features_create(&fc, &c->feat);
-    if (st == AF_OK && cfg->n_fir_taps) {
-        st = c->d_taps.reserve(cfg->n_fir_taps * sizeof(float));
-        if (st == AF_OK && hipMemcpy(c->d_taps.p, cfg->fir_taps, cfg->n_fir_taps * sizeof(float),
-                                     hipMemcpyHostToDevice) != hipSuccess)
-            st = fail(AF_ERR_HIP, "uploading FIR taps failed");
-    }
+    // everything run_device needs is built here, so that it only launches kernels
+    if (st == AF_OK && cfg->n_fir_taps) st = af_fir_create(cfg->fir_taps, cfg->n_fir_taps, &c->fir);
+    if (st == AF_OK) st = af_resample_prepare(cfg->input_rate, cfg->output_rate);
     if (st != AF_OK) { af_chain_destroy(c); return st; }
     *out = c;
     return AF_OK;
@@ -74,6 +72,7 @@ void af_chain_destroy(af_chain* c)
 {
     if (!c) return;
     af_features_destroy(c->feat);
+    af_fir_destroy(c->fir);
     delete c;
 }
 
@@ -126,8 +125,7 @@ af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev,
     }
     }
     if (c->cfg.n_fir_taps) {
-        AF_TRY(af_fir_batch_device(c->d_taps.as<float>(), c->cfg.n_fir_taps, cur, c->n_clips, c->n_res,
-                                   c->d_fir.as<float>(), stream));
+        AF_TRY(af_fir_apply_batch_device(c->fir, cur, c->n_clips, c->n_res, c->d_fir.as<float>(), stream));
         cur = c->d_fir.as<float>();
     }
     return af_features_run_device(c->feat, cur, mel_dev, stream);

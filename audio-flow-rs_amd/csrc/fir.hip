@@ -219,6 +219,17 @@ af_status af_fir_process(af_fir* f, const float* in, size_t n, float* out)
     return AF_OK;
 }
 
+af_status af_fir_apply_batch_device(const af_fir* f, const float* in_dev, size_t n_clips, size_t n,
+                                    float* out_dev, void* stream)
+{
+    AF_REQUIRE(f, "af_fir_apply_batch_device: null handle");
+    if (n_clips == 0 || n == 0) return AF_OK;
+    AF_REQUIRE(in_dev && out_dev, "af_fir_apply_batch_device: null buffer");
+    return firk::launch(f->plan, f->d_afrag.as<float>(), f->d_taps.as<float>(), (int)f->taps.size(), in_dev, 0,
+                        (int64_t)n, (int64_t)n, out_dev, (int64_t)n, 0, (int64_t)n, (int64_t)n_clips,
+                        as_stream(stream));
+}
+
 af_status af_fir_batch_device(const float* taps_dev, size_t n_taps, const float* in_dev, size_t n_clips,
                               size_t n, float* out_dev, void* stream)
 {

@@ -19,6 +19,7 @@
 // with coalesced loads, one thread per output.
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <vector>
@@ -382,10 +383,13 @@ size_t af_resample_out_len(uint32_t input_rate, uint32_t output_rate, size_t n_i
 
 namespace {
 
-// one cached design per (in, out) pair and thread for the stateless batch calls
+// one cached design per (in, out) pair for the stateless batch calls (process-wide, immutable
+// once built; the device tables belong to the device that was current at first use)
 af_status cached_design(uint32_t in_hz, uint32_t out_hz, rs::Design** out)
 {
-    static thread_local std::vector<rs::Design*> cache;
+    static std::mutex mu;
+    static std::vector<rs::Design*> cache;
+    std::lock_guard<std::mutex> lock(mu);
     for (rs::Design* d : cache)
         if (d->in_hz == in_hz && d->out_hz == out_hz) { *out = d; return AF_OK; }
     rs::Design* d = new (std::nothrow) rs::Design();
@@ -417,6 +421,15 @@ af_status af_resample_batch_device(uint32_t input_rate, uint32_t output_rate, co
     const int64_t n_out = (int64_t)af_resample_out_len(input_rate, output_rate, n_in);
     return rs::launch(*d, in_dev, 0, (int64_t)n_in, (int64_t)n_in, out_dev, n_out, 0, n_out,
                       (int64_t)n_clips, as_stream(stream));
+}
+
+af_status af_resample_prepare(uint32_t input_rate, uint32_t output_rate)
+{
+    AF_REQUIRE(input_rate > 0 && output_rate > 0, "sample rates must be positive");
+    if (input_rate == output_rate) return AF_OK;
+    AF_TRY(ensure_device(-1));
+    rs::Design* d = nullptr;
+    return cached_design(input_rate, output_rate, &d);
 }
 
 af_status af_resample_batch_stereo_device(uint32_t input_rate, uint32_t output_rate,

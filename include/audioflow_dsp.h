@@ -160,6 +160,9 @@ af_status af_resample_batch_stereo_device(uint32_t input_rate, uint32_t output_r
                                           const float* in_dev, size_t n_clips, size_t n_frames,
                                           float* out_dev, void* stream);
 int       af_resample_has_stereo_path(uint32_t input_rate, uint32_t output_rate);
+/* builds the per-ratio tables now, so that later af_resample_batch*_device calls only launch
+ * kernels (call it before capturing them into a hipGraph) */
+af_status af_resample_prepare(uint32_t input_rate, uint32_t output_rate);
 /* prototype filter taps h[L*T] as used by the device (f32), for inspection */
 af_status af_resample_taps(uint32_t input_rate, uint32_t output_rate,
                            float* taps, size_t cap, uint32_t* L, uint32_t* M, uint32_t* T);
@@ -194,6 +197,10 @@ af_status af_fir_batch(const float* taps, size_t n_taps, const float* in,
                        size_t n_clips, size_t n, float* out);
 af_status af_fir_batch_device(const float* taps_dev, size_t n_taps, const float* in_dev,
                               size_t n_clips, size_t n, float* out_dev, void* stream);
+/* the same stateless batch with the taps of a handle (its history is neither read nor
+ * written): nothing is allocated or rebuilt, so the call can be captured into a hipGraph */
+af_status af_fir_apply_batch_device(const af_fir* f, const float* in_dev, size_t n_clips, size_t n,
+                                    float* out_dev, void* stream);
 
 /* FeaturePipeline (docs/OPS.md "STFT", "Mel"): interleaved PCM ->
  * to_mono (capture.rs:30-42 semantics) -> periodic-Hann STFT (n_fft 1024,

@@ -104,3 +104,28 @@ def test_streaming_step_by_step_with_hipgraph(af, po):
     full = one.run(x)
     assert got.shape == full.shape == (n_steps * frames_per_step, 80)
     assert np.array_equal(got, full)                             # same frame indices, same bits
+
+
+def test_chain_is_capturable_without_a_warm_up(af, po):
+    """af_chain_run_device only launches kernels (tables, FIR fragments and intermediates exist
+    after create / set_batch), so its very first call can be captured into a hipGraph."""
+    torch = pytest.importorskip("torch")
+    taps = lowpass_taps()
+    n_clips, n = 2, 48000
+    clips = [synth_clip(400 + i, n, 2, 48000) for i in range(n_clips)]
+    chain = af.ChainPipeline(input_rate=48000, channels=2, output_rate=16000, fir_taps=taps)
+    total = chain.set_batch_uniform(n_clips, n)
+    dev = torch.device("cuda:0")
+    pcm = torch.from_numpy(np.concatenate(clips)).to(dev)
+    mel = torch.zeros(total, 80, device=dev)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            chain.run_device(pcm.data_ptr(), mel.data_ptr(), s.cuda_stream)
+    g.replay()
+    torch.cuda.synchronize()
+    nf = chain.n_frames(n)
+    got = mel.cpu().numpy()
+    for i, x in enumerate(clips):
+        assert frame_rel_err(got[i * nf:(i + 1) * nf], oracle_chain(po, x, 2, 48000, 16000, taps)) < 2e-5
