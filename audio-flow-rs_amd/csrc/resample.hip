@@ -423,6 +423,18 @@ af_status af_resample_batch_device(uint32_t input_rate, uint32_t output_rate, co
                       (int64_t)n_clips, as_stream(stream));
 }
 
+int af_resample_plan_describe(uint32_t input_rate, uint32_t output_rate, uint32_t channels, int32_t* info)
+{
+    // host-only: which kernel shape a ratio gets (tests/test_host_mirror.py checks the invariants)
+    if (!info || !input_rate || !output_rate || (channels != 1 && channels != 2)) return 0;
+    const uint32_t g = std::gcd(input_rate, output_rate);
+    const banded::Plan p = banded::make_plan(output_rate / g, input_rate / g, rs::kT, rs::kT / 2, (int)channels);
+    const int32_t v[12] = {p.ok ? 1 : 0, (int32_t)p.L, (int32_t)p.M, p.nb, p.S, p.NK, p.G, p.wpp,
+                           p.nwaves, p.seg_len, p.seg_stride, (int32_t)p.smem};
+    for (int i = 0; i < 12; ++i) info[i] = v[i];
+    return p.ok ? 1 : 0;
+}
+
 af_status af_resample_prepare(uint32_t input_rate, uint32_t output_rate)
 {
     AF_REQUIRE(input_rate > 0 && output_rate > 0, "sample rates must be positive");

@@ -163,6 +163,12 @@ int       af_resample_has_stereo_path(uint32_t input_rate, uint32_t output_rate)
 /* builds the per-ratio tables now, so that later af_resample_batch*_device calls only launch
  * kernels (call it before capturing them into a hipGraph) */
 af_status af_resample_prepare(uint32_t input_rate, uint32_t output_rate);
+/* diagnostics, host only: the banded-MFMA shape of a ratio.  info[12] = {ok, L, M, block
+ * matrices, input samples per block period, MFMA steps per chain, block periods per tile,
+ * waves per matrix, waves per workgroup, segment length, segment stride, LDS bytes};
+ * returns 0 when the ratio runs on the thread-per-output kernel instead. */
+int       af_resample_plan_describe(uint32_t input_rate, uint32_t output_rate, uint32_t channels,
+                                    int32_t* info);
 /* prototype filter taps h[L*T] as used by the device (f32), for inspection */
 af_status af_resample_taps(uint32_t input_rate, uint32_t output_rate,
                            float* taps, size_t cap, uint32_t* L, uint32_t* M, uint32_t* T);

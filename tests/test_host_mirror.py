@@ -88,3 +88,44 @@ def test_vad_config_defaults(af):
     assert (c.threshold_db, c.smoothing_factor, c.silence_timeout_frames, c.min_speech_frames) \
         == (-50.0, 0.3, 15, 3)
     assert af.VadState.Silence == 0 and af.VadState.Speech == 1 and af.VadState.Ending == 2
+
+
+def test_banded_plan_invariants(af):
+    """Host-side shape selection of the MFMA resampler (banded_mfma.hip make_plan): no GPU."""
+    import ctypes as C
+    from math import gcd
+    lib = af.library()
+    names = ["ok", "L", "M", "nb", "S", "NK", "G", "wpp", "nwaves", "seg_len", "seg_stride", "smem"]
+
+    def plan(fi, fo, ch=1):
+        info = (C.c_int32 * 12)()
+        ok = lib.af_resample_plan_describe(fi, fo, ch, info)
+        d = dict(zip(names, list(info)))
+        assert ok == d["ok"]
+        return d
+
+    # BASELINE's ratios
+    p = plan(44100, 16000)
+    assert (p["ok"], p["L"], p["M"], p["nb"], p["S"], p["NK"], p["G"], p["nwaves"]) == (1, 160, 441, 10, 441, 28, 2, 10)
+    p = plan(48000, 16000)
+    assert (p["ok"], p["L"], p["M"], p["nb"], p["S"], p["NK"], p["nwaves"]) == (1, 1, 3, 1, 48, 28, 8)
+    assert plan(48000, 16000, 2)["ok"] == 1 and plan(44100, 16000, 2)["ok"] == 0
+    assert plan(48000, 44100)["ok"] == 0                      # 147 block matrices: VALU kernel
+    for fi, fo in [(44100, 16000), (48000, 16000), (16000, 48000), (8000, 16000), (22050, 16000),
+                   (44100, 48000), (32000, 16000), (96000, 16000), (11025, 16000), (16000, 8000)]:
+        for ch in (1, 2):
+            p = plan(fi, fo, ch)
+            if not p["ok"]:
+                continue
+            g = gcd(fi, fo)
+            L, M = fo // g, fi // g
+            assert (p["L"], p["M"]) == (L, M)
+            assert p["nb"] == L // gcd(16, L) and p["S"] == 16 // gcd(16, L) * M
+            assert p["nwaves"] == p["nb"] * p["wpp"] <= 16
+            assert p["G"] % (2 * p["wpp"]) == 0               # chains run in pairs on every wave
+            W = 64 + max(((16 * b * M) % L + 15 * M) // L for b in range(p["nb"]))
+            assert 4 * p["NK"] >= W                           # the window fits the MFMA steps
+            qp_last = 16 * (p["nb"] - 1) * M // L
+            assert p["seg_len"] == (p["G"] - 1) * p["S"] + qp_last + 4 * p["NK"] <= min(1000, 2 * 64 * p["nwaves"])
+            assert p["seg_stride"] % 2 == 1 and p["seg_stride"] >= p["seg_len"]
+            assert p["smem"] == 16 * p["seg_stride"] * 4 <= 64 * 1024
