@@ -81,3 +81,29 @@ def gather_rows(local_rows, n_rows_per_rank: List[int]):
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded)
     return torch.cat([b[:n] for b, n in zip(bufs, n_rows_per_rank)], dim=0)
+
+
+def scatter_rows(rows_on_root, n_rows_per_rank: List[int], width: int, dtype=None, device=None, src: int = 0):
+    """Root-scatter of PCM shards: rank ``src`` holds ``[sum(n), width]``
+    rows (e.g. one clip per row), every rank receives its contiguous ``[n_rows_r, width]`` slice.
+    One padded ``dist.scatter``; the direct-load mode (every rank ingests its own shard) needs none
+    of this and is what bench.py measures."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rows_on_root
+    world, rank = dist.get_world_size(), dist.get_rank()
+    cap = max(n_rows_per_rank)
+    if rank == src:
+        dtype, device = rows_on_root.dtype, rows_on_root.device
+        chunks, pos = [], 0
+        for n in n_rows_per_rank:
+            pad = torch.zeros(cap, width, dtype=dtype, device=device)
+            pad[:n] = rows_on_root[pos:pos + n]
+            chunks.append(pad)
+            pos += n
+    else:
+        chunks = None
+    out = torch.empty(cap, width, dtype=dtype, device=device)
+    dist.scatter(out, chunks, src=src)
+    return out[: n_rows_per_rank[rank]]

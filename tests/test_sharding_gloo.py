@@ -55,12 +55,21 @@ def _worker(rank, world, port, n_clips, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from audio_flow_rs_amd.shard import gather_rows, max_over_ranks, shard_range, sum_over_ranks
+        from audio_flow_rs_amd.shard import (gather_rows, max_over_ranks, scatter_rows, shard_range,
+                                             sum_over_ranks)
         from oracle import pyoracle as po
         from util import synth_clip
         b, e = shard_range(n_clips, world, rank)
+        # root-scatter mode: rank 0 holds every clip, each rank receives its contiguous range
+        per = [shard_range(n_clips, world, r)[1] - shard_range(n_clips, world, r)[0] for r in range(world)]
+        root = (torch.from_numpy(np.stack([synth_clip(c, 3000, 2, 48000) for c in range(n_clips)]))
+                if rank == 0 else None)
+        mine = scatter_rows(root, per, 6000, dtype=torch.float32, device=torch.device("cpu"))
+        assert mine.shape == (e - b, 6000)
+        for i, c in enumerate(range(b, e)):
+            assert np.array_equal(mine[i].numpy(), synth_clip(c, 3000, 2, 48000))
         # each rank computes ITS clips only (the checker stands in for the device here)
-        rows = [po.features(synth_clip(c, 3000, 2, 48000), 2, 48000.0) for c in range(b, e)]
+        rows = [po.features(mine[i].numpy(), 2, 48000.0) for i in range(e - b)]
         local = torch.from_numpy(np.concatenate(rows) if rows else np.zeros((0, 80)))
         counts = [(shard_range(n_clips, world, r)[1] - shard_range(n_clips, world, r)[0]) * 8
                   for r in range(world)]
