@@ -471,6 +471,16 @@ af_status af_features_mel_weights(const af_features* p, float* W, size_t cap)
 
 const char* af_features_kernel_name(void) { return "af_features_kernel"; }
 
+// diagnostics, host only: the mel plan -- info[6] = {groups, K-steps, slots of wave 0..3}
+int af_features_plan_describe(const af_features* p, int32_t* info)
+{
+    if (!p || !info) return 0;
+    info[0] = p->plan.n_groups;
+    info[1] = p->plan.n_steps;
+    for (int w = 0; w < kWaves; ++w) info[2 + w] = p->plan.wave_nslots[w];
+    return 1;
+}
+
 // Diagnostics: enable == 1 allocates/zeroes the in-kernel phase stamps (subsequent runs
 // record them, slightly slower); out[32] (optional) receives [wave][phase] cycle sums.
 af_status af_features_debug_stamps(af_features* p, int enable, unsigned long long* out)

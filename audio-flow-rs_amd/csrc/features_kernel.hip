@@ -339,10 +339,11 @@ __device__ __forceinline__ void fft_phase_b(float* wbuf, int lane, float (&ur)[3
 // Steps come in slots of 8 (branch-free); when a slot ends a group, the 16 frames
 // x <=16 filters accumulator goes straight to HBM: lane (frame j, quarter kq)
 // owns filters 4kq..4kq+3 of the group = one 16-byte store.
-template <bool STAMPS>
+// MS = slots per wave compiled in (12 covers the 80-filter banks, 16 every supported one)
+template <bool STAMPS, int MS>
 __device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restrict__ lmeta,
-                                          const float (&wf)[kMaxSteps], int n_slots,
-                                          const int (&slot_end)[kMaxSlotsW],
+                                          const float (&wf)[MS * kSlotSteps], int n_slots,
+                                          const int (&slot_end)[MS],
                                           float* __restrict__ orow, bool fvalid, bool vec_ok,
                                           bool log_out, int lane, unsigned long long (&acc_t)[8],
                                           unsigned long long& t_prev)
@@ -352,13 +353,13 @@ __device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restr
     // Branch-free on purpose.  The 4 steps of a slot read consecutive bins (4 apart), so one
     // broadcast read per slot gives its first bin and the operands follow at fixed offsets
     // (padding steps read real bins of the same frame and multiply them by zero weights).
-    float b[kMaxSteps];
+    float b[MS * kSlotSteps];
     {
-        int meta[kMaxSlotsW];
+        int meta[MS];
 #pragma unroll
-        for (int q = 0; q < kMaxSlotsW; ++q) meta[q] = lmeta[q];
+        for (int q = 0; q < MS; ++q) meta[q] = lmeta[q];
 #pragma unroll
-        for (int q = 0; q < kMaxSlotsW; ++q) {
+        for (int q = 0; q < MS; ++q) {
             const float* bq = pbase + meta[q];
 #pragma unroll
             for (int i = 0; i < kSlotSteps; ++i) b[q * kSlotSteps + i] = bq[4 * i];
@@ -375,7 +376,7 @@ __device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restr
     }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < kMaxSlotsW; ++q) {
+    for (int q = 0; q < MS; ++q) {
         if (q < n_slots) {
 #pragma unroll
             for (int s = q * kSlotSteps; s < (q + 1) * kSlotSteps; s += 2) {
@@ -455,7 +456,7 @@ __device__ __forceinline__ ClipEntry load_clip_entry(const int64_t* pcm_off, con
 
 // ---------------------------------------------------------------------------
 // SEP (stereo only): no downmix, table entry e is channel e & 1 of clip e / 2
-template <int HOP_T, int CH, bool I16, bool STAMPS, bool SEP>
+template <int HOP_T, int CH, bool I16, bool STAMPS, bool SEP, int NSLOT>
 __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p)
 {
     using St = Stage<CH, I16>;
@@ -494,9 +495,9 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
     // this wave's share of the mel plan
     const float* __restrict__ wfrag_w = p.wfrag + (((size_t)w * kMaxSlotsW) * 64 + lane) * 4;
     const int n_slots_w = p.plan.wave_nslots[w];
-    int slot_end_w[kMaxSlotsW];
+    int slot_end_w[NSLOT];
 #pragma unroll
-    for (int q = 0; q < kMaxSlotsW; ++q) slot_end_w[q] = p.plan.slot_end[w][q];
+    for (int q = 0; q < NSLOT; ++q) slot_end_w[q] = p.plan.slot_end[w][q];
     const int n_mels = p.plan.n_mels;
     const bool vec_ok = (n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(p.mel) % 16 == 0);
 
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
         }
 
         AF_STAMP(1);
-        float wf[kMaxSteps];
+        float wf[NSLOT * kSlotSteps];
         {
             float ur[32], ui[32];
             fft_phase_a<HOP_T>(tile, wbufs + w * kWbuf, hop, w, lane, wtab, ttab, ur, ui);
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
                 asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
                 const float4* wp = reinterpret_cast<const float4*>(wfrag_w) + opaque_zero;
 #pragma unroll
-                for (int q4 = 0; q4 < kMaxSlotsW; q4 += 4) {
+                for (int q4 = 0; q4 < NSLOT; q4 += 4) {
                     if (q4 < n_slots_w && !p.out_power) {   // wave-uniform: skip unused slots
 #pragma unroll
                         for (int q = q4; q < q4 + 4; ++q) {
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
             const int j = lane & 15;
             float* orow = p.mel + (c_out0 + F0 + j) * n_mels;
             if (!p.out_power) {
-                mel_phase<STAMPS>(wbufs, lmeta + w * kMaxSlotsW, wf, n_slots_w, slot_end_w, orow,
+                mel_phase<STAMPS, NSLOT>(wbufs, lmeta + w * kMaxSlotsW, wf, n_slots_w, slot_end_w, orow,
                                   F0 + j < c_frames, vec_ok, p.log_mel != 0, lane, acc_t, t_prev);
             } else {
                 // power output: this wave's four rows [frame][513], consecutive lanes on
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(kThreads, 2) void af_mel_apply_kernel(const MelAppl
         if (u + gridDim.x < n_units) fetch(u + gridDim.x);
         const int j = lane & 15;
         float* orow = p.mel + (F0 + j) * n_mels;
-        mel_phase<false>(wbufs, lmeta + w * kMaxSlotsW, wf, n_slots_w, slot_end_w, orow,
+        mel_phase<false, kMaxSlotsW>(wbufs, lmeta + w * kMaxSlotsW, wf, n_slots_w, slot_end_w, orow,
                          F0 + j < p.n_frames, vec_ok, p.log_mel != 0, lane, acc_t, t_prev);
     }
 }
@@ -736,10 +737,10 @@ size_t features_smem_bytes(int hop)
                             kWaves * kMaxSlotsW);
 }
 
-template <int HOP_T, int CH, bool I16, bool STAMPS, bool SEP>
+template <int HOP_T, int CH, bool I16, bool STAMPS, bool SEP, int NSLOT>
 static af_status launch_k(const Params& p, int grid, size_t smem, hipStream_t stream)
 {
-    auto kern = af_features_kernel<HOP_T, CH, I16, STAMPS, SEP>;
+    auto kern = af_features_kernel<HOP_T, CH, I16, STAMPS, SEP, NSLOT>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -755,10 +756,17 @@ template <int HOP_T, int CH, bool I16>
 static af_status launch_one(const Params& p, int grid, size_t smem, hipStream_t stream)
 {
     if constexpr (CH == 2) {
-        if (p.separate) return launch_k<HOP_T, CH, I16, false, true>(p, grid, smem, stream);
+        if (p.separate) return launch_k<HOP_T, CH, I16, false, true, kMaxSlotsW>(p, grid, smem, stream);
     }
-    return p.stamps ? launch_k<HOP_T, CH, I16, true, false>(p, grid, smem, stream)
-                    : launch_k<HOP_T, CH, I16, false, false>(p, grid, smem, stream);
+    if (p.stamps) return launch_k<HOP_T, CH, I16, true, false, kMaxSlotsW>(p, grid, smem, stream);
+    // the common filterbanks (80 mels) need at most 12 slots on a wave: 16 fewer live registers
+    // in the FFT and 16 fewer operand registers in the mel phase
+    int most = 0;
+    for (int w = 0; w < kWaves; ++w) most = p.plan.wave_nslots[w] > most ? p.plan.wave_nslots[w] : most;
+    if constexpr (HOP_T == 256) {
+        if (most <= 12) return launch_k<HOP_T, CH, I16, false, false, 12>(p, grid, smem, stream);
+    }
+    return launch_k<HOP_T, CH, I16, false, false, kMaxSlotsW>(p, grid, smem, stream);
 }
 
 af_status launch_features(const Params& p, int channels, bool i16, int grid, size_t smem,

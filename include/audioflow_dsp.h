@@ -270,6 +270,9 @@ af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t me
 af_status af_features_mel_weights(const af_features* p, float* W, size_t cap);
 /* name and launch geometry of the fused kernel, for profiling harnesses */
 const char* af_features_kernel_name(void);
+/* diagnostics, host only: the mel plan of a handle, info[6] = {filter groups, MFMA K-steps,
+ * 4-step slots of wave 0..3} */
+int       af_features_plan_describe(const af_features* p, int32_t* info);
 /* diagnostics: enable/disable in-kernel phase stamps; out[32] (optional) receives the
  * [wave][phase] shader-cycle sums recorded since they were enabled */
 af_status af_features_debug_stamps(af_features* p, int enable, unsigned long long* out);
