@@ -32,6 +32,10 @@ class FeaturesConfig(C.Structure):
                 ("mel_norm", C.c_uint32), ("channel_mode", C.c_uint32)]
 
 
+class BatchDesc(C.Structure):
+    _fields_ = [("cfg", FeaturesConfig), ("n_clips", C.c_size_t), ("clip_offsets", C.c_void_p)]
+
+
 class StftConfig(C.Structure):
     _fields_ = [("channels", C.c_uint32), ("n_fft", C.c_uint32), ("hop", C.c_uint32),
                 ("sample_format", C.c_uint32), ("device", C.c_int32)]
@@ -142,6 +146,7 @@ SIGNATURES = {
     "af_features_set_batch_spans": (_st, [_vp, _vp, _vp, _sz, _szp]),
     "af_features_run_device": (_st, [_vp, _vp, _vp, _vp]),
     "af_features_run": (_st, [_vp, _vp, _vp, _sz]),
+    "af_pipeline_run": (_st, [C.POINTER(BatchDesc), _vp, _vp, _sz, _szp]),
     "af_features_mel_weights": (_st, [_vp, _vp, _sz]),
     "af_features_kernel_name": (C.c_char_p, []),
     "af_features_plan_describe": (C.c_int, [_vp, _vp]),

@@ -460,6 +460,20 @@ af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t me
     return AF_OK;
 }
 
+af_status af_pipeline_run(const af_batch_desc* batch, const void* pcm, float* out, size_t out_cap,
+                          size_t* total_rows_out)
+{
+    AF_REQUIRE(batch && (batch->clip_offsets || batch->n_clips == 0), "af_pipeline_run: null batch");
+    af_features* p = nullptr;
+    AF_TRY(af_features_create(&batch->cfg, &p));
+    size_t total = 0;
+    af_status st = af_features_set_batch(p, batch->clip_offsets, batch->n_clips, &total);
+    if (total_rows_out) *total_rows_out = total;
+    if (st == AF_OK && !(out == nullptr && out_cap == 0)) st = af_features_run(p, pcm, out, out_cap);
+    af_features_destroy(p);
+    return st;
+}
+
 af_status af_features_mel_weights(const af_features* p, float* W, size_t cap)
 {
     AF_REQUIRE(p && W, "af_features_mel_weights: null argument");

@@ -266,6 +266,18 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
                                  void* stream);
 /* host buffers: H2D, run, D2H, synchronise */
 af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t mel_cap);
+/* One-shot form of the above for callers without a handle (the `af_pipeline_run(batch desc,
+ * pcm, mel_out)` of SURVEY.md section 8(b)): creates the pipeline described by `cfg`, runs the
+ * batch whose clip c occupies PCM frames [clip_offsets[c], clip_offsets[c+1]) of `pcm` (host
+ * memory), writes the rows to `out` (host, row length as af_features_row_len) and frees
+ * everything again.  *total_rows_out may be queried with out == NULL and out_cap == 0. */
+typedef struct {
+    af_features_config cfg;
+    size_t n_clips;
+    const int64_t* clip_offsets;   /* n_clips + 1 monotone frame offsets */
+} af_batch_desc;
+af_status af_pipeline_run(const af_batch_desc* batch, const void* pcm, float* out, size_t out_cap,
+                          size_t* total_rows_out);
 /* the filterbank the device uses: W[n_mels][n_fft/2+1] f32 */
 af_status af_features_mel_weights(const af_features* p, float* W, size_t cap);
 /* name and launch geometry of the fused kernel, for profiling harnesses */

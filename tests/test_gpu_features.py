@@ -196,3 +196,23 @@ def test_many_ragged_clips_stress(af, po):
             continue
         ref = po.features(pcm[offs[c]:offs[c + 1]], 1, 16000.0)
         assert frame_rel_err(mel[rows[c]:rows[c + 1]], ref) < TOL
+
+
+def test_one_shot_pipeline_run(af, po):
+    # af_pipeline_run: handle-free form of create / set_batch / run / destroy
+    import ctypes as C
+    lens = [3000, 1024, 500]
+    clips = [synth_clip(600 + i, n, 2, 48000) for i, n in enumerate(lens)]
+    pcm = np.concatenate(clips)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    d = af._ffi.BatchDesc()
+    af.library().af_features_default_config(C.byref(d.cfg))
+    d.n_clips = len(lens)
+    d.clip_offsets = offs.ctypes.data
+    total = C.c_size_t()
+    assert af.library().af_pipeline_run(C.byref(d), None, None, 0, C.byref(total)) == 0
+    assert total.value == sum(po.stft_n_frames(n) for n in lens)
+    out = np.empty((total.value, 80), np.float32)
+    assert af.library().af_pipeline_run(C.byref(d), pcm.ctypes.data, out.ctypes.data, out.size, C.byref(total)) == 0
+    ref = np.concatenate([po.features(c, 2, 48000.0) for c in clips])
+    assert frame_rel_err(out, ref) < TOL
