@@ -15,9 +15,10 @@ constexpr int kFramesPerIter = 16;        // spectrogram frames per workgroup it
 constexpr int kWaves = 4;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kProw = 514;                // dwords per power row (513 + 1; == 2 mod 32)
-constexpr int kXStride = 33;              // exchange row stride (32 + 1)
-constexpr int kHalfDw = 32 * kXStride;    // exchange region of one half-wave (1056 dwords)
-constexpr int kWbuf = 2 * kHalfDw + 8;    // per-wave LDS buffer (2120 dwords; == 8 mod 32)
+constexpr int kXStride = 33;              // transpose row stride (32 + 1)
+constexpr int kPStride = 35;              // partner-exchange row stride (17 re + 17 im + 1)
+constexpr int kHalfDw = 32 * kPStride;    // exchange region of one half-wave (1120 dwords)
+constexpr int kWbuf = 2 * kHalfDw + 8;    // per-wave LDS buffer (2248 dwords; == 8 mod 32)
 constexpr int kMaxSteps = 64;             // MFMA K-steps (4 bins each) per wave
 constexpr int kWinRow = 36;               // LDS window table row: 32 values + 4 pad
 // LDS twiddle table row: 32 (cos,sin) + 2 pad.  The kernel reads a row as 8-byte pairs

@@ -291,44 +291,62 @@ __device__ __forceinline__ void fft_phase_b(float* wbuf, int lane, float (&ur)[3
     // (lane 0: k2' = (32-q)%32).  Publish k2 in {0,16..31} -> slots {0,1..16}.
     const int k1 = n2;
     const int d = (k1 == 0) ? 1 : 0;
-    float* mine = xb + k1 * kXStride;
-    const float* theirs = xb + ((32 - k1) & 31) * kXStride + d;
+    // row k1 of the exchange buffer: re of k2 in {0, 16..31} at slots 0..16, im at 17..33
+    float* mine = xb + k1 * kPStride;
+    const float* theirs = xb + ((32 - k1) & 31) * kPStride + d;
     const int first = d ? 0 : 16;                 // slot of the q = 0 partner
-    float pr[17], pi[17];
 
     mine[0] = ur[brev5(0)];
+    mine[17] = ui[brev5(0)];
 #pragma unroll
-    for (int k2 = 16; k2 < 32; ++k2) mine[k2 - 15] = ur[brev5(k2)];
+    for (int k2 = 16; k2 < 32; ++k2) {
+        mine[k2 - 15] = ur[brev5(k2)];
+        mine[k2 + 2] = ui[brev5(k2)];
+    }
     wave_sync();
-    pr[0] = xb[((32 - k1) & 31) * kXStride + first];
+    // partner values are fetched a few q at a time and turned into power right away (the
+    // power takes over the registers of Z[k]); the rows alias the exchange buffer, so they are
+    // written only after every lane of the wave has read its partners
+    float pa[17], pb[17];
+    constexpr int kChunk = 6;
 #pragma unroll
-    for (int q = 1; q <= 16; ++q) pr[q] = theirs[16 - q];
-    wave_sync();
-    mine[0] = ui[brev5(0)];
+    for (int q0 = 0; q0 <= 16; q0 += kChunk) {
+        float pr[kChunk], pi[kChunk];
 #pragma unroll
-    for (int k2 = 16; k2 < 32; ++k2) mine[k2 - 15] = ui[brev5(k2)];
-    wave_sync();
-    pi[0] = xb[((32 - k1) & 31) * kXStride + first];
+        for (int j = 0; j < kChunk; ++j) {
+            const int q = q0 + j;
+            if (q > 16) break;
+            if (q == 0) {
+                pr[j] = xb[((32 - k1) & 31) * kPStride + first];
+                pi[j] = xb[((32 - k1) & 31) * kPStride + first + 17];
+            } else {
+                pr[j] = theirs[16 - q];
+                pi[j] = theirs[16 - q + 17];
+            }
+        }
 #pragma unroll
-    for (int q = 1; q <= 16; ++q) pi[q] = theirs[16 - q];
+        for (int j = 0; j < kChunk; ++j) {
+            const int q = q0 + j;
+            if (q > 16) break;
+            const float zr = ur[brev5(q)], zi = ui[brev5(q)];
+            const float a1 = zr + pr[j], a2 = zi - pi[j];
+            const float b1 = zi + pi[j], b2 = zr - pr[j];
+            pa[q] = a1 * a1 + a2 * a2;
+            pb[q] = b1 * b1 + b2 * b2;
+        }
+    }
     wave_sync();
 
     float* prow_a = wbuf + (2 * half) * kProw + k1;
     float* prow_b = prow_a + kProw;
 #pragma unroll
-    for (int q = 0; q <= 16; ++q) {
-        const float zr = ur[brev5(q)], zi = ui[brev5(q)];
-        const float a1 = zr + pr[q], a2 = zi - pi[q];
-        const float b1 = zi + pi[q], b2 = zr - pr[q];
-        const float pa = a1 * a1 + a2 * a2;
-        const float pb = b1 * b1 + b2 * b2;
-        if (q < 16) {
-            prow_a[32 * q] = pa;
-            prow_b[32 * q] = pb;
-        } else if (k1 == 0) {                     // Nyquist bin 512
-            prow_a[512] = pa;
-            prow_b[512] = pb;
-        }
+    for (int q = 0; q < 16; ++q) {
+        prow_a[32 * q] = pa[q];
+        prow_b[32 * q] = pb[q];
+    }
+    if (k1 == 0) {                                // Nyquist bin 512
+        prow_a[512] = pa[16];
+        prow_b[512] = pb[16];
     }
 }
 
