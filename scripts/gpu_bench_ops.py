@@ -84,4 +84,17 @@ host = s[: k * 1440000].cpu().numpy()
 pipe.run(host)
 t0 = time.perf_counter(); mel = pipe.run(host); dt = time.perf_counter() - t0
 out["features_host_buffers_64clips"] = dict(ms=dt * 1e3, frames_per_s=mel.shape[0] / dt, note="H2D + kernel + D2H, pageable host memory")
+# the same with page-locked host buffers (hipHostMalloc / torch pin_memory): hipMemcpy then runs at PCIe speed
+try:
+    hp = torch.empty(host.size, dtype=torch.float32).pin_memory(); hp.numpy()[:] = host.reshape(-1)
+    mp = torch.empty(mel.shape, dtype=torch.float32).pin_memory()
+    import ctypes as _C
+    def run_pinned():
+        st = lib.af_features_run(pipe._h, _C.c_void_p(hp.data_ptr()), _C.c_void_p(mp.data_ptr()), mp.numel())
+        assert st == 0
+    run_pinned()
+    t0 = time.perf_counter(); run_pinned(); dt = time.perf_counter() - t0
+    out["features_host_buffers_64clips_pinned"] = dict(ms=dt * 1e3, frames_per_s=mel.shape[0] / dt, note="H2D + kernel + D2H, page-locked host memory")
+except Exception as e:
+    out["features_host_buffers_64clips_pinned"] = dict(ms=0.0, note="failed: %r" % (e,))
 print(json.dumps(out, indent=1))
