@@ -21,6 +21,29 @@ af_status ensure_device(int device /* -1 = current */);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Current device ordinal (0 when the runtime cannot say) and its CU count.
+inline int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev;
+}
+int device_cu_count(int device);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: `done` is the
+// caller's static per-kernel flag array, indexed by device ordinal.
+constexpr int kMaxDevices = 64;
+template <class K>
+inline hipError_t allow_big_lds(K kern, int bytes, bool (&done)[kMaxDevices])
+{
+    const int dev = current_device();
+    if (dev < kMaxDevices && done[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev < kMaxDevices) done[dev] = true;
+    return e;
+}
+
 #define AF_HIP(expr)                                                              \
     do {                                                                          \
         hipError_t _e = (expr);                                                   \

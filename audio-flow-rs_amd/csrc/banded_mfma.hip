@@ -96,6 +96,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     const int out_step = 16 * g.nb;                             // per block period
     const int out_per_tile = 256 * g.G * g.nb;
     const int col_span = g.G * g.S;
+    // seg_len may be shorter than the workgroup (short block periods, e.g. 48 k -> 45 k): lanes
+    // past the segment neither load nor store, or they would land in the neighbouring column
+    const bool first = tid < g.seg_len;
     const bool second = tid + nthreads < g.seg_len;             // this thread fills two samples per segment
     const uint32_t tpc = (uint32_t)g.tiles_per_clip, n_tiles = (uint32_t)g.n_tiles;
 
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride * CH), 0,
                                                  (int)(uint32_t)(g.x_len * 4 * CH), 0x00020000);
         const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * (4u * CH);
-        voff[0] = live ? v0 : kOob;
+        voff[0] = live && first ? v0 : kOob;
         voff[1] = live && second ? v0 + (uint32_t)nthreads * (4u * CH) : kOob;
     };
     auto issue_load = [&](int s) {                              // s = h * 16 + cc
@@ -148,8 +151,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 if constexpr (CH == 1) return pf[cc * kPfSlots + h];
                 else return (pf[(cc * kPfSlots + h) * 2] + pf[(cc * kPfSlots + h) * 2 + 1]) * 0.5f;
             };
+            if (first) {
 #pragma unroll
-            for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = staged(cc, 0);
+                for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = staged(cc, 0);
+            }
             if (second) {
 #pragma unroll
                 for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = staged(cc, 1);
@@ -334,7 +339,8 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
     g.seg_stride = p.seg_stride;
     const int wg_per_cu = (2 * 64 * p.nwaves <= 2048 && 2 * p.smem <= 150 * 1024) ? 2 : 1;
     int64_t grid = g.n_tiles;
-    if (grid > 256 * wg_per_cu) grid = 256 * wg_per_cu;
+    const int64_t n_cus = device_cu_count(current_device());
+    if (grid > n_cus * wg_per_cu) grid = n_cus * wg_per_cu;
     const unsigned block = 64u * p.nwaves;
     const bool five = wg_per_cu == 2 && 2 * p.nwaves > 16;
     switch (p.NK) {

@@ -46,6 +46,21 @@ af_status ensure_device(int device)
     return AF_OK;
 }
 
+int device_cu_count(int device)
+{
+    // queried once per device ordinal; 256 (MI355X) only if the runtime cannot say
+    static std::mutex mu;
+    static int cus[kMaxDevices] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device >= 0 && device < kMaxDevices && cus[device] > 0) return cus[device];
+    hipDeviceProp_t prop;
+    int n = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        n = prop.multiProcessorCount;
+    if (device >= 0 && device < kMaxDevices) cus[device] = n;
+    return n;
+}
+
 }  // namespace af
 
 extern "C" {

@@ -36,13 +36,62 @@ constexpr int kTwRow = 66;
 // branch-free inside a slot and the "group finished" code exists once per slot.
 constexpr int kSlotSteps = 4;
 constexpr int kMaxSlotsW = kMaxSteps / kSlotSteps;       // slots per wave
+constexpr int kPlanWaves = 8;            // the general kernel deals the groups to 4 waves, the hop-256 kernel to 8
 struct Plan {
     int n_mels, n_groups, n_steps;        // n_steps = real (unpadded) steps over all waves
-    int wave_nslots[kWaves];              // slots used by each wave
+    int n_waves;                          // waves the groups are dealt to
+    int wave_nslots[kPlanWaves];          // slots used by each wave
     // per slot: 0 = group continues; else 0x10000 | filters << 8 | first filter
     // (the group ends with this slot and its accumulator is written out)
-    int slot_end[kWaves][kMaxSlotsW];
+    int slot_end[kPlanWaves][kMaxSlotsW];
 };
+
+// ---- hop-256 kernel (features_v2.hip) ---------------------------------------------------------
+// One wave64 owns one frame pair (f, f+1) packed as one 1024-point complex FFT done as
+// 16 x 16 x 4 with 16 register-resident points per lane and two transpositions through a
+// wave-private LDS buffer; 8 waves = one 16-frame unit, two workgroups per CU = 4 waves per SIMD.
+namespace v2 {
+constexpr int kW = 8;                     // waves per workgroup
+constexpr int kT = 64 * kW;               // threads per workgroup
+constexpr int kHop = 256;
+constexpr int kTile = 15 * kHop + kNfft;  // mono samples of one unit (4864)
+constexpr int kTail = kNfft - kHop;       // samples shared with the next unit (768)
+constexpr int kWb = 1284;                 // per-wave LDS buffer in dwords (== 4 mod 32: the 16 frames x 2
+                                          // k-groups of a mel operand read fall into 32 different banks)
+constexpr int kT1Row = 66;                // first transposition: row k1 = 64 columns + 2 (bank-conflict-free
+                                          // column reads by lanes (k1, c): 2 k1 + c)
+constexpr int kT2Plane = 80;              // second transposition: plane b = 64 columns + 16
+constexpr int kWinRow2 = 20;              // window table row (lane n2): 16 values + 4 pad
+constexpr int kTw1Row = 36;               // twiddle table row (lane n2): 16 (cos, sin) + 4 pad
+constexpr int kTw2Row = 36;               // second twiddle table row (c = 0..3): 16 (cos, sin) + 4 pad
+constexpr int kTabFloats = 64 * kWinRow2 + 64 * kTw1Row + 4 * kTw2Row;
+constexpr int kLdsFloats = kW * kWb + kTile + kTabFloats + kW * kMaxSlotsW;
+
+// One 16-frame unit, 32 bytes, read with one scalar load.
+struct UnitDesc {
+    int64_t pcm0;        // first PCM frame of the unit's signal tile (frames from the buffer start)
+    int64_t out0;        // first output row
+    int32_t n_avail;     // PCM frames from pcm0 to the end of the clip (clamped to 2^30)
+    int32_t n_rows;      // valid output rows (1..16)
+    int32_t flags;       // bit 0: the next unit continues this clip (its tile = this one shifted by 16 hops)
+    int32_t sel;         // -1: downmix; 0 / 1: that channel alone (AF_CH_SEPARATE)
+};
+
+struct Params {
+    const void* pcm;
+    float* out;               // mel rows [total_frames][n_mels] or power rows [total_frames][513]
+    const float* tabs;        // wintab [64][kWinRow2] | tw1 [64][kTw1Row] | tw2 [4][kTw2Row]
+    const float* wfrag;       // [8][kMaxSlotsW][64][4]
+    const int* meta;          // [8][kMaxSlotsW]
+    const UnitDesc* units;
+    Plan plan;
+    int64_t total_units;
+    int out_power, log_mel;
+    unsigned long long* stamps;   // diagnostics only: [4 waves][8] summed phase cycles, or null
+};
+
+af_status launch(const Params& p, int channels, bool i16, bool separate, int grid, hipStream_t stream);
+}  // namespace v2
 
 struct Params {
     const void* pcm;          // interleaved PCM (f32 or i16)

@@ -18,12 +18,18 @@ struct af_features {
     int device = 0;
     int n_cus = 256;
     std::vector<float> W;            // [n_mels][513] f32, as used on the device
-    Plan plan{};
-    DevBuf d_const;                  // wintab | twtab | wfrag | plan
+    Plan plan{};                     // groups dealt to the 4 waves of the general kernel
+    Plan plan8{};                    // ... and to the 8 waves of the hop-256 kernel (n_waves == 0: not usable)
+    DevBuf d_const;                  // wintab | twtab | wfrag | meta | v2 tables | wfrag8 | meta8
     const float* d_wintab = nullptr;
     const float* d_twtab = nullptr;
     const float* d_wfrag = nullptr;
     const int* d_meta = nullptr;
+    const float* d_tabs2 = nullptr;
+    const float* d_wfrag8 = nullptr;
+    const int* d_meta8 = nullptr;
+    DevBuf d_units;                  // v2::UnitDesc per 16-frame unit (hop 256 only)
+    bool units_ok = false;
     // batch description
     DevBuf d_tables;                 // start[n] | len[n] | out_off[n+1] | unit_off[n+1]
     size_t n_clips = 0;
@@ -91,12 +97,17 @@ int flush_cost()
     return 8;
 }
 
-af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
+af_status build_plan(const std::vector<float>& W, int n_mels, int kWaves, int max_slots, int uf, Plan& plan,
                      std::vector<float>& wfrag, std::vector<int>& meta)
 {
     std::memset(&plan, 0, sizeof(plan));
     plan.n_mels = n_mels;
-    const int U = (n_mels + 3) / 4;                      // units of 4 filters
+    plan.n_waves = kWaves;
+    const int kMaxStepsW = max_slots * kSlotSteps;
+    // uf = filters per unit (4: every group ends in whole float4 stores; 2: finer cuts, the groups
+    // that are not multiples of 4 filters are stored as single floats)
+    const int U = (n_mels + uf - 1) / uf;
+    const int gmax = 16 / uf;                            // units per group (one 16-row MFMA tile)
     // band of each filter
     std::vector<int> lo(n_mels, kBins), hi(n_mels, -1);
     for (int m = 0; m < n_mels; ++m)
@@ -107,7 +118,7 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
             }
     auto band = [&](int u0, int u1, int& b0, int& steps) {  // units [u0, u1)
         int l = kBins, h = -1;
-        for (int m = 4 * u0; m < 4 * u1 && m < n_mels; ++m)
+        for (int m = uf * u0; m < uf * u1 && m < n_mels; ++m)
             if (hi[m] >= 0) { l = std::min(l, lo[m]); h = std::max(h, hi[m]); }
         if (h < l) { l = 0; h = 0; }                        // all-zero group: one harmless step
         steps = (h - l + 1 + 3) / 4;
@@ -122,17 +133,21 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
     // (up to 16-byte) stores of 16 frames, measured at about kFlushCost MFMA steps.
     const int kFlushCost = flush_cost();
     // g[i][j]: cheapest cover of units [i, j) with groups of <= 4 units (steps + flushes)
-    std::vector<std::vector<int>> g(U + 1, std::vector<int>(U + 1, INF)), gcut = g;
-    for (int i = 0; i <= U; ++i) g[i][i] = 0;
+    // gs[i][j]: the padded K-steps of that cover (a wave has room for kMaxStepsW of them)
+    std::vector<std::vector<int>> g(U + 1, std::vector<int>(U + 1, INF)), gcut = g, gs = g;
+    for (int i = 0; i <= U; ++i) g[i][i] = gs[i][i] = 0;
     for (int len = 1; len <= U; ++len)
         for (int i = 0; i + len <= U; ++i) {
             const int j = i + len;
-            for (int k = std::max(i, j - 4); k < j; ++k) {  // last group = units [k, j)
+            for (int k = std::max(i, j - gmax); k < j; ++k) {  // last group = units [k, j)
                 int b0, st;
                 band(k, j, b0, st);
                 st = (st + kSlotSteps - 1) / kSlotSteps * kSlotSteps;   // groups occupy whole slots
-                st += kFlushCost;
-                if (g[i][k] + st < g[i][j]) { g[i][j] = g[i][k] + st; gcut[i][j] = k; }
+                if (g[i][k] + st + kFlushCost < g[i][j]) {
+                    g[i][j] = g[i][k] + st + kFlushCost;
+                    gs[i][j] = gs[i][k] + st;
+                    gcut[i][j] = k;
+                }
             }
         }
     // f[w][j]: (max wave load, total) for the first w waves covering units [0, j)
@@ -144,15 +159,17 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
     for (int w = 1; w <= kWaves; ++w)
         for (int j = 0; j <= U; ++j)
             for (int i = 0; i <= j; ++i) {
-                if (f[w - 1][i].mx >= INF) continue;
+                if (f[w - 1][i].mx >= INF || gs[i][j] > kMaxStepsW) continue;
                 const Cost c{std::max(f[w - 1][i].mx, g[i][j]), f[w - 1][i].tot + g[i][j]};
                 if (better(c, f[w][j])) { f[w][j] = c; fcut[w][j] = i; }
             }
-    int wave_lo[kWaves + 1];
+    if (f[kWaves][U].mx >= INF)
+        return fail(AF_ERR_UNSUPPORTED, "mel plan does not fit %d waves x %d K-steps", kWaves, kMaxStepsW);
+    int wave_lo[kPlanWaves + 1];
     wave_lo[kWaves] = U;
     for (int w = kWaves; w >= 1; --w) wave_lo[w - 1] = fcut[w][wave_lo[w]];
 
-    wfrag.assign((size_t)kWaves * kMaxSteps * 64, 0.0f);
+    wfrag.assign((size_t)kWaves * kMaxSteps * 64, 0.0f);      // [wave][kMaxSlotsW][64][4]
     meta.assign((size_t)kWaves * kMaxSlotsW, 0);
     for (int w = 0; w < kWaves; ++w) {
         // groups of this wave, recovered from gcut
@@ -168,15 +185,15 @@ af_status build_plan(const std::vector<float>& W, int n_mels, Plan& plan,
             band(gr.first, gr.second, b0, st);
             need += (st + kSlotSteps - 1) / kSlotSteps * kSlotSteps;
         }
-        if (need > kMaxSteps)
+        if (need > kMaxStepsW)
             return fail(AF_ERR_UNSUPPORTED, "mel plan needs %d K-steps on one wave (limit %d)", need,
-                        kMaxSteps);
+                        kMaxStepsW);
         int s = 0;
         for (auto it = groups.rbegin(); it != groups.rend(); ++it) {
             int b0, st;
             band(it->first, it->second, b0, st);
-            const int m0 = 4 * it->first;
-            const int cnt = std::min(4 * it->second, n_mels) - m0;
+            const int m0 = uf * it->first;
+            const int cnt = std::min(uf * it->second, n_mels) - m0;
             const int padded = (st + kSlotSteps - 1) / kSlotSteps * kSlotSteps;
             for (int i = 0; i < padded; ++i, ++s) {
                 const int bin = b0 + 4 * i;
@@ -244,6 +261,31 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     p->offsets_aligned = aligned;
     AF_TRY(p->d_tables.reserve((tab.size() ? tab.size() : 1) * sizeof(int64_t)));
     AF_HIP(hipMemcpy(p->d_tables.p, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    // hop-256 kernel: one 32-byte record per 16-frame unit
+    p->units_ok = false;
+    if (p->plan8.n_waves == v2::kW && aligned && p->total_units > 0 && p->total_units < (1ll << 26)) {
+        std::vector<v2::UnitDesc> units((size_t)p->total_units);
+        const bool sep = p->cfg.channel_mode == AF_CH_SEPARATE;
+        size_t k = 0;
+        for (size_t c = 0; c < n; ++c) {
+            const int64_t nf = out_off[c + 1] - out_off[c];
+            const int64_t nu = unit_off[c + 1] - unit_off[c];
+            for (int64_t i = 0; i < nu; ++i, ++k) {
+                v2::UnitDesc& d = units[k];
+                const int64_t first = i * kFramesPerIter * (int64_t)v2::kHop;
+                d.pcm0 = t_start[c] + first;
+                d.out0 = out_off[c] + i * kFramesPerIter;
+                const int64_t left = t_len[c] - first;
+                d.n_avail = (int32_t)std::min<int64_t>(left, (int64_t)1 << 30);
+                d.n_rows = (int32_t)std::min<int64_t>(nf - i * kFramesPerIter, kFramesPerIter);
+                d.flags = i + 1 < nu ? 1 : 0;
+                d.sel = sep ? (int32_t)(c & 1) : -1;
+            }
+        }
+        AF_TRY(p->d_units.reserve(units.size() * sizeof(v2::UnitDesc)));
+        AF_HIP(hipMemcpy(p->d_units.p, units.data(), units.size() * sizeof(v2::UnitDesc), hipMemcpyHostToDevice));
+        p->units_ok = true;
+    }
     return AF_OK;
 }
 
@@ -297,14 +339,27 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     if (!p) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
     p->cfg = *cfg;
     if (hipGetDevice(&p->device) != hipSuccess) p->device = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->n_cus = prop.multiProcessorCount;
+    p->n_cus = device_cu_count(p->device);
 
     build_mel(*cfg, f_max, p->W);
     std::vector<float> wfrag;
     std::vector<int> meta;
-    af_status st = build_plan(p->W, (int)cfg->n_mels, p->plan, wfrag, meta);
+    af_status st = build_plan(p->W, (int)cfg->n_mels, kWaves, kMaxSlotsW, 4, p->plan, wfrag, meta);
     if (st != AF_OK) { delete p; return st; }
+    // hop-256 kernel: the same groups dealt to 8 waves, at most 8 slots each; a filterbank that
+    // does not fit leaves plan8.n_waves == 0 and the general kernel serves hop 256 as well
+    std::vector<float> wfrag8;
+    std::vector<int> meta8;
+    if (cfg->hop == (uint32_t)v2::kHop) {
+        // 6 slots per wave where the filterbank allows it (the instance with the smaller register budget)
+        if (build_plan(p->W, (int)cfg->n_mels, v2::kW, 6, 2, p->plan8, wfrag8, meta8) != AF_OK &&
+            build_plan(p->W, (int)cfg->n_mels, v2::kW, 8, 2, p->plan8, wfrag8, meta8) != AF_OK) {
+            std::memset(&p->plan8, 0, sizeof(p->plan8));
+            wfrag8.clear();
+            meta8.clear();
+            last_error_slot().clear();
+        }
+    }
 
     // constant block: wintab [32][kWinRow] | twtab [32][kTwRow] | wfrag | meta
     // (the two tables are copied verbatim into LDS by every workgroup; rows are
@@ -323,11 +378,42 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
             twtab[n2 * kTwRow + 2 * k1] = (float)std::cos(a);
             twtab[n2 * kTwRow + 2 * k1 + 1] = (float)std::sin(a);
         }
+    // hop-256 kernel tables: window [64][kWinRow2] (lane n2, n1 = 0..15: 0.5 hann[64 n1 + n2]),
+    // twiddles [64][kTw1Row] (lane n2: (cos, sin)(2 pi n2 k1 / 1024), k1 = 0..15) and
+    // [4][kTw2Row] (c: (cos, sin)(2 pi c b / 64), b = 0..15)
+    std::vector<float> tabs2(v2::kTabFloats, 0.0f);
+    {
+        float* win2 = tabs2.data();
+        float* tw1 = win2 + 64 * v2::kWinRow2;
+        float* tw2 = tw1 + 64 * v2::kTw1Row;
+        for (int n2 = 0; n2 < 64; ++n2)
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int i = 64 * n1 + n2;
+                const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)kNfft);
+                win2[n2 * v2::kWinRow2 + n1] = 0.5f * (float)w;
+                const double a = 2.0 * kPi * (double)(n1 * n2) / (double)kNfft;   // n1 plays k1
+                tw1[n2 * v2::kTw1Row + 2 * n1] = (float)std::cos(a);
+                tw1[n2 * v2::kTw1Row + 2 * n1 + 1] = (float)std::sin(a);
+            }
+        for (int c = 0; c < 4; ++c)
+            for (int b = 0; b < 16; ++b) {
+                const double a = 2.0 * kPi * (double)(c * b) / 64.0;
+                tw2[c * v2::kTw2Row + 2 * b] = (float)std::cos(a);
+                tw2[c * v2::kTw2Row + 2 * b + 1] = (float)std::sin(a);
+            }
+    }
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t off_tw = wintab.size() * sizeof(float);
     const size_t off_wf = off_tw + twtab.size() * sizeof(float);
-    const size_t off_meta = (off_wf + wfrag.size() * sizeof(float) + 15) & ~(size_t)15;
-    const size_t total = off_meta + meta.size() * sizeof(int);
+    const size_t off_meta = up16(off_wf + wfrag.size() * sizeof(float));
+    const size_t off_tabs2 = up16(off_meta + meta.size() * sizeof(int));
+    const size_t off_wf8 = up16(off_tabs2 + tabs2.size() * sizeof(float));
+    const size_t off_meta8 = up16(off_wf8 + wfrag8.size() * sizeof(float));
+    const size_t total = off_meta8 + meta8.size() * sizeof(int);
     std::vector<char> blob(total, 0);
+    std::memcpy(blob.data() + off_tabs2, tabs2.data(), tabs2.size() * sizeof(float));
+    if (!wfrag8.empty()) std::memcpy(blob.data() + off_wf8, wfrag8.data(), wfrag8.size() * sizeof(float));
+    if (!meta8.empty()) std::memcpy(blob.data() + off_meta8, meta8.data(), meta8.size() * sizeof(int));
     std::memcpy(blob.data(), wintab.data(), off_tw);
     std::memcpy(blob.data() + off_tw, twtab.data(), twtab.size() * sizeof(float));
     std::memcpy(blob.data() + off_wf, wfrag.data(), wfrag.size() * sizeof(float));
@@ -341,6 +427,9 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     p->d_twtab = reinterpret_cast<const float*>(base + off_tw);
     p->d_wfrag = reinterpret_cast<const float*>(base + off_wf);
     p->d_meta = reinterpret_cast<const int*>(base + off_meta);
+    p->d_tabs2 = reinterpret_cast<const float*>(base + off_tabs2);
+    p->d_wfrag8 = reinterpret_cast<const float*>(base + off_wf8);
+    p->d_meta8 = reinterpret_cast<const int*>(base + off_meta8);
     *out = p;
     return AF_OK;
 }
@@ -427,6 +516,29 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     prm.log_mel = (int)p->cfg.log_mel;
     prm.separate = p->cfg.channel_mode == AF_CH_SEPARATE;
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
+    if (p->units_ok && prm.aligned16 && !std::getenv("AF_FEATURES_GENERAL")) {
+        // hop 256, 16-byte aligned clips: the 8-wave kernel, two workgroups per CU
+        v2::Params q{};
+        q.pcm = pcm_dev;
+        q.out = mel_dev;
+        q.tabs = p->d_tabs2;
+        q.wfrag = p->d_wfrag8;
+        q.meta = p->d_meta8;
+        q.units = p->d_units.as<v2::UnitDesc>();
+        q.plan = p->plan8;
+        q.total_units = p->total_units;
+        q.out_power = prm.out_power;
+        q.log_mel = prm.log_mel;
+        q.stamps = prm.stamps;
+        int64_t grid2 = (int64_t)p->n_cus * 2;
+        if (const char* e = std::getenv("AF_FEATURES_WG_PER_CU")) {   // diagnostics only
+            const int v = std::atoi(e);
+            if (v >= 1 && v <= 2) grid2 = (int64_t)p->n_cus * v;
+        }
+        if (grid2 > p->total_units) grid2 = p->total_units;
+        return v2::launch(q, (int)p->cfg.channels, p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
+                          (int)grid2, as_stream(stream));
+    }
     const size_t smem = features_smem_bytes(prm.hop);
     AF_REQUIRE(smem <= 160 * 1024, "hop %d needs %zu bytes of LDS", prm.hop, smem);
     // persistent grid: as many workgroups as stay resident (LDS-limited, at most 2 per CU)
@@ -485,13 +597,18 @@ af_status af_features_mel_weights(const af_features* p, float* W, size_t cap)
 
 const char* af_features_kernel_name(void) { return "af_features_kernel"; }
 
-// diagnostics, host only: the mel plan -- info[6] = {groups, K-steps, slots of wave 0..3}
+// diagnostics, host only: the mel plans -- info[17] = {groups, K-steps, slots of wave 0..3} of the
+// general kernel, then {waves (0: not in use), groups, K-steps, slots of wave 0..7} of the hop-256 kernel
 int af_features_plan_describe(const af_features* p, int32_t* info)
 {
     if (!p || !info) return 0;
     info[0] = p->plan.n_groups;
     info[1] = p->plan.n_steps;
     for (int w = 0; w < kWaves; ++w) info[2 + w] = p->plan.wave_nslots[w];
+    info[6] = p->plan8.n_waves;
+    info[7] = p->plan8.n_groups;
+    info[8] = p->plan8.n_steps;
+    for (int w = 0; w < v2::kW; ++w) info[9 + w] = p->plan8.wave_nslots[w];
     return 1;
 }
 

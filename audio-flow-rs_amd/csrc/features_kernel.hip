@@ -26,175 +26,11 @@
 //     of mel values straight to HBM and nothing is reduced across waves.
 //   * other outputs of the same kernel (Params flags / template SEP): the power rows
 //     themselves (AF_OUT_POWER), log10 of the mel values, one spectrogram per channel.
-#include "features.hpp"
+#include "features_dev.hpp"
+#include "fft_regs.hpp"
 
 namespace af {
 namespace feat {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ constexpr int brev5(int x)
-{
-    return ((x & 1) << 4) | ((x & 2) << 2) | (x & 4) | ((x & 8) >> 2) | ((x & 16) >> 4);
-}
-
-// cos / sin (2 pi j / 32), j = 0..15
-__device__ static constexpr float kC32[16] = {
-    1.0f, 0.980785251f, 0.923879504f, 0.831469595f, 0.707106769f, 0.555570245f,
-    0.382683426f, 0.195090324f, 0.0f, -0.195090324f, -0.382683426f, -0.555570245f,
-    -0.707106769f, -0.831469595f, -0.923879504f, -0.980785251f};
-__device__ static constexpr float kS32[16] = {
-    0.0f, 0.195090324f, 0.382683426f, 0.555570245f, 0.707106769f, 0.831469595f,
-    0.923879504f, 0.980785251f, 1.0f, 0.980785251f, 0.923879504f, 0.831469595f,
-    0.707106769f, 0.555570245f, 0.382683426f, 0.195090324f};
-
-// One decimation-in-frequency stage over 32 register-resident complex points.
-// Everything is compile-time indexed after unrolling.
-template <int SPAN>
-__device__ __forceinline__ void dif_stage(float (&re)[32], float (&im)[32])
-{
-#pragma unroll
-    for (int g = 0; g < 32; g += 2 * SPAN) {
-#pragma unroll
-        for (int j = 0; j < SPAN; ++j) {
-            const int a = g + j, b = a + SPAN;
-            const int t = j * (16 / SPAN);        // twiddle e^{-2 pi i t / 32}
-            const float ar = re[a], ai = im[a], br = re[b], bi = im[b];
-            re[a] = ar + br;
-            im[a] = ai + bi;
-            const float dr = ar - br, di = ai - bi;
-            if (t == 0) {
-                re[b] = dr;
-                im[b] = di;
-            } else if (t == 8) {                  // * (-i)
-                re[b] = di;
-                im[b] = -dr;
-            } else if (t == 4) {                  // * (1 - i)/sqrt2
-                re[b] = (dr + di) * 0.707106769f;
-                im[b] = (di - dr) * 0.707106769f;
-            } else if (t == 12) {                 // * (-1 - i)/sqrt2
-                re[b] = (di - dr) * 0.707106769f;
-                im[b] = (-dr - di) * 0.707106769f;
-            } else {                              // (dr + i di)(c - i s)
-                const float c = kC32[t], s = kS32[t];
-                re[b] = dr * c + di * s;
-                im[b] = di * c - dr * s;
-            }
-        }
-    }
-}
-
-// 32-point DFT in registers; output X[k] lands in element brev5(k).
-__device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32])
-{
-    dif_stage<16>(re, im);
-    dif_stage<8>(re, im);
-    dif_stage<4>(re, im);
-    dif_stage<2>(re, im);
-    dif_stage<1>(re, im);
-}
-
-// LDS traffic inside one wave needs no s_barrier (a wave's DS operations are
-// executed in order); this only stops the compiler from moving LDS accesses
-// across the hand-off.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ---------------------------------------------------------------------------
-// PCM staging: one 16-byte unit of interleaved PCM -> MS mono samples.
-// to_mono semantics (capture.rs:34-40): sequential f32 sum over the channels,
-// then divided by the channel count (x0.5 is exact for stereo).
-// i16 samples are scaled by 1/32768 (docs/OPS.md "PCM formats").
-template <int CH, bool I16>
-struct Stage {
-    static constexpr int kBytesPerFrame = CH * (I16 ? 2 : 4);
-    static constexpr int MS = 16 / kBytesPerFrame;   // mono samples per 16-B unit
-
-    __device__ static __forceinline__ float sample(const void* pcm, int64_t elem)
-    {
-        if (I16) return (float)static_cast<const int16_t*>(pcm)[elem] * (1.0f / 32768.0f);
-        return static_cast<const float*>(pcm)[elem];
-    }
-
-    // the 16 raw bytes holding mono samples [pos, pos+MS) of a clip whose first
-    // frame is `base` and which has `n` frames; zero beyond the end of the clip.
-    // No arithmetic here, so a prefetch does not have to wait for its data.
-    __device__ static __forceinline__ uint4 load_raw(const void* pcm, int64_t base, int64_t pos,
-                                                     int64_t n, bool aligned)
-    {
-        if (aligned && pos + MS <= n)
-            return *reinterpret_cast<const uint4*>(static_cast<const char*>(pcm) +
-                                                   (base + pos) * kBytesPerFrame);
-        uint32_t r[4] = {0u, 0u, 0u, 0u};
-        constexpr int E = I16 ? 8 : 4;                 // elements in 16 bytes
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (pos + e / CH < n) {
-                const int64_t idx = (base + pos) * CH + e;
-                if constexpr (I16)
-                    r[e >> 1] |= (uint32_t)static_cast<const uint16_t*>(pcm)[idx] << (16 * (e & 1));
-                else
-                    r[e] = static_cast<const uint32_t*>(pcm)[idx];
-            }
-        }
-        return uint4{r[0], r[1], r[2], r[3]};
-    }
-
-    // raw bytes -> mono samples.  sel < 0: to_mono downmix; sel = 0 / 1 (stereo only): that
-    // channel alone ("separate channels" mode, wave-uniform).
-    __device__ static __forceinline__ void convert(const uint4 raw, float (&m)[MS], int sel)
-    {
-        const uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
-        if constexpr (!I16) {
-            float f[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(r[i]);
-            if constexpr (CH == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) m[i] = f[i];
-            } else if (sel < 0) {
-                m[0] = (f[0] + f[1]) * 0.5f;
-                m[1] = (f[2] + f[3]) * 0.5f;
-            } else {
-                m[0] = sel ? f[1] : f[0];
-                m[1] = sel ? f[3] : f[2];
-            }
-        } else {
-            float f[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f[2 * i] = (float)(int16_t)(r[i] & 0xffffu) * (1.0f / 32768.0f);
-                f[2 * i + 1] = (float)(int16_t)(r[i] >> 16) * (1.0f / 32768.0f);
-            }
-            if constexpr (CH == 1) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) m[i] = f[i];
-            } else if (sel < 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) m[i] = (f[2 * i] + f[2 * i + 1]) * 0.5f;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) m[i] = sel ? f[2 * i + 1] : f[2 * i];
-            }
-        }
-    }
-
-    __device__ static __forceinline__ void load(const void* pcm, int64_t base, int64_t pos,
-                                                int64_t n, bool aligned, float (&m)[MS], int sel)
-    {
-        convert(load_raw(pcm, base, pos, n, aligned), m, sel);
-    }
-
-    __device__ static __forceinline__ void store(float* dst, const float (&m)[MS])
-    {
-#pragma unroll
-        for (int i = 0; i < MS; ++i) dst[i] = m[i];
-    }
-};
 
 // ---------------------------------------------------------------------------
 // FFT phase of one wave: 4 frames (two per half-wave) -> 4 power rows in LDS.
@@ -226,20 +62,28 @@ __device__ __forceinline__ void fft_phase_a(const float* __restrict__ tile, floa
 #pragma unroll
             for (int j = 0; j < 32 + SH; ++j) s[j] = src[32 * j];
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) {
-                re[n1] = s[n1] * win[n1];
-                im[n1] = s[n1 + SH] * win[n1];
+            for (int e = 0; e < 32; e += 2) {      // window fused into the twiddle-free first stage
+                const int na = brev5(e), nb = na + 16;
+                const float mr = s[nb] * win[nb], mi = s[nb + SH] * win[nb];
+                re[e] = __builtin_fmaf(s[na], win[na], mr);
+                re[e + 1] = __builtin_fmaf(s[na], win[na], -mr);
+                im[e] = __builtin_fmaf(s[na + SH], win[na], mi);
+                im[e + 1] = __builtin_fmaf(s[na + SH], win[na], -mi);
             }
         } else {
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) {
-                re[n1] = src[32 * n1] * win[n1];
-                im[n1] = src[hop + 32 * n1] * win[n1];
+            for (int e = 0; e < 32; e += 2) {
+                const int na = brev5(e), nb = na + 16;
+                const float mr = src[32 * nb] * win[nb], mi = src[hop + 32 * nb] * win[nb];
+                re[e] = __builtin_fmaf(src[32 * na], win[na], mr);
+                re[e + 1] = __builtin_fmaf(src[32 * na], win[na], -mr);
+                im[e] = __builtin_fmaf(src[hop + 32 * na], win[na], mi);
+                im[e + 1] = __builtin_fmaf(src[hop + 32 * na], win[na], -mi);
             }
         }
     }
 
-    fft32(re, im);                                // over n1 -> Y[k1] at brev5(k1)
+    fftr::dit_fft<32, 2>(re, im);                 // over n1 (bit-reversed on entry) -> Y[k1] at k1
 
     // inter-stage twiddle e^{-2 pi i n2 k1 / 1024}; row n2 of the LDS table holds
     // (cos, sin) for k1 = 0..31, read as 8-byte pairs
@@ -249,13 +93,13 @@ __device__ __forceinline__ void fft_phase_a(const float* __restrict__ tile, floa
         for (int j = 0; j < 16; ++j) {
             if (j > 0) {
                 const float2 t = trow[2 * j];
-                const int r = brev5(2 * j);
+                const int r = 2 * j;
                 const float xr = re[r], xi = im[r];
                 re[r] = xr * t.x + xi * t.y;
                 im[r] = xi * t.x - xr * t.y;
             }
             const float2 t = trow[2 * j + 1];
-            const int r = brev5(2 * j + 1);
+            const int r = 2 * j + 1;
             const float xr = re[r], xi = im[r];
             re[r] = xr * t.x + xi * t.y;
             im[r] = xi * t.x - xr * t.y;
@@ -265,16 +109,16 @@ __device__ __forceinline__ void fft_phase_a(const float* __restrict__ tile, floa
     // transpose (k1, n2) through LDS, real parts then imaginary parts
     float* xb = wbuf + half * kHalfDw;
 #pragma unroll
-    for (int k1 = 0; k1 < 32; ++k1) xb[k1 * kXStride + n2] = re[brev5(k1)];
+    for (int k1 = 0; k1 < 32; ++k1) xb[k1 * kXStride + n2] = re[k1];
     wave_sync();
 #pragma unroll
-    for (int n = 0; n < 32; ++n) ur[n] = xb[n2 * kXStride + n];
+    for (int n = 0; n < 32; ++n) ur[brev5(n)] = xb[n2 * kXStride + n];
     wave_sync();
 #pragma unroll
-    for (int k1 = 0; k1 < 32; ++k1) xb[k1 * kXStride + n2] = im[brev5(k1)];
+    for (int k1 = 0; k1 < 32; ++k1) xb[k1 * kXStride + n2] = im[k1];
     wave_sync();
 #pragma unroll
-    for (int n = 0; n < 32; ++n) ui[n] = xb[n2 * kXStride + n];
+    for (int n = 0; n < 32; ++n) ui[brev5(n)] = xb[n2 * kXStride + n];
     wave_sync();
 
 }
@@ -283,7 +127,7 @@ __device__ __forceinline__ void fft_phase_b(float* wbuf, int lane, float (&ur)[3
 {
     const int half = lane >> 5, n2 = lane & 31;
     float* xb = wbuf + half * kHalfDw;
-    fft32(ur, ui);                                // over n2 -> Z[k1 + 32 k2] at brev5(k2)
+    fftr::dit_fft<32>(ur, ui);                    // over n2 -> Z[k1 + 32 k2] at k2
 
     // Split the packed spectrum: A[k] = (Z[k] + conj Z[N-k])/2 (frame a),
     // B[k] = (Z[k] - conj Z[N-k])/(2i) (frame b); the 1/2 is folded into the
@@ -296,12 +140,12 @@ __device__ __forceinline__ void fft_phase_b(float* wbuf, int lane, float (&ur)[3
     const float* theirs = xb + ((32 - k1) & 31) * kPStride + d;
     const int first = d ? 0 : 16;                 // slot of the q = 0 partner
 
-    mine[0] = ur[brev5(0)];
-    mine[17] = ui[brev5(0)];
+    mine[0] = ur[0];
+    mine[17] = ui[0];
 #pragma unroll
     for (int k2 = 16; k2 < 32; ++k2) {
-        mine[k2 - 15] = ur[brev5(k2)];
-        mine[k2 + 2] = ui[brev5(k2)];
+        mine[k2 - 15] = ur[k2];
+        mine[k2 + 2] = ui[k2];
     }
     wave_sync();
     // partner values are fetched a few q at a time and turned into power right away (the
@@ -328,7 +172,7 @@ __device__ __forceinline__ void fft_phase_b(float* wbuf, int lane, float (&ur)[3
         for (int j = 0; j < kChunk; ++j) {
             const int q = q0 + j;
             if (q > 16) break;
-            const float zr = ur[brev5(q)], zi = ui[brev5(q)];
+            const float zr = ur[q], zi = ui[q];
             const float a1 = zr + pr[j], a2 = zi - pi[j];
             const float b1 = zi + pi[j], b2 = zr - pr[j];
             pa[q] = a1 * a1 + a2 * a2;
@@ -347,83 +191,6 @@ __device__ __forceinline__ void fft_phase_b(float* wbuf, int lane, float (&ur)[3
     if (k1 == 0) {                                // Nyquist bin 512
         prow_a[512] = pa[16];
         prow_b[512] = pb[16];
-    }
-}
-
-// ---------------------------------------------------------------------------
-// mel phase: this wave's filter groups, banded W (A operand, in registers) times
-// P^T (B operand, bins x 16 frames from LDS) on v_mfma_f32_16x16x4_f32.  All B
-// operands of the unit are fetched up front so the MFMA chain never waits on LDS.
-// Steps come in slots of 8 (branch-free); when a slot ends a group, the 16 frames
-// x <=16 filters accumulator goes straight to HBM: lane (frame j, quarter kq)
-// owns filters 4kq..4kq+3 of the group = one 16-byte store.
-// MS = slots per wave compiled in (12 covers the 80-filter banks, 16 every supported one)
-template <bool STAMPS, int MS>
-__device__ __forceinline__ void mel_phase(const float* wbufs, const int* __restrict__ lmeta,
-                                          const float (&wf)[MS * kSlotSteps], int n_slots,
-                                          const int (&slot_end)[MS],
-                                          float* __restrict__ orow, bool fvalid, bool vec_ok,
-                                          bool log_out, int lane, unsigned long long (&acc_t)[8],
-                                          unsigned long long& t_prev)
-{
-    const int f = lane & 15, kq = lane >> 4;
-    const float* pbase = wbufs + (f >> 2) * kWbuf + (f & 3) * kProw + kq;
-    // Branch-free on purpose.  The 4 steps of a slot read consecutive bins (4 apart), so one
-    // broadcast read per slot gives its first bin and the operands follow at fixed offsets
-    // (padding steps read real bins of the same frame and multiply them by zero weights).
-    float b[MS * kSlotSteps];
-    {
-        int meta[MS];
-#pragma unroll
-        for (int q = 0; q < MS; ++q) meta[q] = lmeta[q];
-#pragma unroll
-        for (int q = 0; q < MS; ++q) {
-            const float* bq = pbase + meta[q];
-#pragma unroll
-            for (int i = 0; i < kSlotSteps; ++i) b[q * kSlotSteps + i] = bq[4 * i];
-        }
-    }
-    if constexpr (STAMPS) {                       // diagnostics: operands landed
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        acc_t[5] += t - t_prev;
-        t_prev = t;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < MS; ++q) {
-        if (q < n_slots) {
-#pragma unroll
-            for (int s = q * kSlotSteps; s < (q + 1) * kSlotSteps; s += 2) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], b[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s + 1], b[s + 1], acc1, 0, 0, 0);
-            }
-            const int e = slot_end[q];            // wave-uniform (kernarg)
-            if (e != 0) {
-                f32x4 r = acc0 + acc1;
-                if (log_out) {                    // wave-uniform: log10(max(mel, 1e-10))
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] = __log10f(fmaxf(r[i], 1e-10f));
-                }
-                acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int m0 = e & 255, cnt = (e >> 8) & 31;
-                const int i0 = 4 * kq;            // first filter of this lane in the group
-                float* o = orow + m0 + i0;
-                if (vec_ok && (cnt & 3) == 0) {   // wave-uniform choice
-                    if (fvalid && i0 < cnt)
-                        *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
-                } else if (fvalid) {
-                    if (i0 < cnt) o[0] = r[0];
-                    if (i0 + 1 < cnt) o[1] = r[1];
-                    if (i0 + 2 < cnt) o[2] = r[2];
-                    if (i0 + 3 < cnt) o[3] = r[3];
-                }
-            }
-        }
     }
 }
 
@@ -653,7 +420,9 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
             const int j = lane & 15;
             float* orow = p.mel + (c_out0 + F0 + j) * n_mels;
             if (!p.out_power) {
-                mel_phase<STAMPS, NSLOT>(wbufs, lmeta + w * kMaxSlotsW, wf, n_slots_w, slot_end_w, orow,
+                const int mf = lane & 15;
+                mel_phase<STAMPS, NSLOT>(wbufs + (mf >> 2) * kWbuf + (mf & 3) * kProw + (lane >> 4),
+                                         lmeta + w * kMaxSlotsW, wf, n_slots_w, slot_end_w, orow,
                                   F0 + j < c_frames, vec_ok, p.log_mel != 0, lane, acc_t, t_prev);
             } else {
                 // power output: this wave's four rows [frame][513], consecutive lanes on
@@ -734,7 +503,8 @@ __global__ __launch_bounds__(kThreads, 2) void af_mel_apply_kernel(const MelAppl
         if (u + gridDim.x < n_units) fetch(u + gridDim.x);
         const int j = lane & 15;
         float* orow = p.mel + (F0 + j) * n_mels;
-        mel_phase<false, kMaxSlotsW>(wbufs, lmeta + w * kMaxSlotsW, wf, n_slots_w, slot_end_w, orow,
+        mel_phase<false, kMaxSlotsW>(wbufs + (j >> 2) * kWbuf + (j & 3) * kProw + (lane >> 4),
+                                     lmeta + w * kMaxSlotsW, wf, n_slots_w, slot_end_w, orow,
                          F0 + j < p.n_frames, vec_ok, p.log_mel != 0, lane, acc_t, t_prev);
     }
 }
@@ -759,12 +529,8 @@ template <int HOP_T, int CH, bool I16, bool STAMPS, bool SEP, int NSLOT>
 static af_status launch_k(const Params& p, int grid, size_t smem, hipStream_t stream)
 {
     auto kern = af_features_kernel<HOP_T, CH, I16, STAMPS, SEP, NSLOT>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool attr_set[kMaxDevices] = {};
+    AF_HIP(allow_big_lds(kern, 160 * 1024, attr_set));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), smem, stream, p);
     AF_HIP(hipGetLastError());
     return AF_OK;

@@ -1,0 +1,565 @@
+// features_v2.hip -- the fused  interleaved PCM -> to_mono -> Hann STFT(1024) -> |X|^2 -> mel
+// kernel for hop 256 (the BASELINE configuration), built for four waves per SIMD.
+//
+// Same contract as features_kernel.hip (to_mono: reference capture.rs:30-42; STFT / mel:
+// docs/OPS.md, build-defined); what differs is how a workgroup is cut:
+//   * 512 threads = 8 wave64, one 16-frame unit per iteration; wave w owns the frame pair
+//     (2w, 2w+1), packed as the real / imaginary part of ONE 1024-point complex FFT.
+//   * the FFT is 16 x 16 x 4 with 16 complex points per lane (32 data VGPRs instead of the 64 of
+//     the 32 x 32 scheme), so the kernel fits 128 VGPRs and two workgroups (16 waves) share a CU:
+//       stage 1   lane n2 = 0..63:  radix-16 over n1  (n = 64 n1 + n2), twiddle W1024^(n2 k1)
+//       T1        through LDS: row k1, column n2;  lane (k1, c) reads columns c + 4m
+//       stage 2a  radix-16 over m -> b, twiddle W64^(c b)
+//       T2        in registers (v_permlane32_swap / v_permlane16_swap): lane (k1, j) gets b = j + 4b' of its four c lanes
+//       stage 2b  four radix-4 over c -> a;  lane L = k1 + 16 j then holds Z[L + 64 t], t = b' + 4a
+//     All butterflies are FMA-shaped (fft_regs.hpp).  The transposition stores are
+//     ds_write_addtid_b32 (row / plane offset in the instruction, no address register, half the
+//     LDS cycles of ds_write_b32).
+//   * split of the packed spectrum: Z[1024 - k] sits in lane (64 - L) % 64, register 15 - t
+//     (lane 0: 16 - t), exchanged through the same buffer; power rows [frame][514] in LDS.
+//   * mel: the banded filterbank groups are dealt to the 8 waves (features_api.hip build_plan),
+//     v_mfma_f32_16x16x4_f32, A fragments resident in registers for the whole launch.
+//   * every unit is described by one 32-byte record (UnitDesc, built on the host): no clip search,
+//     no 64-bit index arithmetic in the loop.
+#include "features_dev.hpp"
+#include "fft_regs.hpp"
+
+namespace af {
+namespace feat {
+namespace v2 {
+
+__device__ __forceinline__ constexpr int brev4(int x)
+{
+    return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3);
+}
+
+// v_permlane32_swap: lanes 32..63 of a <-> lanes 0..31 of b;  v_permlane16_swap: rows 1, 3 of a <->
+// rows 0, 2 of b (rows of 16 lanes)
+__device__ __forceinline__ void swap_rows32(float& a, float& b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_rows16(float& a, float& b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// compiler-only ordering point between this wave's LDS accesses (a wave's DS operations execute
+// in order, nothing has to be waited for)
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
+// Lane-consecutive LDS stores without an address register: ds_write_addtid_b32 writes lane l's
+// value to  M0 + offset + 4 l  (half the LDS cycles of ds_write_b32: no address VGPR to move).
+// m0 = LDS byte address of the wave's buffer (wave-uniform); value i goes to row i, rows STRIDE
+// bytes apart from BASE.  M0 is set inside every statement (the compiler treats it as a scratch
+// register), followed by the wait state the ISA asks for between an M0 write and an add-TID access.
+// AF_V2_NO_ADDTID (diagnostics): the same stores as plain ds_write_b32.
+struct WaveBuf {
+    float* wb;
+    unsigned m0;
+    int lane;
+};
+template <int STRIDE, int BASE>
+__device__ __forceinline__ void addtid_store8(const WaveBuf& b, float v0, float v1, float v2, float v3,
+                                              float v4, float v5, float v6, float v7)
+{
+    static_assert(BASE >= 0 && BASE + 7 * STRIDE < 65536 && STRIDE % 4 == 0 && BASE % 4 == 0, "16-bit offset field");
+#ifdef AF_V2_NO_ADDTID
+    float* d = b.wb + BASE / 4 + b.lane;
+    d[0] = v0; d[STRIDE / 4] = v1; d[2 * (STRIDE / 4)] = v2; d[3 * (STRIDE / 4)] = v3;
+    d[4 * (STRIDE / 4)] = v4; d[5 * (STRIDE / 4)] = v5; d[6 * (STRIDE / 4)] = v6; d[7 * (STRIDE / 4)] = v7;
+    asm volatile("" ::: "memory");
+#else
+    asm volatile("s_mov_b32 m0, %8\n\t"
+                 "s_nop 0\n\t"
+                 "ds_write_addtid_b32 %0 offset:%9\n\t"
+                 "ds_write_addtid_b32 %1 offset:%10\n\t"
+                 "ds_write_addtid_b32 %2 offset:%11\n\t"
+                 "ds_write_addtid_b32 %3 offset:%12\n\t"
+                 "ds_write_addtid_b32 %4 offset:%13\n\t"
+                 "ds_write_addtid_b32 %5 offset:%14\n\t"
+                 "ds_write_addtid_b32 %6 offset:%15\n\t"
+                 "ds_write_addtid_b32 %7 offset:%16"
+                 :
+                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "s"(b.m0),
+                   "n"(BASE), "n"(BASE + STRIDE), "n"(BASE + 2 * STRIDE), "n"(BASE + 3 * STRIDE),
+                   "n"(BASE + 4 * STRIDE), "n"(BASE + 5 * STRIDE), "n"(BASE + 6 * STRIDE),
+                   "n"(BASE + 7 * STRIDE)
+                 : "memory");
+#endif
+}
+template <int BASE>
+__device__ __forceinline__ void addtid_store1(const WaveBuf& b, float v0)
+{
+#ifdef AF_V2_NO_ADDTID
+    b.wb[BASE / 4 + b.lane] = v0;
+    asm volatile("" ::: "memory");
+#else
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(v0), "s"(b.m0), "n"(BASE)
+                 : "memory");
+#endif
+}
+template <int STRIDE, int BASE>
+__device__ __forceinline__ void addtid_store16(const WaveBuf& b, const float (&v)[16])
+{
+    addtid_store8<STRIDE, BASE>(b, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    addtid_store8<STRIDE, BASE + 8 * STRIDE>(b, v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
+}
+
+// ---------------------------------------------------------------------------
+// One frame pair: signal tile -> two power rows in this wave's buffer wb.
+//   tile   mono samples of the unit, frame f starts at tile[f * kHop]
+//   wb     this wave's buffer (kWb dwords), m0 its byte offset in LDS
+// Part 1: stage 1 and the first transposition; ur / ui hold stage 2a's inputs (element brev4(m)).
+__device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float* wb, const WaveBuf& wv, int w,
+                                           int lane, const float* __restrict__ wtab,
+                                           const float* __restrict__ tw1, float (&ur)[16], float (&ui)[16])
+{
+    const int k1 = lane & 15, hi = lane >> 4;
+    float re[16], im[16];
+
+    // ---- stage 1: lane n2 = lane; z[64 n1 + n2] = w * (a + i b); frame b = frame a shifted by
+    // kHop samples = 4 registers.  The window multiply is fused into the twiddle-free first DIT
+    // stage (element e holds input brev4(e): elements (e, e + 1) are inputs (na, na + 8)).
+    {
+        const float* src = tile + (2 * w) * kHop + lane;
+        float s[20];
+#pragma unroll
+        for (int j = 0; j < 20; ++j) s[j] = src[64 * j];
+        float win[16];
+        const float4* wrow = reinterpret_cast<const float4*>(wtab + lane * kWinRow2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = wrow[j];
+            win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const int na = brev4(e), nb = na + 8;
+            const float mr = s[nb] * win[nb], mi = s[nb + 4] * win[nb];
+            re[e] = __builtin_fmaf(s[na], win[na], mr);
+            re[e + 1] = __builtin_fmaf(s[na], win[na], -mr);
+            im[e] = __builtin_fmaf(s[na + 4], win[na], mi);
+            im[e + 1] = __builtin_fmaf(s[na + 4], win[na], -mi);
+        }
+    }
+    fftr::dit_fft<16, 2>(re, im);                  // Y[k1] at element k1
+
+    // twiddle W1024^(n2 k1): row n2 of the table holds (cos, sin) for k1 = 0..15
+    {
+        const float4* trow = reinterpret_cast<const float4*>(tw1 + lane * kTw1Row);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float4 t = trow[jj];
+            if (jj > 0) {
+                const float xr = re[2 * jj], xi = im[2 * jj];
+                re[2 * jj] = __builtin_fmaf(xr, t.x, xi * t.y);
+                im[2 * jj] = __builtin_fmaf(xi, t.x, -(xr * t.y));
+            }
+            const float xr = re[2 * jj + 1], xi = im[2 * jj + 1];
+            re[2 * jj + 1] = __builtin_fmaf(xr, t.z, xi * t.w);
+            im[2 * jj + 1] = __builtin_fmaf(xi, t.z, -(xr * t.w));
+        }
+    }
+
+    // ---- T1: row k1, column n2; lane (k1, c = hi) reads columns c + 4m into element brev4(m)
+    {
+        const float* rd = wb + k1 * kT1Row + hi;
+        addtid_store16<4 * kT1Row, 0>(wv, re);
+        lds_order();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) ur[brev4(m)] = rd[4 * m];
+        lds_order();
+        addtid_store16<4 * kT1Row, 0>(wv, im);
+        lds_order();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) ui[brev4(m)] = rd[4 * m];
+        lds_order();
+    }
+
+}
+
+// Part 2: stage 2, spectrum split, power rows.
+__device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lane, const float* __restrict__ tw2,
+                                           float (&ur)[16], float (&ui)[16])
+{
+    const int hi = lane >> 4;
+    // ---- stage 2a: radix-16 over m -> b, twiddle W64^(c b)
+    fftr::dit_fft<16>(ur, ui);
+    {
+        const float4* trow = reinterpret_cast<const float4*>(tw2 + hi * kTw2Row);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float4 t = trow[jj];
+            if (jj > 0) {
+                const float xr = ur[2 * jj], xi = ui[2 * jj];
+                ur[2 * jj] = __builtin_fmaf(xr, t.x, xi * t.y);
+                ui[2 * jj] = __builtin_fmaf(xi, t.x, -(xr * t.y));
+            }
+            const float xr = ur[2 * jj + 1], xi = ui[2 * jj + 1];
+            ur[2 * jj + 1] = __builtin_fmaf(xr, t.z, xi * t.w);
+            ui[2 * jj + 1] = __builtin_fmaf(xi, t.z, -(xr * t.w));
+        }
+    }
+
+    // ---- T2: lane (k1, j) needs U'[k1][c][j + 4b'] for c = 0..3 from the four lanes (k1, c): per b' a
+    // 4 x 4 transpose (lane row c, register j) -> (lane row j, register c) of registers 4b'..4b'+3,
+    // done in registers: v_permlane32_swap exchanges rows {2, 3} of one register with rows {0, 1} of
+    // another, v_permlane16_swap rows {1, 3} with rows {0, 2}.  Afterwards element 4b' + c holds x_c.
+#pragma unroll
+    for (int bp = 0; bp < 4; ++bp) {
+        swap_rows32(ur[4 * bp], ur[4 * bp + 2]);
+        swap_rows32(ur[4 * bp + 1], ur[4 * bp + 3]);
+        swap_rows16(ur[4 * bp], ur[4 * bp + 1]);
+        swap_rows16(ur[4 * bp + 2], ur[4 * bp + 3]);
+        swap_rows32(ui[4 * bp], ui[4 * bp + 2]);
+        swap_rows32(ui[4 * bp + 1], ui[4 * bp + 3]);
+        swap_rows16(ui[4 * bp], ui[4 * bp + 1]);
+        swap_rows16(ui[4 * bp + 2], ui[4 * bp + 3]);
+    }
+
+    // ---- stage 2b: radix-4 over c -> a, in place: Z[lane + 64 t], t = b' + 4a, is element 4b' + a
+#pragma unroll
+    for (int bp = 0; bp < 4; ++bp) {
+        const float x0r = ur[4 * bp], x1r = ur[4 * bp + 1], x2r = ur[4 * bp + 2], x3r = ur[4 * bp + 3];
+        const float x0i = ui[4 * bp], x1i = ui[4 * bp + 1], x2i = ui[4 * bp + 2], x3i = ui[4 * bp + 3];
+        const float t0r = x0r + x2r, t0i = x0i + x2i, t1r = x0r - x2r, t1i = x0i - x2i;
+        const float t2r = x1r + x3r, t2i = x1i + x3i, t3r = x1r - x3r, t3i = x1i - x3i;
+        ur[4 * bp] = t0r + t2r;     ui[4 * bp] = t0i + t2i;         // a = 0
+        ur[4 * bp + 2] = t0r - t2r; ui[4 * bp + 2] = t0i - t2i;     // a = 2
+        ur[4 * bp + 1] = t1r + t3i; ui[4 * bp + 1] = t1i - t3r;     // a = 1: t1 - i t3
+        ur[4 * bp + 3] = t1r - t3i; ui[4 * bp + 3] = t1i + t3r;     // a = 3: t1 + i t3
+    }
+#define ZR(t) ur[4 * ((t) & 3) + ((t) >> 2)]
+#define ZI(t) ui[4 * ((t) & 3) + ((t) >> 2)]
+
+    // ---- split of the packed spectrum.  A[k] = (Z[k] + conj Z[N-k]) / 2 (frame a),
+    // B[k] = (Z[k] - conj Z[N-k]) / 2i (frame b); the 1/2 sits in the window table.  Z[N-k] for
+    // k = lane + 64 t is register 15 - t of lane (64 - lane) % 64 (lane 0: register 16 - t).
+    // Published: registers 8..15 as planes 0..7, register 0 as plane 8 (lane 0's "register 16");
+    // real parts at plane * 64, imaginary parts 576 dwords further.
+    {
+        addtid_store8<256, 0>(wv, ZR(8), ZR(9), ZR(10), ZR(11), ZR(12), ZR(13), ZR(14), ZR(15));
+        addtid_store1<8 * 256>(wv, ZR(0));
+        addtid_store8<256, 576 * 4>(wv, ZI(8), ZI(9), ZI(10), ZI(11), ZI(12), ZI(13), ZI(14), ZI(15));
+        addtid_store1<576 * 4 + 8 * 256>(wv, ZI(0));
+        lds_order();
+        const int pl = (64 - lane) & 63;
+        const int d = lane == 0 ? 1 : 0;
+        const float* ex = wb + pl + 64 * d;
+        float pa[9], pb[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // t = 8 only matters for lane 0 (bin 512, its own register 8 = plane 0)
+            const float pr = t < 8 ? ex[(7 - t) * 64] : wb[pl];
+            const float pi = t < 8 ? ex[576 + (7 - t) * 64] : wb[576 + pl];
+            const float a1 = ZR(t) + pr, a2 = ZI(t) - pi;
+            const float b1 = ZI(t) + pi, b2 = ZR(t) - pr;
+            pa[t] = __builtin_fmaf(a1, a1, a2 * a2);
+            pb[t] = __builtin_fmaf(b1, b1, b2 * b2);
+        }
+        lds_order();
+        // power rows [frame][514] (they alias the exchange planes: every lane has read its partners)
+        addtid_store8<256, 0>(wv, pa[0], pa[1], pa[2], pa[3], pa[4], pa[5], pa[6], pa[7]);
+        addtid_store8<256, 4 * kProw>(wv, pb[0], pb[1], pb[2], pb[3], pb[4], pb[5], pb[6], pb[7]);
+        if (lane == 0) {
+            wb[512] = pa[8];
+            wb[kProw + 512] = pb[8];
+        }
+    }
+#undef ZR
+#undef ZI
+}
+
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ UnitDesc load_desc(const UnitDesc* units, unsigned u)
+{
+    // through the scalar cache: a vector load would make every unit wait for vmcnt(0), i.e. for
+    // the previous unit's mel stores.  The wait is inside: hipcc does not track loads issued
+    // from inline asm.
+    const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(u) * 32u;
+    u32x8 r;
+    asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(units), "s"(off) : "memory");
+    UnitDesc d;
+    d.pcm0 = (int64_t)(((unsigned long long)r[1] << 32) | r[0]);
+    d.out0 = (int64_t)(((unsigned long long)r[3] << 32) | r[2]);
+    d.n_avail = (int)r[4];
+    d.n_rows = (int)r[5];
+    d.flags = (int)r[6];
+    d.sel = (int)r[7];
+    return d;
+}
+
+// Diagnostics (Params::stamps != null only): per-phase cycle sums of waves 0..3.
+#define AF_STAMP2(i)                                                        \
+    do {                                                                    \
+        if constexpr (STAMPS) {                                             \
+            __builtin_amdgcn_sched_barrier(0);                              \
+            const unsigned long long _t = __builtin_amdgcn_s_memtime();     \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+            acc_t[i] += _t - t_prev;                                        \
+            t_prev = _t;                                                    \
+            __builtin_amdgcn_sched_barrier(0);                              \
+        }                                                                   \
+    } while (0)
+
+template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS>
+__global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
+{
+    using St = Stage<CH, I16>;
+    constexpr int MS = St::MS;                       // mono samples per 16-byte staging unit
+    constexpr int PFU = 16 * kHop / MS / kT;         // staging units per thread and unit of work
+    static_assert(PFU >= 1 && PFU * MS * kT == 16 * kHop, "prefetch shape");
+    constexpr int kFreshIters = (kTile / MS + kT - 1) / kT;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wbufs = smem;                             // first: ds_write_addtid reaches M0 < 64 KB
+    float* tile = wbufs + kW * kWb;
+    float* wtab = tile + kTile;
+    float* tw1 = wtab + 64 * kWinRow2;
+    float* tw2 = tw1 + 64 * kTw1Row;
+    int* lmeta = reinterpret_cast<int*>(tw2 + 4 * kTw2Row);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* wb = wbufs + w * kWb;
+    // LDS byte address of this wave's buffer = the low half of its flat address
+    const WaveBuf wv{wb, (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<uintptr_t>(wb)), lane};
+
+    const int64_t G = gridDim.x, bid = blockIdx.x;
+    unsigned u = (unsigned)(p.total_units * bid / G);
+    const unsigned u_end = (unsigned)(p.total_units * (bid + 1) / G);
+    if (u >= u_end) return;
+
+    // tables -> LDS (visible after the first barrier)
+    for (int i = tid; i < kTabFloats / 4; i += kT)
+        reinterpret_cast<float4*>(wtab)[i] = reinterpret_cast<const float4*>(p.tabs)[i];
+    for (int i = tid; i < kW * kMaxSlotsW; i += kT) lmeta[i] = p.meta[i];
+
+    // this wave's share of the mel plan
+    const float4* __restrict__ wfrag_w = reinterpret_cast<const float4*>(p.wfrag) + ((size_t)w * kMaxSlotsW) * 64 + lane;
+    const int n_slots_w = p.plan.wave_nslots[w];
+    int slot_end_w[NSLOT];
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) slot_end_w[q] = p.plan.slot_end[w][q];
+    const int n_mels = p.plan.n_mels;
+    const bool vec_ok = (n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(p.out) % 16 == 0);
+    const float* pbase = wbufs + ((lane & 15) >> 1) * kWb + (lane & 1) * kProw + (lane >> 4);
+    const unsigned row_off = (unsigned)(lane & 15) * (unsigned)n_mels + 4u * (unsigned)(lane >> 4);
+
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memtime() : 0;
+    bool fresh = true;
+    while (u < u_end) {
+        const UnitDesc ud = load_desc(p.units, u);
+        AF_STAMP2(0);
+        const int sel = SEP ? ud.sel : -1;
+        const int64_t n_avail = ud.n_avail;
+
+        if (fresh) {
+            __syncthreads();                         // nobody still reads the old tile / power rows
+#pragma unroll
+            for (int i = 0; i < kFreshIters; ++i) {
+                const int v = tid + i * kT;
+                if (v * MS < kTile) {
+                    float m[MS];
+                    St::load(p.pcm, ud.pcm0, (int64_t)v * MS, n_avail, true, m, sel);
+                    St::store(tile + v * MS, m);
+                }
+            }
+        }
+        __syncthreads();                             // B1: tile ready, previous mel phase done
+        AF_STAMP2(1);
+
+        const bool has_next = (u + 1 < u_end) && (ud.flags & 1);
+        uint4 pf[PFU];
+        if (has_next) {
+            if (n_avail >= kTile + 16 * kHop) {      // wave-uniform: the new region lies inside the clip
+                const char* src = static_cast<const char*>(p.pcm) +
+                                  (ud.pcm0 + kTile) * St::kBytesPerFrame;
+#pragma unroll
+                for (int i = 0; i < PFU; ++i)
+                    pf[i] = *reinterpret_cast<const uint4*>(src + (unsigned)(tid + i * kT) * 16u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PFU; ++i)
+                    pf[i] = St::load_raw(p.pcm, ud.pcm0, kTile + (int64_t)(tid + i * kT) * MS, n_avail, true);
+            }
+        }
+
+        float wf[NSLOT * kSlotSteps];
+        {
+            float ur[16], ui[16];
+#ifdef AF_V2_PRIO
+            if (w < 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+            fft_pair_1(tile, wb, wv, w, lane, wtab, tw1, ur, ui);
+#ifdef AF_V2_PRIO
+            if (w < 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+#endif
+            AF_STAMP2(2);
+            // This wave's filterbank fragments (L2-resident, one float4 per slot), issued where the
+            // register pressure has dropped and early enough to be back for the mel phase.
+            if (!p.out_power) {
+                int opaque_zero;                     // pins the loads here (and defeats hoisting)
+                asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+                const float4* wp = wfrag_w + opaque_zero;
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) {
+                    const float4 v = wp[q * 64];
+                    wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NSLOT * kSlotSteps; ++q) wf[q] = 0.0f;
+            }
+            fft_pair_2(wb, wv, lane, tw2, ur, ui);
+        }
+        AF_STAMP2(3);
+
+#ifdef AF_V2_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        __syncthreads();                             // B2: power rows ready, tile reads done
+        AF_STAMP2(4);
+
+        if (has_next) {
+            // The next tile is this one shifted by 16 hops: the last kTail samples move to the front,
+            // the new samples follow.  A staging unit that lands on part of the old tail is handled by
+            // one thread: read the old samples, store the new ones there, store the old ones at the front.
+#pragma unroll
+            for (int i = 0; i < PFU; ++i) {
+                const int v = tid + i * kT;
+                float m[MS];
+                St::convert(pf[i], m, sel);
+                float* dst = tile + kTail + v * MS;
+                if ((i + 1) * kT * MS > 16 * kHop - kTail) {        // compile time: this round reaches the tail
+                    if (v * MS >= 16 * kHop - kTail) {
+                        float old[MS];
+#pragma unroll
+                        for (int e = 0; e < MS; ++e) old[e] = dst[e];
+                        St::store(dst, m);
+                        St::store(tile + v * MS - (16 * kHop - kTail), old);
+                        continue;
+                    }
+                }
+                St::store(dst, m);
+            }
+        }
+
+        AF_STAMP2(5);
+        if (!p.out_power) {
+            // mel: banded W (A, registers) x P^T (B, bins x 16 frames from the power rows) on
+            // v_mfma_f32_16x16x4_f32; all B operands first, then the chain; a slot that ends a group
+            // sends the 16 frames x <= 16 filters accumulator to HBM (one 16-byte store per lane)
+            float bop[NSLOT * kSlotSteps];
+            {
+                const int* lm = lmeta + w * kMaxSlotsW;
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) {
+                    const float* bq = pbase + lm[q];
+#pragma unroll
+                    for (int i = 0; i < kSlotSteps; ++i) bop[q * kSlotSteps + i] = bq[4 * i];
+                }
+            }
+            float* obase = p.out + ud.out0 * n_mels;                // wave-uniform
+            const bool fvalid = (lane & 15) < ud.n_rows;
+            const int i0 = 4 * (lane >> 4);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) {
+                if (q < n_slots_w) {
+#pragma unroll
+                    for (int st = q * kSlotSteps; st < (q + 1) * kSlotSteps; st += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], bop[st], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st + 1], bop[st + 1], acc1, 0, 0, 0);
+                    }
+                    const int e = slot_end_w[q];                    // wave-uniform (kernarg)
+                    if (e != 0) {
+                        f32x4 r = acc0 + acc1;
+                        if (p.log_mel) {                            // wave-uniform: log10(max(mel, 1e-10))
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) r[i] = __log10f(fmaxf(r[i], 1e-10f));
+                        }
+                        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const int mm = e & 255, cnt = (e >> 8) & 31;
+                        float* o = obase + mm + row_off;            // uniform base + 32-bit lane offset
+                        if (vec_ok && ((cnt | mm) & 3) == 0) {      // wave-uniform choice
+                            if (fvalid && i0 < cnt) *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
+                        } else if (fvalid) {
+                            if (i0 < cnt) o[0] = r[0];
+                            if (i0 + 1 < cnt) o[1] = r[1];
+                            if (i0 + 2 < cnt) o[2] = r[2];
+                            if (i0 + 3 < cnt) o[3] = r[3];
+                        }
+                    }
+                }
+            }
+        } else {
+            // power output: this wave's two rows [frame][513], consecutive lanes on consecutive bins
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int f = 2 * w + r;
+                if (f < ud.n_rows) {
+                    float* o = p.out + (ud.out0 + f) * kBins;
+                    for (int k = lane; k < kBins; k += 64) o[k] = wb[r * kProw + k];
+                }
+            }
+        }
+        AF_STAMP2(6);
+        ++u;
+        fresh = !has_next;
+    }
+    if constexpr (STAMPS) {
+        if (lane == 0 && w < 4)
+            for (int i = 0; i < 8; ++i) atomicAdd(p.stamps + w * 8 + i, acc_t[i]);
+    }
+}
+
+template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS = false>
+static af_status launch_k(const Params& p, int grid, hipStream_t stream)
+{
+    auto kern = af_features_v2_kernel<CH, I16, SEP, NSLOT, STAMPS>;
+    constexpr size_t smem = sizeof(float) * kLdsFloats;
+    static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
+    static bool attr_set[kMaxDevices] = {};
+    AF_HIP(allow_big_lds(kern, (int)smem, attr_set));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kT), smem, stream, p);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+template <int CH, bool I16>
+static af_status launch_fmt(const Params& p, bool separate, int grid, hipStream_t stream)
+{
+    int most = 0;
+    for (int w = 0; w < kW; ++w) most = p.plan.wave_nslots[w] > most ? p.plan.wave_nslots[w] : most;
+    if (most > 8) return fail(AF_ERR_UNSUPPORTED, "features v2: %d mel slots on one wave (limit 8)", most);
+    if constexpr (CH == 2) {
+        if (separate) return launch_k<CH, I16, true, 8>(p, grid, stream);
+    }
+    if constexpr (CH == 2 && !I16) {
+        if (p.stamps) return launch_k<CH, I16, false, 8, true>(p, grid, stream);
+    }
+    if (most <= 6) return launch_k<CH, I16, false, 6>(p, grid, stream);
+    return launch_k<CH, I16, false, 8>(p, grid, stream);
+}
+
+af_status launch(const Params& p, int channels, bool i16, bool separate, int grid, hipStream_t stream)
+{
+    if (grid <= 0) return AF_OK;
+    if (channels == 2 && !i16) return launch_fmt<2, false>(p, separate, grid, stream);
+    if (channels == 1 && !i16) return launch_fmt<1, false>(p, false, grid, stream);
+    if (channels == 2 && i16) return launch_fmt<2, true>(p, separate, grid, stream);
+    if (channels == 1 && i16) return launch_fmt<1, true>(p, false, grid, stream);
+    return fail(AF_ERR_UNSUPPORTED, "features: channels must be 1 or 2 (got %d)", channels);
+}
+
+}  // namespace v2
+}  // namespace feat
+}  // namespace af

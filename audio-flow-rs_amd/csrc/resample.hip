@@ -219,14 +219,10 @@ af_status launch(const Design& d, const float* x_dev, int64_t x_abs0, int64_t x_
     g.M = d.M;
     g.taps_in_lds = d.taps_in_lds;
     g.x_tile_cap = d.x_tile_cap;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool attr_set[kMaxDevices] = {};
+    AF_HIP(allow_big_lds(resample_kernel, 160 * 1024, attr_set));
     int64_t grid = g.n_tiles;
-    const int64_t cap = 256 * (int64_t)(d.smem > 80 * 1024 ? 1 : d.smem > 53 * 1024 ? 2 : 3) * 4;
+    const int64_t cap = device_cu_count(current_device()) * (int64_t)(d.smem > 80 * 1024 ? 1 : d.smem > 53 * 1024 ? 2 : 3) * 4;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(resample_kernel, dim3((unsigned)grid), dim3(kBlock), d.smem, stream, g);
     AF_HIP(hipGetLastError());
@@ -387,16 +383,18 @@ namespace {
 // once built; the device tables belong to the device that was current at first use)
 af_status cached_design(uint32_t in_hz, uint32_t out_hz, rs::Design** out)
 {
+    // a design owns device tables: one per (ratio, device ordinal)
     static std::mutex mu;
-    static std::vector<rs::Design*> cache;
+    static std::vector<std::pair<int, rs::Design*>> cache;
     std::lock_guard<std::mutex> lock(mu);
-    for (rs::Design* d : cache)
-        if (d->in_hz == in_hz && d->out_hz == out_hz) { *out = d; return AF_OK; }
+    const int dev = current_device();
+    for (const auto& e : cache)
+        if (e.first == dev && e.second->in_hz == in_hz && e.second->out_hz == out_hz) { *out = e.second; return AF_OK; }
     rs::Design* d = new (std::nothrow) rs::Design();
     if (!d) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
     af_status st = rs::make_design(in_hz, out_hz, *d, true);
     if (st != AF_OK) { delete d; return st; }
-    cache.push_back(d);
+    cache.push_back({dev, d});
     *out = d;
     return AF_OK;
 }

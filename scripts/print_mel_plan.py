@@ -8,6 +8,6 @@ for sr, nm in [(48000, 80), (16000, 80), (48000, 128), (16000, 40), (22050, 64),
         p = af.FeaturePipeline(sample_rate=sr, channels=1, n_mels=nm)
     except af.AudioError as e:
         print(sr, nm, "unsupported:", e); continue
-    info = (C.c_int32 * 6)()
+    info = (C.c_int32 * 17)()
     lib.af_features_plan_describe(p._h, info)
     print(sr, nm, list(info))

@@ -23,7 +23,9 @@ def test_resample_golden(af, name):
 
 
 @pytest.mark.parametrize("fi,fo", [(44100, 16000), (48000, 16000), (16000, 48000), (48000, 44100),
-                                   (8000, 16000), (22050, 16000)])
+                                   (8000, 16000), (22050, 16000),
+                                   # L = 15: column segments shorter than the workgroup (960 threads)
+                                   (48000, 45000), (8000, 15000)])
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 1000, 20011])
 def test_resample_batch_vs_oracle(af, po, fi, fo, n):
     clips = np.stack([synth_clip(50 + i, n, 1, fi) for i in range(3)])

@@ -111,8 +111,10 @@ def test_banded_plan_invariants(af):
     assert (p["ok"], p["L"], p["M"], p["nb"], p["S"], p["NK"], p["nwaves"]) == (1, 1, 3, 1, 48, 28, 8)
     assert plan(48000, 16000, 2)["ok"] == 1 and plan(44100, 16000, 2)["ok"] == 0
     assert plan(48000, 44100)["ok"] == 0                      # 147 block matrices: VALU kernel
+    short = 0
     for fi, fo in [(44100, 16000), (48000, 16000), (16000, 48000), (8000, 16000), (22050, 16000),
-                   (44100, 48000), (32000, 16000), (96000, 16000), (11025, 16000), (16000, 8000)]:
+                   (44100, 48000), (32000, 16000), (96000, 16000), (11025, 16000), (16000, 8000),
+                   (48000, 45000), (16000, 15000), (8000, 15000), (24000, 45000)]:
         for ch in (1, 2):
             p = plan(fi, fo, ch)
             if not p["ok"]:
@@ -129,3 +131,6 @@ def test_banded_plan_invariants(af):
             assert p["seg_len"] == (p["G"] - 1) * p["S"] + qp_last + 4 * p["NK"] <= min(1000, 2 * 64 * p["nwaves"])
             assert p["seg_stride"] % 2 == 1 and p["seg_stride"] >= p["seg_len"]
             assert p["smem"] == 16 * p["seg_stride"] * 4 <= 64 * 1024
+            # segments may be shorter than the workgroup (the kernel masks the lanes beyond them)
+            short += p["seg_len"] < 64 * p["nwaves"]
+    assert short >= 2                                          # the L = 15 ratios exercise that mask
