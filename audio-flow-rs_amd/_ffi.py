@@ -32,6 +32,10 @@ class FeaturesConfig(C.Structure):
                 ("mel_norm", C.c_uint32), ("channel_mode", C.c_uint32)]
 
 
+class StreamConfig(C.Structure):
+    _fields_ = [("features", FeaturesConfig), ("step_frames", C.c_size_t)]
+
+
 class BatchDesc(C.Structure):
     _fields_ = [("cfg", FeaturesConfig), ("n_clips", C.c_size_t), ("clip_offsets", C.c_void_p)]
 
@@ -76,6 +80,7 @@ SIGNATURES = {
     "af_last_error": (C.c_char_p, []),
     "af_version": (C.c_char_p, []),
     "af_device_count": (C.c_int, []),
+    "af_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
     # to_mono
     "af_to_mono_out_len": (_sz, [_sz, C.c_uint16]),
     "af_to_mono": (_st, [_vp, _sz, C.c_uint16, _vp, _sz, _szp]),
@@ -145,8 +150,8 @@ SIGNATURES = {
     "af_features_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp]),
     "af_features_set_batch_spans": (_st, [_vp, _vp, _vp, _sz, _szp]),
     "af_features_run_device": (_st, [_vp, _vp, _vp, _vp]),
-    "af_features_run": (_st, [_vp, _vp, _vp, _sz]),
-    "af_pipeline_run": (_st, [C.POINTER(BatchDesc), _vp, _vp, _sz, _szp]),
+    "af_features_run": (_st, [_vp, _vp, _sz, _vp, _sz]),
+    "af_pipeline_run": (_st, [C.POINTER(BatchDesc), _vp, _sz, _vp, _sz, _szp]),
     "af_features_mel_weights": (_st, [_vp, _vp, _sz]),
     "af_features_kernel_name": (C.c_char_p, []),
     "af_features_plan_describe": (C.c_int, [_vp, _vp]),
@@ -160,7 +165,7 @@ SIGNATURES = {
     "af_stft_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp]),
     "af_stft_set_batch": (_st, [_vp, _vp, _sz, _szp]),
     "af_stft_power_device": (_st, [_vp, _vp, _vp, _vp]),
-    "af_stft_power": (_st, [_vp, _vp, _vp, _sz]),
+    "af_stft_power": (_st, [_vp, _vp, _sz, _vp, _sz]),
     "af_mel_default_config": (None, [C.POINTER(MelConfig)]),
     "af_mel_create": (_st, [C.POINTER(MelConfig), C.POINTER(_vp)]),
     "af_mel_destroy": (None, [_vp]),
@@ -173,7 +178,27 @@ SIGNATURES = {
     "af_chain_n_frames": (_sz, [_vp, _sz]),
     "af_chain_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp]),
     "af_chain_run_device": (_st, [_vp, _vp, _vp, _vp]),
-    "af_chain_run": (_st, [_vp, _vp, _vp, _sz]),
+    "af_chain_run": (_st, [_vp, _vp, _sz, _vp, _sz]),
+    # RingBuffer (capture.rs:84-161)
+    "af_ring_create": (_st, [_sz, C.POINTER(_vp)]),
+    "af_ring_destroy": (None, [_vp]),
+    "af_ring_capacity": (_sz, [_vp]),
+    "af_ring_write": (_sz, [_vp, _vp, _sz]),
+    "af_ring_read": (_st, [_vp, _sz, _vp, _sz, _szp, C.POINTER(C.c_int)]),
+    "af_ring_available": (_sz, [_vp]),
+    "af_ring_clear": (None, [_vp]),
+    # FeatureStream (BASELINE config 5)
+    "af_stream_default_config": (None, [C.POINTER(StreamConfig)]),
+    "af_stream_create": (_st, [C.POINTER(StreamConfig), C.POINTER(_vp)]),
+    "af_stream_destroy": (None, [_vp]),
+    "af_stream_rows_per_step": (_sz, [_vp]),
+    "af_stream_row_len": (_sz, [_vp]),
+    "af_stream_total_rows": (_sz, [_vp, C.c_uint64]),
+    "af_stream_max_rows": (_sz, [_vp, _sz]),
+    "af_stream_push": (_st, [_vp, _vp, _sz, _vp, _sz, _szp]),
+    "af_stream_flush": (_st, [_vp, _vp, _sz, _szp]),
+    "af_stream_reset": (_st, [_vp]),
+    "af_stream_stats": (_st, [_vp, _vp]),
 }
 
 _lib = None

@@ -161,55 +161,38 @@ class AudioFrame:
 
 
 class RingBuffer:
-    """capture.rs:84-161: mutex-guarded f32 ring with ``capacity - 1`` usable
-    slots.  Pure host bookkeeping (it feeds the device path), restated with the
-    reference's integer arithmetic."""
+    """capture.rs:84-161: mutex-guarded f32 ring with ``capacity - 1`` usable slots, behind the C ABI
+    (``af_ring_*``; pure host bookkeeping, it feeds the device path)."""
 
     def __init__(self, capacity_samples: int):
-        self.capacity = int(capacity_samples)                       # capture.rs:93-100
-        self._buf = np.zeros(self.capacity, np.float32)
-        self._w = 0
-        self._r = 0
-        self._lock = threading.Lock()
+        self._lib = library()
+        h = C.c_void_p()
+        _check(self._lib.af_ring_create(int(capacity_samples), C.byref(h)))    # capture.rs:93-100
+        self._h = h
+        self.capacity = int(capacity_samples)
 
-    def _used(self) -> int:
-        if self.capacity == 0:
-            return 0
-        return (self._w - self._r + self.capacity) % self.capacity
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_ring_destroy(h)
 
     def write(self, data) -> int:
-        """capture.rs:103-122"""
+        """capture.rs:103-122: samples actually stored"""
         x = _f32(data)
-        with self._lock:
-            if self.capacity == 0:
-                return 0
-            available = max(self.capacity - self._used(), 0)
-            to_write = min(x.size, max(available - 1, 0))
-            idx = (self._w + np.arange(to_write)) % self.capacity
-            self._buf[idx] = x[:to_write]
-            if to_write > 0:
-                self._w = (self._w + to_write) % self.capacity
-            return to_write
+        return int(self._lib.af_ring_write(self._h, _ptr(x), x.size))
 
     def read(self, size: int) -> Optional[np.ndarray]:
         """capture.rs:125-145 (``None`` when empty)"""
-        with self._lock:
-            available = self._used()
-            if available == 0:
-                return None
-            to_read = min(size, available)
-            idx = (self._r + np.arange(to_read)) % self.capacity
-            out = self._buf[idx].copy()
-            self._r = (self._r + to_read) % self.capacity
-            return out
+        out = np.empty(min(int(size), self.capacity), np.float32)
+        n, none = C.c_size_t(), C.c_int()
+        _check(self._lib.af_ring_read(self._h, int(size), _ptr(out), out.size, C.byref(n), C.byref(none)))
+        return None if none.value else out[:n.value].copy()
 
     def available(self) -> int:
-        return self._used()                                          # capture.rs:148-152
+        return int(self._lib.af_ring_available(self._h))                   # capture.rs:148-152
 
     def clear(self) -> None:
-        with self._lock:                                             # capture.rs:155-160
-            self._w = self._r = 0
-            self._buf[:] = 0.0
+        self._lib.af_ring_clear(self._h)                                    # capture.rs:155-160
 
 
 # --------------------------------------------------------------------------
@@ -541,7 +524,7 @@ class FeaturePipeline:
         dt = np.int16 if self.cfg.sample_format == _ffi.AF_PCM_I16 else np.float32
         x = np.ascontiguousarray(pcm, dt).reshape(-1)
         mel = np.empty((self.total_frames, self.row_len()), np.float32)
-        _check(self._lib.af_features_run(self._h, _ptr(x), _ptr(mel), mel.size))
+        _check(self._lib.af_features_run(self._h, _ptr(x), x.size, _ptr(mel), mel.size))
         return mel
 
     def process_batch(self, frames: Sequence[AudioFrame]) -> List[MelSpectrogram]:
@@ -559,12 +542,67 @@ class FeaturePipeline:
         pcm = (np.concatenate([f.samples[: (f.samples.size // ch) * ch] for f in frames])
                if frames else np.zeros(0, np.float32))
         mel = self.run(pcm)
+        # AF_CH_SEPARATE: a clip's rows are its channel-0 spectrogram followed by its channel-1 one
+        per_clip = 2 if self.cfg.channel_mode == _ffi.AF_CH_SEPARATE else 1
         out, row = [], 0
         for i in range(len(frames)):
-            nf = self.n_frames(int(offs[i + 1] - offs[i]))
+            nf = per_clip * self.n_frames(int(offs[i + 1] - offs[i]))
             out.append(MelSpectrogram(mel[row:row + nf], self.cfg.sample_rate, self.cfg.hop))
             row += nf
         return out
+
+
+class FeatureStream:
+    """The fused path over an unbounded stream in fixed steps (BASELINE config 5, ``af_stream_*``):
+    ``push`` returns the rows of every step it completed (one hipGraph replay each), ``flush`` the rows
+    of the last partial step; all rows in order == one-shot framing of the whole stream, bit for bit."""
+
+    def __init__(self, step_frames: int = 1 << 20, **features):
+        self._lib = library()
+        cfg = _ffi.StreamConfig()
+        self._lib.af_stream_default_config(C.byref(cfg))
+        for k, v in features.items():
+            setattr(cfg.features, k, v)
+        cfg.step_frames = int(step_frames)
+        self.cfg = cfg
+        h = C.c_void_p()
+        _check(self._lib.af_stream_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.row_len = int(self._lib.af_stream_row_len(h))
+        self.rows_per_step = int(self._lib.af_stream_rows_per_step(h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_stream_destroy(h)
+
+    def _dtype(self):
+        return np.int16 if self.cfg.features.sample_format == _ffi.AF_PCM_I16 else np.float32
+
+    def push(self, pcm) -> np.ndarray:
+        x = np.ascontiguousarray(pcm, self._dtype()).reshape(-1)
+        n_frames = x.size // self.cfg.features.channels
+        rows = np.empty((int(self._lib.af_stream_max_rows(self._h, n_frames)), self.row_len), np.float32)
+        n = C.c_size_t()
+        _check(self._lib.af_stream_push(self._h, _ptr(x), n_frames, _ptr(rows), rows.size, C.byref(n)))
+        return rows[:n.value]
+
+    def flush(self) -> np.ndarray:
+        rows = np.empty((self.rows_per_step, self.row_len), np.float32)
+        n = C.c_size_t()
+        _check(self._lib.af_stream_flush(self._h, _ptr(rows), rows.size, C.byref(n)))
+        return rows[:n.value].copy()
+
+    def reset(self) -> None:
+        _check(self._lib.af_stream_reset(self._h))
+
+    def total_rows(self, n_frames: int) -> int:
+        return int(self._lib.af_stream_total_rows(self._h, int(n_frames)))
+
+    def stats(self) -> dict:
+        v = (C.c_double * 4)()
+        _check(self._lib.af_stream_stats(self._h, v))
+        return {"device_ms": v[0], "wall_ms": v[1], "steps": int(v[2]), "rows": int(v[3])}
 
 
 class Stft:
@@ -615,7 +653,7 @@ class Stft:
         if self.total_frames == 0:
             self.set_batch_uniform(1, x.size // self.cfg.channels)
         out = np.empty((self.total_frames, self.n_bins()), np.float32)
-        _check(self._lib.af_stft_power(self._h, _ptr(x), _ptr(out), out.size))
+        _check(self._lib.af_stft_power(self._h, _ptr(x), x.size, _ptr(out), out.size))
         return out
 
 
@@ -692,5 +730,5 @@ class ChainPipeline:
     def run(self, pcm) -> np.ndarray:
         x = np.ascontiguousarray(pcm, np.float32).reshape(-1)
         mel = np.empty((self.total_frames, self.cfg.n_mels), np.float32)
-        _check(self._lib.af_chain_run(self._h, _ptr(x), _ptr(mel), mel.size))
+        _check(self._lib.af_chain_run(self._h, _ptr(x), x.size, _ptr(mel), mel.size))
         return mel

@@ -30,6 +30,15 @@ inline int current_device()
 }
 int device_cu_count(int device);
 
+// Diagnostic switches behind af_debug_set() (include/audioflow_dsp.h); 0 = product behaviour.
+enum DebugKnob {
+    kKnobFeaturesKernel = 0,   // 1: the general fused kernel also at hop 256
+    kKnobFeaturesWgPerCu,      // 1, 2: workgroups per CU of the fused kernels
+    kKnobBandedOff,            // 1: resampler / FIR on the thread-per-output kernels
+    kKnobCount
+};
+int debug_knob(DebugKnob k);
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: `done` is the
 // caller's static per-kernel flag array, indexed by device ordinal.
 constexpr int kMaxDevices = 64;

@@ -9,7 +9,6 @@
 //   w(t, g4) = 64 FULL + (t - 16 FULL) + TAILQ g4  for the TAILQ = NK % 16 tail steps,
 // i.e. the two k-groups of a lane group are 16 samples apart (bank-conflict free with an odd
 // column stride).  The A fragments are gathered with the same mapping (build_afrag_kernel).
-#include <cstdlib>
 #include <numeric>
 #include <type_traits>
 
@@ -258,7 +257,7 @@ Plan make_plan(uint32_t L, uint32_t M, int T, int c, int ch)
     p.T = T;
     p.c = c;
     if (L == 0 || M == 0 || T < 1) return p;
-    if (std::getenv("AF_BANDED_OFF")) return p;              // diagnostics: force the VALU kernels
+    if (debug_knob(kKnobBandedOff)) return p;               // diagnostics: force the VALU kernels
     const uint32_t g16 = std::gcd(16u, L);
     const uint64_t nb = L / g16;
     const uint64_t S = (uint64_t)(16 / g16) * M;

@@ -131,9 +131,12 @@ af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev,
     return af_features_run_device(c->feat, cur, mel_dev, stream);
 }
 
-af_status af_chain_run(af_chain* c, const float* pcm, float* mel, size_t mel_cap)
+af_status af_chain_run(af_chain* c, const float* pcm, size_t pcm_len, float* mel, size_t mel_cap)
 {
     AF_REQUIRE(c, "af_chain_run: null handle");
+    if (pcm_len < c->n_clips * c->n_in * c->cfg.channels)
+        return fail(AF_ERR_BUFFER_TOO_SMALL, "pcm buffer holds %zu samples, the batch describes %zu", pcm_len,
+                    c->n_clips * c->n_in * c->cfg.channels);
     const size_t n_out = c->total_frames * c->cfg.n_mels;
     if (mel_cap < n_out) return fail(AF_ERR_BUFFER_TOO_SMALL, "mel buffer holds %zu floats, need %zu", mel_cap, n_out);
     if (c->n_clips == 0 || c->n_in == 0) return AF_OK;

@@ -1,4 +1,6 @@
 // core.hip -- error reporting and device bring-up for libaudioflow_dsp.so
+#include <atomic>
+#include <cstring>
 #include <mutex>
 
 #include "af_common.hpp"
@@ -46,6 +48,13 @@ af_status ensure_device(int device)
     return AF_OK;
 }
 
+namespace {
+std::atomic<int> g_knobs[kKnobCount];
+const char* const kKnobNames[kKnobCount] = {"features.kernel", "features.wg_per_cu", "banded.off"};
+}  // namespace
+
+int debug_knob(DebugKnob k) { return g_knobs[k].load(std::memory_order_relaxed); }
+
 int device_cu_count(int device)
 {
     // queried once per device ordinal; 256 (MI355X) only if the runtime cannot say
@@ -68,6 +77,17 @@ extern "C" {
 const char* af_last_error(void) { return af::last_error_slot().c_str(); }
 
 const char* af_version(void) { return "audioflow-dsp-mi355x 0.1.0 (gfx950)"; }
+
+af_status af_debug_set(const char* key, int value)
+{
+    if (!key) return af::fail(AF_ERR_INVALID_ARG, "af_debug_set: null key");
+    for (int i = 0; i < af::kKnobCount; ++i)
+        if (std::strcmp(key, af::kKnobNames[i]) == 0) {
+            af::g_knobs[i].store(value, std::memory_order_relaxed);
+            return AF_OK;
+        }
+    return af::fail(AF_ERR_INVALID_ARG, "af_debug_set: unknown switch '%s'", key);
+}
 
 int af_device_count(void)
 {

@@ -91,11 +91,7 @@ void build_mel(const af_features_config& c, double f_max, std::vector<float>& W)
 // Dynamic programming picks the groups and deals them, in order, to the 4
 // waves so that the largest per-wave step count is minimal (ties: fewest
 // steps in total).
-int flush_cost()
-{
-    if (const char* e = std::getenv("AF_FEATURES_FLUSH_COST")) return std::atoi(e);   // tuning only
-    return 8;
-}
+int flush_cost() { return 8; }
 
 af_status build_plan(const std::vector<float>& W, int n_mels, int kWaves, int max_slots, int uf, Plan& plan,
                      std::vector<float>& wfrag, std::vector<int>& meta)
@@ -516,7 +512,8 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     prm.log_mel = (int)p->cfg.log_mel;
     prm.separate = p->cfg.channel_mode == AF_CH_SEPARATE;
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
-    if (p->units_ok && prm.aligned16 && !std::getenv("AF_FEATURES_GENERAL")) {
+    const int wg_knob = debug_knob(kKnobFeaturesWgPerCu);
+    if (p->units_ok && prm.aligned16 && !debug_knob(kKnobFeaturesKernel)) {
         // hop 256, 16-byte aligned clips: the 8-wave kernel, two workgroups per CU
         v2::Params q{};
         q.pcm = pcm_dev;
@@ -531,10 +528,7 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
         q.log_mel = prm.log_mel;
         q.stamps = prm.stamps;
         int64_t grid2 = (int64_t)p->n_cus * 2;
-        if (const char* e = std::getenv("AF_FEATURES_WG_PER_CU")) {   // diagnostics only
-            const int v = std::atoi(e);
-            if (v >= 1 && v <= 2) grid2 = (int64_t)p->n_cus * v;
-        }
+        if (wg_knob == 1) grid2 = (int64_t)p->n_cus;
         if (grid2 > p->total_units) grid2 = p->total_units;
         return v2::launch(q, (int)p->cfg.channels, p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
                           (int)grid2, as_stream(stream));
@@ -545,19 +539,20 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     int per_cu = (int)((160 * 1024) / smem);
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
-    if (const char* e = std::getenv("AF_FEATURES_WG_PER_CU")) {   // tuning/diagnostics only
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 8) per_cu = v;
-    }
+    if (wg_knob >= 1 && wg_knob <= 8) per_cu = wg_knob;
     int64_t grid = (int64_t)p->n_cus * per_cu;
     if (grid > p->total_units) grid = p->total_units;
     return launch_features(prm, (int)p->cfg.channels, p->cfg.sample_format == AF_PCM_I16,
                            (int)grid, smem, as_stream(stream));
 }
 
-af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t mel_cap)
+af_status af_features_run(af_features* p, const void* pcm, size_t pcm_len, float* mel, size_t mel_cap)
 {
     AF_REQUIRE(p, "af_features_run: null handle");
+    const size_t need_in = (size_t)p->total_pcm_frames * p->cfg.channels;
+    if (pcm_len < need_in)
+        return fail(AF_ERR_BUFFER_TOO_SMALL, "pcm buffer holds %zu samples, the batch describes %zu", pcm_len,
+                    need_in);
     const size_t n_out = (size_t)p->total_frames * af_features_row_len(p);
     if (mel_cap < n_out)
         return fail(AF_ERR_BUFFER_TOO_SMALL, "mel buffer holds %zu floats, need %zu", mel_cap, n_out);
@@ -572,8 +567,8 @@ af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t me
     return AF_OK;
 }
 
-af_status af_pipeline_run(const af_batch_desc* batch, const void* pcm, float* out, size_t out_cap,
-                          size_t* total_rows_out)
+af_status af_pipeline_run(const af_batch_desc* batch, const void* pcm, size_t pcm_len, float* out,
+                          size_t out_cap, size_t* total_rows_out)
 {
     AF_REQUIRE(batch && (batch->clip_offsets || batch->n_clips == 0), "af_pipeline_run: null batch");
     af_features* p = nullptr;
@@ -581,7 +576,7 @@ af_status af_pipeline_run(const af_batch_desc* batch, const void* pcm, float* ou
     size_t total = 0;
     af_status st = af_features_set_batch(p, batch->clip_offsets, batch->n_clips, &total);
     if (total_rows_out) *total_rows_out = total;
-    if (st == AF_OK && !(out == nullptr && out_cap == 0)) st = af_features_run(p, pcm, out, out_cap);
+    if (st == AF_OK && !(out == nullptr && out_cap == 0)) st = af_features_run(p, pcm, pcm_len, out, out_cap);
     af_features_destroy(p);
     return st;
 }
@@ -696,10 +691,10 @@ af_status af_stft_power_device(af_stft* s, const void* pcm_dev, float* power_dev
     AF_REQUIRE(s, "af_stft_power_device: null handle");
     return af_features_run_device(s->f, pcm_dev, power_dev, stream);
 }
-af_status af_stft_power(af_stft* s, const void* pcm, float* power, size_t power_cap)
+af_status af_stft_power(af_stft* s, const void* pcm, size_t pcm_len, float* power, size_t power_cap)
 {
     AF_REQUIRE(s, "af_stft_power: null handle");
-    return af_features_run(s->f, pcm, power, power_cap);
+    return af_features_run(s->f, pcm, pcm_len, power, power_cap);
 }
 
 // ---- MelFilterbank: weights + the stand-alone contraction ------------------------------------

@@ -394,13 +394,8 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         float wf[NSLOT * kSlotSteps];
         {
             float ur[16], ui[16];
-#ifdef AF_V2_PRIO
-            if (w < 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
             fft_pair_1(tile, wb, wv, w, lane, wtab, tw1, ur, ui);
-#ifdef AF_V2_PRIO
-            if (w < 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
-#endif
+
             AF_STAMP2(2);
             // This wave's filterbank fragments (L2-resident, one float4 per slot), issued where the
             // register pressure has dropped and early enough to be back for the mel phase.
@@ -421,10 +416,10 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         }
         AF_STAMP2(3);
 
-#ifdef AF_V2_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __syncthreads();                             // B2: power rows ready, tile reads done
+        // the tile update and the mel phase hold up the next unit's FFT and issue few instructions:
+        // let them go ahead of the other workgroup's FFT stream
+        __builtin_amdgcn_s_setprio(2);
         AF_STAMP2(4);
 
         if (has_next) {
@@ -511,6 +506,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         AF_STAMP2(6);
         ++u;
         fresh = !has_next;

@@ -6,6 +6,7 @@
 // error behaviour as the reference:
 //
 //   AudioFrame::to_mono                 capture.rs:30
+//   RingBuffer::{new_, write, read, available, clear}                     capture.rs:93-160
 //   AudioResampler::{new_, create_48k_to_16k, process, input_rate, ...}   resampler.rs:32-108
 //   BatchResampler::{new_, process, flush}                                resampler.rs:121-166
 //   VoiceActivityDetector::{detect, reset, state, is_speaking, ...}       vad.rs:80-205
@@ -18,6 +19,7 @@
 
 #include <cstdint>
 #include <limits>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -62,6 +64,40 @@ struct AudioFrame {
         mono.resize(n);
         return AudioFrame{std::move(mono), sample_rate, 1, timestamp_ns};
     }
+};
+
+// capture.rs:84-161: mutex-guarded f32 ring, capacity - 1 usable slots
+class RingBuffer {
+public:
+    static RingBuffer new_(size_t capacity_samples)                              // capture.rs:93
+    {
+        af_ring* h = nullptr;
+        detail::check(af_ring_create(capacity_samples, &h));
+        return RingBuffer(h);
+    }
+    RingBuffer(RingBuffer&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    RingBuffer(const RingBuffer&) = delete;
+    RingBuffer& operator=(const RingBuffer&) = delete;
+    ~RingBuffer() { af_ring_destroy(h_); }
+
+    size_t write(const std::vector<float>& data) { return af_ring_write(h_, data.data(), data.size()); }   // :103
+    size_t write(const float* data, size_t n) { return af_ring_write(h_, data, n); }
+    std::optional<std::vector<float>> read(size_t size)                           // :125, nullopt = None
+    {
+        std::vector<float> out(size < af_ring_capacity(h_) ? size : af_ring_capacity(h_));
+        size_t n = 0;
+        int none = 0;
+        detail::check(af_ring_read(h_, size, out.data(), out.size(), &n, &none));
+        if (none) return std::nullopt;
+        out.resize(n);
+        return out;
+    }
+    size_t available() const { return af_ring_available(h_); }                    // :148
+    void clear() { af_ring_clear(h_); }                                           // :155
+
+private:
+    explicit RingBuffer(af_ring* h) : h_(h) {}
+    af_ring* h_;
 };
 
 // resampler.rs:12-109
@@ -259,7 +295,7 @@ public:
         size_t total = 0;
         detail::check(af_stft_set_batch_uniform(h_, 1, pcm.size() / channels, &total));
         std::vector<float> out(total * n_bins());
-        detail::check(af_stft_power(h_, pcm.data(), out.data(), out.size()));
+        detail::check(af_stft_power(h_, pcm.data(), pcm.size(), out.data(), out.size()));
         return out;
     }
 
@@ -335,11 +371,12 @@ public:
         size_t total = 0;
         detail::check(af_features_set_batch(h_, off.data(), frames.size(), &total));
         std::vector<float> mel(total * cfg_.n_mels);
-        detail::check(af_features_run(h_, pcm.data(), mel.data(), mel.size()));
+        detail::check(af_features_run(h_, pcm.data(), pcm.size(), mel.data(), mel.size()));
         std::vector<MelSpectrogram> out;
         size_t row = 0;
         for (size_t i = 0; i < frames.size(); ++i) {
-            const size_t nf = n_frames((size_t)(off[i + 1] - off[i]));
+            // AF_CH_SEPARATE: channel-0 rows then channel-1 rows of the clip
+            const size_t nf = (cfg_.channel_mode == AF_CH_SEPARATE ? 2 : 1) * n_frames((size_t)(off[i + 1] - off[i]));
             MelSpectrogram m;
             m.n_frames = nf;
             m.n_mels = cfg_.n_mels;
@@ -353,6 +390,49 @@ public:
 private:
     af_features_config cfg_;
     af_features* h_ = nullptr;
+};
+
+// BASELINE config 5: the fused path over an unbounded stream in fixed, hipGraph-replayed steps
+// (af_stream_*).  push() returns the rows of every step it completed, flush() the last partial step.
+class FeatureStream {
+public:
+    explicit FeatureStream(size_t step_frames = (size_t)1 << 20, const af_features_config* features = nullptr)
+    {
+        af_stream_config cfg;
+        af_stream_default_config(&cfg);
+        if (features) cfg.features = *features;
+        cfg.step_frames = step_frames;
+        channels_ = cfg.features.channels;
+        detail::check(af_stream_create(&cfg, &h_));
+    }
+    FeatureStream(const FeatureStream&) = delete;
+    FeatureStream& operator=(const FeatureStream&) = delete;
+    ~FeatureStream() { af_stream_destroy(h_); }
+
+    size_t row_len() const { return af_stream_row_len(h_); }
+    size_t total_rows(uint64_t n_frames) const { return af_stream_total_rows(h_, n_frames); }
+    std::vector<float> push(const std::vector<float>& pcm)
+    {
+        const size_t n_frames = pcm.size() / channels_;
+        std::vector<float> rows(af_stream_max_rows(h_, n_frames) * row_len());
+        size_t n = 0;
+        detail::check(af_stream_push(h_, pcm.data(), n_frames, rows.data(), rows.size(), &n));
+        rows.resize(n * row_len());
+        return rows;
+    }
+    std::vector<float> flush()
+    {
+        std::vector<float> rows(af_stream_rows_per_step(h_) * row_len());
+        size_t n = 0;
+        detail::check(af_stream_flush(h_, rows.data(), rows.size(), &n));
+        rows.resize(n * row_len());
+        return rows;
+    }
+    void reset() { detail::check(af_stream_reset(h_)); }
+
+private:
+    af_stream* h_ = nullptr;
+    uint32_t channels_ = 2;
 };
 
 }  // namespace audioflow

@@ -50,6 +50,12 @@ const char* af_last_error(void);
 const char* af_version(void);
 /* number of visible HIP devices (0 if none; never fails) */
 int         af_device_count(void);
+/* Diagnostics only (no reference counterpart): process-wide switches used by the tests and the
+ * profiling scripts; value 0 restores the product behaviour.
+ *   "features.kernel"     1: the general fused STFT+mel kernel also where the hop-256 kernel applies
+ *   "features.wg_per_cu"  workgroups per CU of the fused kernels
+ *   "banded.off"          1: resampler / FIR on the thread-per-output kernels instead of MFMA */
+af_status   af_debug_set(const char* key, int value);
 
 /* ------------------------------------------------------------------ [R] */
 /* AudioFrame::to_mono, modules/audio/capture.rs:30-42.
@@ -264,8 +270,10 @@ af_status af_features_set_batch_spans(af_features* p, const int64_t* starts,
 /* enqueue the fused kernel on `stream` for the batch set above */
 af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel_dev,
                                  void* stream);
-/* host buffers: H2D, run, D2H, synchronise */
-af_status af_features_run(af_features* p, const void* pcm, float* mel, size_t mel_cap);
+/* host buffers: H2D, run, D2H, synchronise.  pcm_len = elements (samples) the caller's buffer holds;
+ * fewer than the batch describes (total PCM frames * channels) is AF_ERR_BUFFER_TOO_SMALL, never an
+ * out-of-bounds read (the same holds for af_stft_power, af_chain_run and af_pipeline_run) */
+af_status af_features_run(af_features* p, const void* pcm, size_t pcm_len, float* mel, size_t mel_cap);
 /* One-shot form of the above for callers without a handle (the `af_pipeline_run(batch desc,
  * pcm, mel_out)` of SURVEY.md section 8(b)): creates the pipeline described by `cfg`, runs the
  * batch whose clip c occupies PCM frames [clip_offsets[c], clip_offsets[c+1]) of `pcm` (host
@@ -276,8 +284,8 @@ typedef struct {
     size_t n_clips;
     const int64_t* clip_offsets;   /* n_clips + 1 monotone frame offsets */
 } af_batch_desc;
-af_status af_pipeline_run(const af_batch_desc* batch, const void* pcm, float* out, size_t out_cap,
-                          size_t* total_rows_out);
+af_status af_pipeline_run(const af_batch_desc* batch, const void* pcm, size_t pcm_len, float* out,
+                          size_t out_cap, size_t* total_rows_out);
 /* the filterbank the device uses: W[n_mels][n_fft/2+1] f32 */
 af_status af_features_mel_weights(const af_features* p, float* W, size_t cap);
 /* name and launch geometry of the fused kernel, for profiling harnesses */
@@ -311,7 +319,7 @@ af_status af_stft_set_batch_uniform(af_stft* s, size_t n_clips, size_t frames_pe
 af_status af_stft_set_batch(af_stft* s, const int64_t* clip_offsets, size_t n_clips,
                             size_t* total_frames_out);
 af_status af_stft_power_device(af_stft* s, const void* pcm_dev, float* power_dev, void* stream);
-af_status af_stft_power(af_stft* s, const void* pcm, float* power, size_t power_cap);
+af_status af_stft_power(af_stft* s, const void* pcm, size_t pcm_len, float* power, size_t power_cap);
 
 /* MelFilterbank (docs/OPS.md "Mel filterbank"): weights and the stand-alone contraction
  * mel[f][m] = sum_k W[m][k] power[f][k] on MFMA, for callers that keep the power spectrum. */
@@ -356,7 +364,53 @@ size_t    af_chain_n_frames(const af_chain* c, size_t n_pcm_frames);
 af_status af_chain_set_batch_uniform(af_chain* c, size_t n_clips, size_t frames_per_clip,
                                      size_t* total_frames_out);
 af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev, void* stream);
-af_status af_chain_run(af_chain* c, const float* pcm, float* mel, size_t mel_cap);
+af_status af_chain_run(af_chain* c, const float* pcm, size_t pcm_len, float* mel, size_t mel_cap);
+
+/* ------------------------------------------------------------------ [R]
+ * RingBuffer, modules/audio/capture.rs:84-161 (tests :426-561): mutex-guarded f32 ring between
+ * the capture callback and the consumer.  capacity - 1 samples are usable (:111); a write that
+ * does not fit is truncated and returns what it stored (:103-122); a read returns
+ * min(size, available) samples; *is_none (optional) = 1 is the reference's `None` for an empty
+ * ring, as opposed to `Some(vec![])` for size == 0 (:125-145). */
+typedef struct af_ring af_ring;
+af_status af_ring_create(size_t capacity_samples, af_ring** out);       /* RingBuffer::new */
+void      af_ring_destroy(af_ring* r);
+size_t    af_ring_capacity(const af_ring* r);
+size_t    af_ring_write(af_ring* r, const float* data, size_t n);       /* samples stored */
+af_status af_ring_read(af_ring* r, size_t size, float* out, size_t out_cap, size_t* n_read, int* is_none);
+size_t    af_ring_available(af_ring* r);
+void      af_ring_clear(af_ring* r);
+
+/* ------------------------------------------------------------------ [B]
+ * FeatureStream: the fused STFT+mel path over an unbounded stream in fixed steps (BASELINE
+ * config 5).  The handle owns page-locked staging, the device buffer [n_fft - hop carried frames |
+ * step_frames new frames], the carry and ONE hipGraph (H2D copy, fused kernel, carry, D2H copy)
+ * captured at create and replayed per step; step k emits the step_frames / hop frames that start in
+ * [k step_frames, (k + 1) step_frames) once their last sample has arrived.  The rows of all pushes +
+ * the flush, in order, are bit-identical to one-shot framing of the whole stream (frame f = samples
+ * [f hop, f hop + n_fft)).  Reference analogue of the carry / flush: BatchResampler,
+ * modules/audio/resampler.rs:132-166; of the feeder loop: capture.rs:247-325. */
+typedef struct af_stream af_stream;
+typedef struct {
+    af_features_config features;   /* channel_mode must be AF_CH_DOWNMIX */
+    size_t step_frames;            /* PCM frames per replayed step: a multiple of 16 * hop, >= n_fft */
+} af_stream_config;
+void      af_stream_default_config(af_stream_config* cfg);              /* features defaults, 2^20 frames */
+af_status af_stream_create(const af_stream_config* cfg, af_stream** out);
+void      af_stream_destroy(af_stream* s);
+size_t    af_stream_rows_per_step(const af_stream* s);                  /* step_frames / hop */
+size_t    af_stream_row_len(const af_stream* s);
+size_t    af_stream_total_rows(const af_stream* s, uint64_t n_frames);  /* after push(es) + flush */
+size_t    af_stream_max_rows(const af_stream* s, size_t n_frames);      /* of the next push of n_frames */
+/* feed n_frames of interleaved host PCM; every completed step replays the graph and appends its
+ * rows to rows_out (capacity in floats); *n_rows = rows written by this call */
+af_status af_stream_push(af_stream* s, const void* pcm, size_t n_frames, float* rows_out, size_t rows_cap,
+                         size_t* n_rows);
+/* end of stream: the rows of the last, partial step */
+af_status af_stream_flush(af_stream* s, float* rows_out, size_t rows_cap, size_t* n_rows);
+af_status af_stream_reset(af_stream* s);                                /* start a new stream */
+/* stats[4] = {device ms of the last replayed step, host wall ms of it, steps so far, rows so far} */
+af_status af_stream_stats(const af_stream* s, double* stats);
 
 #ifdef __cplusplus
 }

@@ -90,7 +90,7 @@ try:
     mp = torch.empty(mel.shape, dtype=torch.float32).pin_memory()
     import ctypes as _C
     def run_pinned():
-        st = lib.af_features_run(pipe._h, _C.c_void_p(hp.data_ptr()), _C.c_void_p(mp.data_ptr()), mp.numel())
+        st = lib.af_features_run(pipe._h, _C.c_void_p(hp.data_ptr()), hp.numel(), _C.c_void_p(mp.data_ptr()), mp.numel())
         assert st == 0
     run_pinned()
     t0 = time.perf_counter(); run_pinned(); dt = time.perf_counter() - t0

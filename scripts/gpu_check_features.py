@@ -25,7 +25,7 @@ def run(pcm_list, channels, sr=48000, hop=256, n_mels=80, fmt=0):
     tot = C.c_size_t(); check(lib.af_features_set_batch(h, offs.ctypes.data, len(pcm_list), C.byref(tot)))
     pcm = np.ascontiguousarray(np.concatenate(pcm_list)) if pcm_list else np.zeros(0, np.float32)
     mel = np.full((tot.value, n_mels), np.nan, np.float32)
-    check(lib.af_features_run(h, pcm.ctypes.data, mel.ctypes.data, mel.size))
+    check(lib.af_features_run(h, pcm.ctypes.data, pcm.size, mel.ctypes.data, mel.size))
     lib.af_features_destroy(h)
     return mel, offs
 

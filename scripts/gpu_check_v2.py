@@ -1,5 +1,5 @@
 """First-light check of the hop-256 kernel (features_v2.hip) on the GPU: aligned ragged batches in all
-four PCM formats against the float64 oracle and against the general kernel (AF_FEATURES_GENERAL=1),
+four PCM formats against the float64 oracle and against the general kernel (af_debug_set features.kernel = 1),
 power / log-mel / separate-channel outputs, then config-2 timing of both kernels."""
 import os, sys, time
 import numpy as np
@@ -11,14 +11,13 @@ from oracle import pyoracle as po
 from util import synth_clip, frame_rel_err
 
 def run(clips, ch, fmt=0, general=False, **kw):
-    if general: os.environ["AF_FEATURES_GENERAL"] = "1"
-    else: os.environ.pop("AF_FEATURES_GENERAL", None)
+    af.library().af_debug_set(b"features.kernel", 1 if general else 0)
     pipe = af.FeaturePipeline(sample_rate=48000, channels=ch, hop=256, sample_format=fmt, **kw)
     offs = np.zeros(len(clips) + 1, np.int64)
     for i, c in enumerate(clips): offs[i + 1] = offs[i] + c.size // ch
     pipe.set_batch(offs)
     out = pipe.run(np.concatenate(clips))
-    os.environ.pop("AF_FEATURES_GENERAL", None)
+    af.library().af_debug_set(b"features.kernel", 0)
     return pipe, out
 
 worst = 0.0
@@ -52,11 +51,10 @@ for kw in (dict(output=1), dict(log_mel=1), dict(channel_mode=1), dict(n_mels=40
     try:
         kw2 = dict(kw); sr = kw2.pop("sample_rate", 48000)
         def mk(general):
-            if general: os.environ["AF_FEATURES_GENERAL"] = "1"
-            else: os.environ.pop("AF_FEATURES_GENERAL", None)
+            af.library().af_debug_set(b"features.kernel", 1 if general else 0)
             p = af.FeaturePipeline(sample_rate=sr, channels=2, hop=256, **kw2)
             offs = np.cumsum([0] + [c.size // 2 for c in x]).astype(np.int64)
-            p.set_batch(offs); o = p.run(np.concatenate(x)); os.environ.pop("AF_FEATURES_GENERAL", None); return o
+            p.set_batch(offs); o = p.run(np.concatenate(x)); af.library().af_debug_set(b"features.kernel", 0); return o
         a, b = mk(False), mk(True)
         print(kw, a.shape, "max rel diff vs general", float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)), flush=True)
     except Exception as ex:

@@ -5,13 +5,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("ffi", os.path.join(ROOT, "audio-flow-rs_amd", "_ffi.py"))
 ffi = importlib.util.module_from_spec(spec); spec.loader.exec_module(ffi)
 lib = C.CDLL(os.environ.get("AF_LIB", ffi.LIB_PATH))
-for name in ["af_last_error", "af_features_default_config", "af_features_create", "af_features_destroy",
+for name in ["af_debug_set", "af_last_error", "af_features_default_config", "af_features_create", "af_features_destroy",
              "af_features_n_frames", "af_features_set_batch", "af_features_set_batch_uniform",
              "af_features_run", "af_features_run_device"]:
     r, a = ffi.SIGNATURES[name]; fn = getattr(lib, name); fn.restype = r; fn.argtypes = a
 def check(st):
     if st != 0: raise RuntimeError(lib.af_last_error().decode())
 n_clips = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+GENERAL = bool(os.environ.get("AF_FEATURES_GENERAL"))          # script-side switch only
+lib.af_debug_set(b"features.kernel", 1 if GENERAL else 0)
+if os.environ.get("AF_FEATURES_WG_PER_CU"): lib.af_debug_set(b"features.wg_per_cu", int(os.environ["AF_FEATURES_WG_PER_CU"]))
 n = 1440000
 dev = torch.device("cuda:0")
 pcm = (torch.rand(n_clips, n, 2, device=dev) * 2 - 1) * 0.3
@@ -39,7 +42,7 @@ check(lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), stream)); to
 out = np.zeros(32, np.uint64)
 check(lib.af_features_debug_stamps(h, 0, out.ctypes.data))
 units = tot.value / 16
-names = ["desc load", "fresh+B1", "pf issue+part1", "wf issue+part2", "B2 wait", "tile write", "mel", "-"] if not os.environ.get("AF_FEATURES_GENERAL") else ["B1 wait", "prefetch issue", "FFT phase", "B2 wait", "tile write", "mel operands", "mel mfma+store", "loop tail"]
+names = ["desc load", "fresh+B1", "pf issue+part1", "wf issue+part2", "B2 wait", "tile write", "mel", "-"] if not GENERAL else ["B1 wait", "prefetch issue", "FFT phase", "B2 wait", "tile write", "mel operands", "mel mfma+store", "loop tail"]
 per = out.reshape(4, 8).astype(np.float64) / units
 print("cycles per unit (iteration), per wave:")
 for i, nm in enumerate(names): print(f"  {nm:15s}", " ".join(f"{per[w, i]:9.0f}" for w in range(4)))

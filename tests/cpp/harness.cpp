@@ -2,6 +2,7 @@
 // mirror (include/audioflow.hpp) and therefore through the exact C-ABI entry points the Rust
 // shim of INTEGRATION.md binds.  Each check cites the #[test] it ports
 // (forfd8960/audio-flow-rs, src-tauri/src/...).  Needs an MI355X; exit code 0 = all passed.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -135,6 +136,41 @@ int main()
         auto lv = level_meter(std::vector<float>(1600, 0.5f), 800);
         CHECK(lv.size() == 2 && std::fabs(lv[0].rms - 0.5f) < 1e-6f && lv[1].peak == 0.5f);
         CHECK(std::fabs(lv[0].dbfs - 20.0f * std::log10(0.5f)) < 1e-4f);
+    }
+    // capture.rs:426-561 ring buffer suite through the C++ mirror
+    {
+        auto r = RingBuffer::new_(1024);                                   // :426-441 write / read
+        CHECK(r.write({1.0f, 2.0f, 3.0f, 4.0f, 5.0f}) == 5 && r.available() == 5);
+        auto got = r.read(5);
+        CHECK(got && *got == std::vector<float>({1.0f, 2.0f, 3.0f, 4.0f, 5.0f}) && r.available() == 0);
+        CHECK(!r.read(5));                                                 // :487-492 empty -> None
+        auto w = RingBuffer::new_(10);                                     // :459-471 wrap-around
+        CHECK(w.write({1, 2, 3, 4, 5, 6, 7}) == 7);
+        CHECK(w.read(5).value() == std::vector<float>({1, 2, 3, 4, 5}));
+        CHECK(w.write({8, 9, 10}) == 3);
+        CHECK(w.read(5).value() == std::vector<float>({6, 7, 8, 9, 10}));
+        auto o = RingBuffer::new_(10);                                     // :473-485 overflow: capacity - 1
+        CHECK(o.write(std::vector<float>(15, 1.0f)) == 9 && o.available() == 9);
+        o.clear();                                                         // :516-529
+        CHECK(o.available() == 0 && !o.read(1));
+    }
+    // FeatureStream (BASELINE config 5): stepped == one-shot, bit for bit
+    {
+        const size_t n = 16 * 256 * 5 + 999;
+        std::vector<float> x(2 * n);
+        for (size_t i = 0; i < x.size(); ++i) x[i] = 0.3f * std::sin(0.01f * (float)i) + 0.1f * std::sin(0.37f * (float)i);
+        FeatureStream st(16 * 256 * 2);
+        std::vector<float> rows;
+        for (size_t pos = 0; pos < n; pos += 3000) {
+            const size_t k = std::min<size_t>(3000, n - pos);
+            auto r = st.push(std::vector<float>(x.begin() + 2 * pos, x.begin() + 2 * (pos + k)));
+            rows.insert(rows.end(), r.begin(), r.end());
+        }
+        auto tail = st.flush();
+        rows.insert(rows.end(), tail.begin(), tail.end());
+        FeaturePipeline one;
+        auto full = one.process_batch({AudioFrame::new_(x, 48000, 2, 0)});
+        CHECK(full.size() == 1 && rows.size() == st.total_rows(n) * 80 && rows == full[0].data);
     }
     std::printf(failures ? "%d check(s) failed\n" : "harness ok\n", failures);
     return failures ? 1 : 0;

@@ -129,3 +129,62 @@ def test_chain_is_capturable_without_a_warm_up(af, po):
     got = mel.cpu().numpy()
     for i, x in enumerate(clips):
         assert frame_rel_err(got[i * nf:(i + 1) * nf], oracle_chain(po, x, 2, 48000, 16000, taps)) < 2e-5
+
+
+# ---- FeatureStream (af_stream_*): library-owned staging, halo carry and hipGraph step -----------
+def test_feature_stream_small_steps_vs_one_shot_and_oracle(af, po):
+    # ragged pushes over several steps, a partial last step, i16 and mono variants
+    for ch, fmt, n in [(2, 0, 16 * 256 * 7 + 1234), (1, 1, 16 * 256 * 3 + 77), (2, 0, 5000), (1, 0, 700)]:
+        x = synth_clip(300 + ch + fmt, n, ch, 48000)
+        if fmt:
+            x = np.round(x * 32767.0).astype(np.int16)
+        st = af.FeatureStream(step_frames=16 * 256 * 2, channels=ch, sample_format=fmt)
+        rng = np.random.default_rng(5)
+        rows, pos = [], 0
+        while pos < n:
+            k = int(rng.integers(0, 9000))
+            rows.append(st.push(x[pos * ch:(pos + k) * ch]))
+            pos += k
+        rows.append(st.flush())
+        got = np.concatenate(rows)
+        assert got.shape[0] == st.total_rows(n) == po.stft_n_frames(n)          # bookkeeping exact
+        one = af.FeaturePipeline(channels=ch, sample_format=fmt)
+        one.set_batch_uniform(1, n)
+        assert np.array_equal(got, one.run(x))                                    # bit for bit
+        if got.shape[0]:
+            xf = x.astype(np.float32) / np.float32(32768.0) if fmt else x
+            assert frame_rel_err(got, po.features(xf, ch, 48000.0)) < TOL
+        with pytest.raises(af.AudioError):
+            st.push(x[:8 * ch])                                                   # pushed after flush
+        st.reset()
+        assert st.push(x[:100 * ch]).shape[0] == 0
+
+
+def test_feature_stream_ten_minutes_bit_equal_to_one_shot(af):
+    """BASELINE config 5 through the product API: >= 10 min of 48 kHz stereo in fixed 2^20-frame
+    steps (one hipGraph replay each) == one-shot framing of the same signal, bit for bit."""
+    torch = pytest.importorskip("torch")
+    sr, ch, step = 48000, 2, 1 << 20
+    n = 10 * 60 * sr + 12345                                     # 28.8 M frames + a partial step
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.rand(n, ch, generator=gen) * 2 - 1).mul_(0.4).numpy()           # 230 MB f32
+    st = af.FeatureStream(step_frames=step)
+    rows, dev_ms, wall_ms = [], [], []
+    for pos in range(0, n, 300000):                              # feeder pushes ~6 s at a time
+        r = st.push(x[pos:pos + 300000])
+        if r.shape[0]:
+            s = st.stats()
+            dev_ms.append(s["device_ms"]); wall_ms.append(s["wall_ms"])
+        rows.append(r)
+    rows.append(st.flush())
+    got = np.concatenate(rows)
+    assert got.shape == (st.total_rows(n), 80) and st.stats()["steps"] == n // step == 27
+    one = af.FeaturePipeline()
+    one.set_batch_uniform(1, n)
+    full = one.run(x.reshape(-1))
+    assert np.array_equal(got, full)
+    # per-step latency (device time of the replayed graph incl. both PCIe copies, and host wall time)
+    print(f"\nfeature stream: {len(dev_ms)} steps of {step / sr:.1f} s audio; device ms/step "
+          f"median {np.median(dev_ms):.2f} max {np.max(dev_ms):.2f}; wall ms/step median {np.median(wall_ms):.2f}; "
+          f"real-time factor {step / sr / (np.median(wall_ms) * 1e-3):.0f}x")
+    assert np.median(wall_ms) * 1e-3 < step / sr / 100            # far faster than real time

@@ -63,6 +63,36 @@ def test_ragged_batch_vs_oracle(af, po, ch, hop):
     assert np.all(np.isfinite(mel))
 
 
+@pytest.mark.parametrize("ch", [1, 2])
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_hop256_kernel_aligned_ragged(af, po, ch, fmt):
+    """Clip bases on 16-byte boundaries at hop 256 select the 8-wave kernel (features_v2.hip):
+    empty / short / unit-boundary / long clips in all four PCM formats against the oracle and
+    against the general kernel (af_debug_set "features.kernel" = 1) on the same input."""
+    lens = [0, 1016, 1024, 1024 + 256 * 15, 1024 + 256 * 16, 1024 + 256 * 16 - 8, 7776, 50000, 8,
+            1024 + 256 * 47, 123456]
+    clips = [synth_clip(i, n, ch, 48000) for i, n in enumerate(lens)]
+    if fmt:
+        clips = [np.round(c * 32767.0).astype(np.int16) for c in clips]
+    lib = af.library()
+    pipe, mel = run_clips(af, clips, ch, fmt=fmt)
+    try:
+        assert lib.af_debug_set(b"features.kernel", 1) == 0
+        _, mel_g = run_clips(af, clips, ch, fmt=fmt)
+    finally:
+        lib.af_debug_set(b"features.kernel", 0)
+    row = 0
+    for n, x in zip(lens, clips):
+        xf = x.astype(np.float32) / np.float32(32768.0) if fmt else x
+        ref = po.features(xf, ch, 48000.0)
+        nf = ref.shape[0]
+        assert nf == pipe.n_frames(n)
+        assert frame_rel_err(mel[row:row + nf], ref) < TOL
+        assert frame_rel_err(mel[row:row + nf], mel_g[row:row + nf]) < TOL
+        row += nf
+    assert row == mel.shape[0] and np.all(np.isfinite(mel))
+
+
 def test_unaligned_clip_offsets_take_the_scalar_path(af, po):
     # odd frame offsets break 16-byte alignment of the clip bases: same results required
     lens = [3001, 2047, 4099]
@@ -210,9 +240,18 @@ def test_one_shot_pipeline_run(af, po):
     d.n_clips = len(lens)
     d.clip_offsets = offs.ctypes.data
     total = C.c_size_t()
-    assert af.library().af_pipeline_run(C.byref(d), None, None, 0, C.byref(total)) == 0
+    assert af.library().af_pipeline_run(C.byref(d), None, 0, None, 0, C.byref(total)) == 0
     assert total.value == sum(po.stft_n_frames(n) for n in lens)
     out = np.empty((total.value, 80), np.float32)
-    assert af.library().af_pipeline_run(C.byref(d), pcm.ctypes.data, out.ctypes.data, out.size, C.byref(total)) == 0
+    assert af.library().af_pipeline_run(C.byref(d), pcm.ctypes.data, pcm.size, out.ctypes.data, out.size, C.byref(total)) == 0
     ref = np.concatenate([po.features(c, 2, 48000.0) for c in clips])
     assert frame_rel_err(out, ref) < TOL
+    # a PCM buffer shorter than the batch describes is refused, not read out of bounds
+    st = af.library().af_pipeline_run(C.byref(d), pcm.ctypes.data, pcm.size - 1, out.ctypes.data, out.size,
+                                      C.byref(total))
+    assert st == af._ffi.AF_ERR_BUFFER_TOO_SMALL
+    pipe = af.FeaturePipeline()
+    pipe.set_batch(offs)
+    with pytest.raises(af.AudioError) as e:
+        pipe.run(pcm[:-2])
+    assert e.value.status == af._ffi.AF_ERR_BUFFER_TOO_SMALL

@@ -70,6 +70,21 @@ def test_separate_channels(af, po, fmt):
     assert row == total == 2 * sum(pipe.n_frames(n) for n in lens)
 
 
+def test_separate_channels_process_batch(af, po):
+    # process_batch in separate mode: clip i's rows are [channel 0 frames | channel 1 frames]
+    lens = [6000, 1024, 3000]
+    frames = [af.AudioFrame.new(synth_clip(700 + i, n, 2, 48000), 48000, 2, 0) for i, n in enumerate(lens)]
+    pipe = af.FeaturePipeline(channel_mode=af._ffi.AF_CH_SEPARATE)
+    out = pipe.process_batch(frames)
+    for f, m, n in zip(frames, out, lens):
+        nf = po.stft_n_frames(n)
+        assert m.data.shape[0] == 2 * nf
+        x = f.samples.reshape(-1, 2)
+        for c in range(2):
+            ref = po.features(np.ascontiguousarray(x[:, c]), 1, 48000.0)
+            assert frame_rel_err(m.data[c * nf:(c + 1) * nf], ref) < TOL
+
+
 def test_separate_needs_stereo(af):
     with pytest.raises(af.AudioError):
         af.FeaturePipeline(channels=1, channel_mode=af._ffi.AF_CH_SEPARATE)

@@ -59,6 +59,42 @@ def test_ring_buffer_matches_oracle_on_random_traffic(af, po):
         assert a.available() == b.available()
 
 
+def test_ring_buffer_c_abi_directly(af):
+    """af_ring_* without the Python class: `None` vs `Some(vec![])` (capture.rs:131-135), capacity - 1
+    usable slots (:111), truncated writes, a read into too small a buffer, a writer thread (:546-561)."""
+    import ctypes as C
+    import threading
+    lib = af.library()
+    h = C.c_void_p()
+    assert lib.af_ring_create(10, C.byref(h)) == 0 and lib.af_ring_capacity(h) == 10
+    out = np.zeros(16, np.float32)
+    n, none = C.c_size_t(), C.c_int()
+    assert lib.af_ring_read(h, 4, out.ctypes.data, out.size, C.byref(n), C.byref(none)) == 0
+    assert (n.value, none.value) == (0, 1)                              # empty -> None
+    x = np.arange(1, 16, dtype=np.float32)
+    assert lib.af_ring_write(h, x.ctypes.data, x.size) == 9            # capacity - 1
+    assert lib.af_ring_available(h) == 9
+    assert lib.af_ring_read(h, 0, out.ctypes.data, out.size, C.byref(n), C.byref(none)) == 0
+    assert (n.value, none.value) == (0, 0)                              # Some(vec![])
+    assert lib.af_ring_read(h, 5, out.ctypes.data, 3, C.byref(n), None) == af._ffi.AF_ERR_BUFFER_TOO_SMALL
+    assert lib.af_ring_available(h) == 9                                # nothing consumed by the failed read
+    assert lib.af_ring_read(h, 5, out.ctypes.data, out.size, C.byref(n), None) == 0 and n.value == 5
+    assert np.array_equal(out[:5], x[:5])
+    assert lib.af_ring_write(h, x.ctypes.data, 7) == 5                  # wraps, truncated to the free slots
+    assert lib.af_ring_read(h, 100, out.ctypes.data, out.size, C.byref(n), None) == 0 and n.value == 9
+    assert np.array_equal(out[:9], np.concatenate([x[5:9], x[:5]]))
+    lib.af_ring_clear(h)
+    assert lib.af_ring_available(h) == 0
+    t = threading.Thread(target=lambda: lib.af_ring_write(h, x.ctypes.data, 3))
+    t.start(); t.join()
+    assert lib.af_ring_available(h) == 3
+    lib.af_ring_destroy(h)
+    z = C.c_void_p()
+    assert lib.af_ring_create(0, C.byref(z)) == 0                       # the reference would divide by zero
+    assert lib.af_ring_write(z, x.ctypes.data, 3) == 0 and lib.af_ring_available(z) == 0
+    lib.af_ring_destroy(z)
+
+
 def test_audio_error_rendering(af):
     e = af.AudioError.resampling_failed("boom")
     assert str(e) == "Resampling failed: boom"                  # error.rs:109
