@@ -590,7 +590,7 @@ af_status af_features_mel_weights(const af_features* p, float* W, size_t cap)
     return AF_OK;
 }
 
-const char* af_features_kernel_name(void) { return "af_features_kernel"; }
+const char* af_features_kernel_name(void) { return "af_features_v2_kernel"; }   // the BASELINE configuration (hop 256); other hops: af_features_kernel
 
 // diagnostics, host only: the mel plans -- info[17] = {groups, K-steps, slots of wave 0..3} of the
 // general kernel, then {waves (0: not in use), groups, K-steps, slots of wave 0..7} of the hop-256 kernel

@@ -9,14 +9,18 @@ One "step" = one pass of that kernel over the whole batch.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, every rank owns its own 256-clip shard (clips are
-independent: weak scaling, no data-path collective); the barrier, the
-max-over-ranks time and the unit count are the only collectives (RCCL).
+N > 1: one process per GPU, every rank owns a contiguous clip range (clips are independent: no
+data-path collective).  --scaling weak (default): 256 clips per GPU; --scaling strong: --total-clips
+(8192 = BASELINE config 4) split over the GPUs.  The barrier, the max-over-ranks time and the unit
+count are the only collectives of the timed region (RCCL); the optional mel all-gather and the root
+scatter of PCM shards are timed separately afterwards (gather_ms / scatter_ms, null at N = 1).
 
 Prints ONE JSON line on rank 0 (contract in the task statement):
   value     = spectrogram frames/s of the whole job, inputs resident in HBM
   roofline  = algorithmic bytes per launch / measured launch time vs 8 TB/s HBM
   cpu_baseline = the oracle's float32 port timed on this host (rank 0, N=1 only)
+  check     = three clips of the result against the float64 oracle, after the timed region
+  secondary = BASELINE config 4's chain on the same shard (N=1 only)
 """
 from __future__ import annotations
 
@@ -104,14 +108,154 @@ def cpu_baseline(pcm_host, n_clips: int, n_frames: int) -> dict:
     }
 
 
+def time_collectives(torch, dist, dev, mel, pcm, world: int, rank: int) -> dict:
+    """the two optional collectives of a sharded job, timed apart from the
+    kernel (they are not on the measured path: every rank ingests its own shard).
+      gather_ms   all-gather of the ranks' mel rows (RCCL over xGMI), what a caller needs when the
+                  whole batch's spectrograms must end up on every rank
+      scatter_ms  root scatter of one PCM shard per rank (rank 0 fans out over its xGMI links)
+    MAX over ranks, null at N = 1.  Also returns what the communicator itself reports."""
+    from audio_flow_rs_amd.shard import max_over_ranks
+    if world == 1:
+        return {"gather_ms": None, "scatter_ms": None, "ranks_seen": 1, "backend": None,
+                "gather_bytes_per_rank": None, "scatter_bytes_per_rank": None}
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)                                  # how many ranks does the communicator hold?
+    ranks_seen = int(ones.item())
+
+    def timed(fn, reps=3):
+        fn()                                               # connections / buffers set up on first use
+        torch.cuda.synchronize() if dev.type == "cuda" else None
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        dist.barrier()
+        return max_over_ranks((time.perf_counter() - t0) / reps * 1e3, dev)
+
+    bufs = [torch.empty_like(mel) for _ in range(world)]
+    gather_ms = timed(lambda: dist.all_gather(bufs, mel))
+    del bufs
+    flat = pcm.reshape(-1)
+    out = torch.empty_like(flat)
+    scatter_ms = timed(lambda: dist.scatter(out, [flat] * world if rank == 0 else None, src=0))
+    return {"gather_ms": gather_ms, "scatter_ms": scatter_ms, "ranks_seen": ranks_seen,
+            "backend": dist.get_backend(),
+            "gather_bytes_per_rank": mel.numel() * mel.element_size() * world,
+            "scatter_bytes_per_rank": flat.numel() * flat.element_size()}
+
+
+def make_result(m: dict) -> dict:
+    """The JSON line from the measurements (pure: tests/test_bench_schema.py builds it on the CPU)."""
+    steps = m["steps"]
+    ms_per_step = m["wall_s"] / steps * 1e3
+    alg_bytes = m["clips_local"] * m["pcm_frames_per_clip"] * CHANNELS * 4 + m["frames_local"] * N_MELS * 4
+    achieved = alg_bytes / (m["kernel_ms"] * 1e-3) / 1e9
+    coll = m["collectives"]
+    return {
+        "metric": "spectrogram frames/sec (whole node) + real-time factor, 48 kHz stereo batch",
+        "value": m["frames_all"] / (m["wall_s"] / steps),
+        "unit": "frames/s",
+        "rtf": m["audio_seconds_all"] / (m["wall_s"] / steps),
+        "n_gpus": m["world"],
+        "steps": steps,
+        "warmup": m["warmup"],
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": m["scaling"],
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"BASELINE config 2: {m['clips_local']} x {CLIP_SECONDS} s stereo {SR} Hz f32 per GPU "
+                         f"-> to_mono -> STFT {N_FFT}/{HOP} Hann -> |X|^2 -> {N_MELS} mel (fused)"
+                         if m["scaling"] == "weak" else
+                         f"BASELINE config 4 sharding: {m['clips_total']} x {CLIP_SECONDS} s stereo {SR} Hz f32 clips "
+                         f"split over {m['world']} GPU(s) -> fused STFT + {N_MELS} mel"),
+            "clips_per_gpu": m["clips_local"], "clips_total": m["clips_total"],
+            "frames_per_gpu": m["frames_local"],
+            "sharding": "contiguous clip ranges, one process per GPU, no data-path collective",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": m.get("traffic"),
+            "traffic_source": m.get("traffic_source"),
+            "kernel": m["kernel"], "kernel_ms": m["kernel_ms"],
+            "algorithmic_bytes_per_launch": alg_bytes,
+        },
+        # SURVEY.md 8(e): collectives timed apart from the kernel; "not measured" (null) at N = 1
+        "ranks_seen": coll["ranks_seen"],
+        "collective_backend": coll["backend"],
+        "gather_ms": coll["gather_ms"],
+        "scatter_ms": coll["scatter_ms"],
+        "gather_bytes_per_rank": coll["gather_bytes_per_rank"],
+        "scatter_bytes_per_rank": coll["scatter_bytes_per_rank"],
+        "check": m.get("check"),
+        "secondary": m.get("secondary"),
+        "cpu_baseline": m.get("cpu_baseline"),
+    }
+
+
+def oracle_check(pcm, mel, n_frames_pcm: int, frames_per_clip: int, n_clips: int) -> dict:
+    """Outside the timed region: three clips of this rank's shard (first, middle, last) through the
+    float64 oracle; the worst per-frame relative error of the kernel's rows (tolerance 1e-5)."""
+    import numpy as np
+    from oracle import pyoracle as po
+    picks = sorted({0, n_clips // 2, n_clips - 1})
+    worst = 0.0
+    for c in picks:
+        x = pcm[c].reshape(-1).cpu().numpy()
+        ref = po.features(x, CHANNELS, float(SR), hop=HOP, n_mels=N_MELS)
+        got = mel[c * frames_per_clip:(c + 1) * frames_per_clip].cpu().numpy().astype(np.float64)
+        err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-300)
+        worst = max(worst, float(err.max()))
+    return {"clips": picks, "max_rel_err": worst, "tol": 1e-5, "ok": worst < 1e-5,
+            "against": "float64 oracle (oracle/af_oracle.c), per-frame ||got - ref|| / ||ref||"}
+
+
+def chain_secondary(torch, af, dev, pcm, n_clips: int, n_frames_pcm: int, stream) -> dict:
+    """BASELINE config 4's chain on this GPU's shard (stereo 48 k -> downmix + 48->16 kHz polyphase ->
+    FIR 129 -> STFT -> 80 mel), timed with HIP events; reported beside the headline, never as `value`."""
+    import numpy as np
+    n = np.arange(129) - 64.0
+    taps = (2 * 7200.0 / 16000.0 * np.sinc(2 * 7200.0 / 16000.0 * n) * np.hamming(129)).astype(np.float32)
+    chain = af.ChainPipeline(input_rate=SR, channels=CHANNELS, output_rate=16000, fir_taps=taps)
+    total = chain.set_batch_uniform(n_clips, n_frames_pcm)
+    out = torch.empty(total, N_MELS, device=dev, dtype=torch.float32)
+    for _ in range(2):
+        chain.run_device(pcm.data_ptr(), out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        chain.run_device(pcm.data_ptr(), out.data_ptr(), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg = n_clips * n_frames_pcm * CHANNELS * 4 + total * N_MELS * 4
+    return {"chain": {"workload": f"{n_clips} x {CLIP_SECONDS} s stereo {SR} Hz -> 16 kHz -> FIR 129 -> STFT -> {N_MELS} mel",
+                      "ms": ms, "frames": total, "rtf": n_clips * CLIP_SECONDS / (ms * 1e-3),
+                      "algorithmic_bytes": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9,
+                      "frac_hbm": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "launches": chain.n_launches() if hasattr(chain, "n_launches") else None}}
+
+
 def main() -> None:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
+    ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --clips per GPU (BASELINE config 2 per GPU); strong: --total-clips split "
+                         "over the GPUs (BASELINE config 4's 8192 / N)")
+    ap.add_argument("--total-clips", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=256)
     args = ap.parse_args()
 
@@ -119,7 +263,7 @@ def main() -> None:
     import torch.distributed as dist
 
     import audio_flow_rs_amd as af
-    from audio_flow_rs_amd.shard import max_over_ranks, sum_over_ranks
+    from audio_flow_rs_amd.shard import max_over_ranks, shard_range, sum_over_ranks
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -142,8 +286,12 @@ def main() -> None:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_frames_pcm = CLIP_SECONDS * SR
-    n_clips = args.clips
-    pcm = synth_batch(torch, dev, rank * n_clips, n_clips, n_frames_pcm)
+    if args.scaling == "strong":
+        first_clip, last_clip = shard_range(args.total_clips, world, rank)
+        n_clips, clips_total = last_clip - first_clip, args.total_clips
+    else:
+        n_clips, first_clip, clips_total = args.clips, rank * args.clips, args.clips * world
+    pcm = synth_batch(torch, dev, first_clip, n_clips, n_frames_pcm)
 
     pipe = af.FeaturePipeline(sample_rate=SR, channels=CHANNELS, n_fft=N_FFT, hop=HOP,
                               n_mels=N_MELS, device=local_rank)
@@ -173,61 +321,40 @@ def main() -> None:
     torch.cuda.synchronize()
     t1 = time.perf_counter()
 
-    wall = max_over_ranks(t1 - t0, dev)
-    kernel_ms = max_over_ranks(ev0.elapsed_time(ev1) / args.steps, dev)   # HIP events, same stream
-    frames_all = sum_over_ranks(float(total_frames), dev)
-    audio_seconds_all = sum_over_ranks(float(n_clips * CLIP_SECONDS), dev)
-
-    ms_per_step = wall / args.steps * 1e3
-    value = frames_all / (wall / args.steps)
-    # algorithmic bytes of ONE launch on one GPU: every stereo f32 input frame
-    # once (8 B) + every mel row once (80 x 4 B)
-    alg_bytes = n_clips * n_frames_pcm * CHANNELS * 4 + total_frames * N_MELS * 4
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tp):
-        try:
-            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    result = {
-        "metric": "spectrogram frames/sec (whole node) + real-time factor, 48 kHz stereo batch",
-        "value": value,
-        "unit": "frames/s",
-        "rtf": audio_seconds_all / (wall / args.steps),
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": f"BASELINE config 2: {n_clips} x {CLIP_SECONDS} s stereo {SR} Hz f32 per GPU "
-                        f"-> to_mono -> STFT {N_FFT}/{HOP} Hann -> |X|^2 -> {N_MELS} mel (fused)",
-            "clips_per_gpu": n_clips, "frames_per_gpu": total_frames,
-            "sharding": "contiguous clip ranges, one process per GPU, no data-path collective",
-        },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "af_features_kernel", "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_launch": alg_bytes,
-        },
+    m = {
+        "steps": args.steps, "warmup": args.warmup, "world": world, "scaling": args.scaling,
+        "wall_s": max_over_ranks(t1 - t0, dev),
+        "kernel_ms": max_over_ranks(ev0.elapsed_time(ev1) / args.steps, dev),   # HIP events, same stream
+        "frames_all": sum_over_ranks(float(total_frames), dev),
+        "audio_seconds_all": sum_over_ranks(float(n_clips * CLIP_SECONDS), dev),
+        "clips_local": n_clips, "clips_total": clips_total, "frames_local": total_frames,
+        "pcm_frames_per_clip": n_frames_pcm,
+        "kernel": af.library().af_features_kernel_name().decode(),
     }
+    # HBM bytes by PMC come from a separate rocprofv3 run (profiles/): quoted only for the
+    # configuration that run profiled, and labelled as recorded
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tp) and n_clips == CLIPS_PER_GPU:
+        try:
+            rec = json.load(open(tp))
+            m["traffic"] = rec.get("hbm_bytes_per_launch")
+            m["traffic_source"] = ("recorded: profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this "
+                                   f"workload, round {rec.get('round')}); not measured by this run")
+        except Exception:
+            pass
 
+    # ---- outside the timed region ----------------------------------------------------------
+    m["collectives"] = time_collectives(torch, dist, dev, mel, pcm, world, rank)
+    if rank == 0:
+        m["check"] = oracle_check(pcm, mel, n_frames_pcm, pipe.n_frames(n_frames_pcm), n_clips)
+    if rank == 0 and world == 1 and not args.no_secondary:
+        m["secondary"] = chain_secondary(torch, af, dev, pcm, n_clips, n_frames_pcm, stream)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         k = max(1, min(args.cpu_clips, n_clips))
-        result["cpu_baseline"] = cpu_baseline(pcm[:k].cpu().numpy(), k, n_frames_pcm)
-    elif rank == 0:
-        result["cpu_baseline"] = None
+        m["cpu_baseline"] = cpu_baseline(pcm[:k].cpu().numpy(), k, n_frames_pcm)
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(make_result(m)))
     if world > 1:
         dist.destroy_process_group()
 

@@ -42,6 +42,36 @@ def test_chain_vs_oracle(af, po, ch, fi, fo, with_fir):
         assert frame_rel_err(mel[i * nf:(i + 1) * nf], ref) < 2e-5
 
 
+def test_chain_config4_per_gpu_share(af, po):
+    # BASELINE config 4's share of one GPU: 1024 clips x 30 s stereo 48 kHz (11.8 GB) through the whole
+    # chain; every row written, duplicates identical, determinism, sampled clips against the oracle chain
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    n_clips, n = 1024, 1440000
+    taps = lowpass_taps()
+    chain = af.ChainPipeline(input_rate=48000, channels=2, output_rate=16000, fir_taps=taps)
+    total = chain.set_batch_uniform(n_clips, n)
+    nf = chain.n_frames(n)
+    assert nf == po.stft_n_frames(480000) == 1872 and total == n_clips * nf
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4)
+    pcm = torch.empty(n_clips, n, 2, device=dev)
+    for c0 in range(0, n_clips, 128):                               # in slices: torch.rand has no in-place form
+        pcm[c0:c0 + 128] = torch.rand(128, n, 2, device=dev, generator=gen).mul_(0.6).sub_(0.3)
+    pcm[1023] = pcm[5]
+    mel = torch.full((total, 80), float("nan"), device=dev)
+    mel2 = torch.empty_like(mel)
+    stream = torch.cuda.current_stream().cuda_stream
+    chain.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+    chain.run_device(pcm.data_ptr(), mel2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    m = mel.view(n_clips, nf, 80)
+    assert bool(torch.isfinite(mel).all()) and torch.equal(mel, mel2) and torch.equal(m[1023], m[5])
+    for c in (0, 512, 1022):
+        ref = oracle_chain(po, pcm[c].cpu().numpy().reshape(-1), 2, 48000, 16000, taps)
+        assert frame_rel_err(m[c].cpu().numpy(), ref) < 2e-5
+
+
 def test_chain_rejects_bad_config(af):
     with pytest.raises(af.AudioError):
         af.ChainPipeline(channels=3)

@@ -111,6 +111,32 @@ def test_batch_resampler_equal_rates_is_passthrough(af):
     assert b.flush().size == 0
 
 
+def test_resample_config3_full_size(af, po):
+    # BASELINE config 3 in full: 4096 mono clips x 441 000 samples @44.1 k (7.2 GB) -> 160 000 @16 k:
+    # every output written, duplicate clips identical, determinism, sampled clips against the oracle
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    dev = torch.device("cuda:0")
+    n_clips, n_in = 4096, 441000
+    lib = af.library()
+    n_out = lib.af_resample_out_len(44100, 16000, n_in)
+    assert n_out == 160000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    x = torch.rand(n_clips, n_in, device=dev, generator=gen).sub_(0.5)
+    x[4095] = x[17]
+    y = torch.full((n_clips, n_out), float("nan"), device=dev)
+    y2 = torch.empty_like(y)
+    for dst in (y, y2):
+        assert lib.af_resample_batch_device(44100, 16000, C.c_void_p(x.data_ptr()), n_clips, n_in,
+                                            C.c_void_p(dst.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all()) and torch.equal(y, y2) and torch.equal(y[4095], y[17])
+    for c in (0, 2048, 4094):
+        ref = po.resample(x[c].cpu().numpy(), 44100, 16000)
+        assert rel_err(y[c].cpu().numpy(), ref) < TOL
+
+
 def test_resample_full_size_property(af):
     # BASELINE config 3 shapes (a 64-clip slice): DC gain 1 and linearity at full length
     torch = pytest.importorskip("torch")
