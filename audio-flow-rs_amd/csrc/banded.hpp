@@ -41,6 +41,10 @@ struct Plan {
 // Decide whether (L, M, T) runs on the MFMA kernel and with which tile shape.
 Plan make_plan(uint32_t L, uint32_t M, int T, int c, int ch = 1);
 
+// Clips the MFMA kernel can address (32-bit buffer offsets); longer ones go to the caller's
+// thread-per-output kernel, which indexes with 64 bits.
+bool fits(const Plan& p, int64_t x_len);
+
 // Gather the A fragments [nb][NK][64] from the prototype (device, prototype order, L*T floats).
 af_status build_afrag(const Plan& p, const float* proto_dev, float* afrag_dev, hipStream_t stream);
 

@@ -294,6 +294,8 @@ Plan make_plan(uint32_t L, uint32_t M, int T, int c, int ch)
     return p;
 }
 
+bool fits(const Plan& p, int64_t x_len) { return p.ok && x_len * p.ch < (int64_t)kMaxClip; }
+
 af_status build_afrag(const Plan& p, const float* proto_dev, float* afrag_dev, hipStream_t stream)
 {
     const int n = (int)p.afrag_floats();

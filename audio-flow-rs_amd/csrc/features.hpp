@@ -105,7 +105,8 @@ struct Params {
     const int64_t* pcm_len;   // [n_clips] PCM frames in each clip
     const int64_t* out_off;   // [n_clips+1] first output frame of each clip
     const int64_t* unit_off;  // [n_clips+1] first 16-frame work unit of each clip
-    int64_t total_units;
+    int64_t total_units;      // units this launch covers ...
+    int64_t unit_begin;       // ... starting at this one (a sub-range = a chunk of the host-buffer pipeline)
     int n_clips;
     int hop;
     int aligned16;            // every clip base and every staging unit is 16-B aligned

@@ -30,6 +30,23 @@ struct af_features {
     const int* d_meta8 = nullptr;
     DevBuf d_units;                  // v2::UnitDesc per 16-frame unit (hop 256 only)
     bool units_ok = false;
+    // the batch tables are rewritten by set_batch*: the last launch that reads them must be done first
+    hipEvent_t last_run = nullptr;
+    bool run_pending = false;
+    // host copies of the tables (chunking of the host-buffer path) and its three streams
+    std::vector<int64_t> h_start, h_len, h_out_off, h_unit_off;
+    bool contiguous = false;         // clips back to back in increasing order: the batch can be cut by clip ranges
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> ev_in, ev_run;
+    ~af_features()
+    {
+        if (last_run) (void)hipEventDestroy(last_run);
+        for (hipEvent_t e : ev_in) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_run) (void)hipEventDestroy(e);
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_run) (void)hipStreamDestroy(s_run);
+        if (s_out) (void)hipStreamDestroy(s_out);
+    }
     // batch description
     DevBuf d_tables;                 // start[n] | len[n] | out_off[n+1] | unit_off[n+1]
     size_t n_clips = 0;
@@ -219,6 +236,10 @@ size_t bytes_per_frame(const af_features_config& c)
 af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
                         const std::vector<int64_t>& len_in)
 {
+    if (p->run_pending) {                      // a launch on a caller's stream may still read the old tables
+        AF_HIP(hipEventSynchronize(p->last_run));
+        p->run_pending = false;
+    }
     // AF_CH_SEPARATE: table entry 2c + ch is channel ch of clip c (same PCM span twice)
     std::vector<int64_t> start, len;
     if (p->cfg.channel_mode == AF_CH_SEPARATE) {
@@ -251,6 +272,14 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
         if ((start[c] * (int64_t)bpf) % 16 != 0) aligned = false;
         end = std::max(end, start[c] + len[c]);
     }
+    p->h_start.assign(t_start, t_start + n);
+    p->h_len.assign(t_len, t_len + n);
+    p->h_out_off.assign(out_off, out_off + n + 1);
+    p->h_unit_off.assign(unit_off, unit_off + n + 1);
+    p->contiguous = true;
+    for (size_t c = 0; c + 1 < n; ++c)
+        if (start[c + 1] < start[c] + len[c] && !(p->cfg.channel_mode == AF_CH_SEPARATE && start[c + 1] == start[c]))
+            p->contiguous = false;
     p->total_pcm_frames = end;
     p->total_frames = out_off[n];
     p->total_units = unit_off[n];
@@ -486,10 +515,31 @@ af_status af_features_set_batch_spans(af_features* p, const int64_t* starts, con
     return AF_OK;
 }
 
+static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel_dev, void* stream,
+                                 int64_t u_begin = 0, int64_t u_count = -1);
+
 af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel_dev, void* stream)
 {
     AF_REQUIRE(p, "af_features_run_device: null handle");
+    AF_TRY(run_device_impl(p, pcm_dev, mel_dev, stream));
     if (p->total_units == 0) return AF_OK;
+    // remember the launch (not inside a stream capture: the replayed graph owns its own ordering)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(as_stream(stream), &cs) != hipSuccess) (void)hipGetLastError();
+    if (cs == hipStreamCaptureStatusNone) {
+        if (!p->last_run) AF_HIP(hipEventCreateWithFlags(&p->last_run, hipEventDisableTiming));
+        AF_HIP(hipEventRecord(p->last_run, as_stream(stream)));
+        p->run_pending = true;
+    }
+    return AF_OK;
+}
+
+// units [u_begin, u_begin + u_count) of the batch (u_count < 0: all of it)
+static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel_dev, void* stream,
+                                 int64_t u_begin, int64_t u_count)
+{
+    if (u_count < 0) u_count = p->total_units - u_begin;
+    if (p->total_units == 0 || u_count <= 0) return AF_OK;
     AF_REQUIRE(pcm_dev && mel_dev, "af_features_run_device: null buffer");
     Params prm{};
     prm.pcm = pcm_dev;
@@ -504,7 +554,8 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     prm.pcm_len = tab + p->n_clips;
     prm.out_off = tab + 2 * p->n_clips;
     prm.unit_off = tab + 2 * p->n_clips + (p->n_clips + 1);
-    prm.total_units = p->total_units;
+    prm.total_units = u_count;
+    prm.unit_begin = u_begin;
     prm.n_clips = (int)p->n_clips;
     prm.hop = (int)p->cfg.hop;
     prm.stamps = p->d_stamps.as<unsigned long long>();
@@ -521,15 +572,15 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
         q.tabs = p->d_tabs2;
         q.wfrag = p->d_wfrag8;
         q.meta = p->d_meta8;
-        q.units = p->d_units.as<v2::UnitDesc>();
+        q.units = p->d_units.as<v2::UnitDesc>() + u_begin;
         q.plan = p->plan8;
-        q.total_units = p->total_units;
+        q.total_units = u_count;
         q.out_power = prm.out_power;
         q.log_mel = prm.log_mel;
         q.stamps = prm.stamps;
         int64_t grid2 = (int64_t)p->n_cus * 2;
         if (wg_knob == 1) grid2 = (int64_t)p->n_cus;
-        if (grid2 > p->total_units) grid2 = p->total_units;
+        if (grid2 > u_count) grid2 = u_count;
         return v2::launch(q, (int)p->cfg.channels, p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
                           (int)grid2, as_stream(stream));
     }
@@ -541,7 +592,7 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     if (per_cu < 1) per_cu = 1;
     if (wg_knob >= 1 && wg_knob <= 8) per_cu = wg_knob;
     int64_t grid = (int64_t)p->n_cus * per_cu;
-    if (grid > p->total_units) grid = p->total_units;
+    if (grid > u_count) grid = u_count;
     return launch_features(prm, (int)p->cfg.channels, p->cfg.sample_format == AF_PCM_I16,
                            (int)grid, smem, as_stream(stream));
 }
@@ -558,12 +609,69 @@ af_status af_features_run(af_features* p, const void* pcm, size_t pcm_len, float
         return fail(AF_ERR_BUFFER_TOO_SMALL, "mel buffer holds %zu floats, need %zu", mel_cap, n_out);
     if (n_out == 0) return AF_OK;
     AF_REQUIRE(pcm && mel, "af_features_run: null buffer");
-    const size_t in_bytes = (size_t)p->total_pcm_frames * bytes_per_frame(p->cfg);
+    const size_t bpf = bytes_per_frame(p->cfg);
+    const size_t in_bytes = (size_t)p->total_pcm_frames * bpf;
     AF_TRY(p->d_pcm.reserve(in_bytes));
     AF_TRY(p->d_mel.reserve(n_out * sizeof(float)));
-    AF_HIP(hipMemcpy(p->d_pcm.p, pcm, in_bytes, hipMemcpyHostToDevice));
-    AF_TRY(af_features_run_device(p, p->d_pcm.p, p->d_mel.as<float>(), nullptr));
-    AF_HIP(hipMemcpy(mel, p->d_mel.p, n_out * sizeof(float), hipMemcpyDeviceToHost));
+    // Chunks of whole clips, about 32 MB of PCM each: H2D of chunk k + 1, the kernel on chunk k and
+    // D2H of chunk k - 1 run on three streams (truly concurrent when the caller's buffers are
+    // page-locked; with pageable memory the runtime stages every copy and the chunks serialise).
+    struct Chunk { int64_t f0, f1, r0, r1, u0, u1; };
+    std::vector<Chunk> chunks;
+    const size_t n = p->n_clips;
+    // (pageable memory goes through the runtime's own staging, which is fastest as ONE copy)
+    hipPointerAttribute_t pa;
+    const bool pinned = hipPointerGetAttributes(&pa, pcm) == hipSuccess && pa.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();
+    if (pinned && p->contiguous && n >= 2 && in_bytes >= ((size_t)64 << 20)) {
+        const int64_t target = (int64_t)(((size_t)32 << 20) / bpf);
+        size_t c0 = 0;
+        while (c0 < n) {
+            size_t c1 = c0 + 1;
+            while (c1 < n && p->h_start[c1 - 1] + p->h_len[c1 - 1] - p->h_start[c0] < target) ++c1;
+            // a separate-channel clip is two table entries over the same PCM: keep them together
+            if (p->cfg.channel_mode == AF_CH_SEPARATE && (c1 & 1)) ++c1;
+            if (c1 > n) c1 = n;
+            chunks.push_back({p->h_start[c0], p->h_start[c1 - 1] + p->h_len[c1 - 1], p->h_out_off[c0], p->h_out_off[c1],
+                              p->h_unit_off[c0], p->h_unit_off[c1]});
+            c0 = c1;
+        }
+    }
+    if (chunks.size() < 2) {
+        AF_HIP(hipMemcpy(p->d_pcm.p, pcm, in_bytes, hipMemcpyHostToDevice));
+        AF_TRY(af_features_run_device(p, p->d_pcm.p, p->d_mel.as<float>(), nullptr));
+        AF_HIP(hipMemcpy(mel, p->d_mel.p, n_out * sizeof(float), hipMemcpyDeviceToHost));
+        return AF_OK;
+    }
+    if (!p->s_in) {
+        AF_HIP(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+        AF_HIP(hipStreamCreateWithFlags(&p->s_run, hipStreamNonBlocking));
+        AF_HIP(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    }
+    while (p->ev_in.size() < chunks.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        AF_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        p->ev_in.push_back(a);
+        AF_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        p->ev_run.push_back(b);
+    }
+    const size_t row = af_features_row_len(p);
+    const char* src = static_cast<const char*>(pcm);
+    for (size_t k = 0; k < chunks.size(); ++k) {
+        const Chunk& c = chunks[k];
+        AF_HIP(hipMemcpyAsync(p->d_pcm.as<char>() + c.f0 * bpf, src + c.f0 * bpf, (size_t)(c.f1 - c.f0) * bpf,
+                              hipMemcpyHostToDevice, p->s_in));
+        AF_HIP(hipEventRecord(p->ev_in[k], p->s_in));
+        AF_HIP(hipStreamWaitEvent(p->s_run, p->ev_in[k], 0));
+        AF_TRY(run_device_impl(p, p->d_pcm.p, p->d_mel.as<float>(), p->s_run, c.u0, c.u1 - c.u0));
+        AF_HIP(hipEventRecord(p->ev_run[k], p->s_run));
+        AF_HIP(hipStreamWaitEvent(p->s_out, p->ev_run[k], 0));
+        if (c.r1 > c.r0)
+            AF_HIP(hipMemcpyAsync(mel + (size_t)c.r0 * row, p->d_mel.as<float>() + (size_t)c.r0 * row,
+                                  (size_t)(c.r1 - c.r0) * row * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
+    }
+    AF_HIP(hipStreamSynchronize(p->s_out));
+    AF_HIP(hipStreamSynchronize(p->s_run));
     return AF_OK;
 }
 

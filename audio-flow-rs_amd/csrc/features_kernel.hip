@@ -267,8 +267,8 @@ __global__ __launch_bounds__(kThreads, 2) void af_features_kernel(const Params p
 
     // work range of this workgroup, in 16-frame units
     const int64_t G = gridDim.x, b = blockIdx.x;
-    int64_t u = p.total_units * b / G;
-    const int64_t u_end = p.total_units * (b + 1) / G;
+    int64_t u = p.unit_begin + p.total_units * b / G;
+    const int64_t u_end = p.unit_begin + p.total_units * (b + 1) / G;
     if (u >= u_end) return;
 
     // window and twiddle tables -> LDS (made visible by the first barrier below)

@@ -88,7 +88,7 @@ af_status launch(const banded::Plan& plan, const float* afrag_dev, const float* 
                  int64_t y_stride, int64_t m0, int64_t n_out, int64_t n_clips, hipStream_t stream)
 {
     if (n_out <= 0 || n_clips <= 0) return AF_OK;
-    if (plan.ok)
+    if (banded::fits(plan, x_len))
         return banded::launch(plan, afrag_dev, x_dev, x_abs0, x_len, x_stride, y_dev, y_stride, m0,
                               n_out, n_clips, stream);
     Geometry g{};

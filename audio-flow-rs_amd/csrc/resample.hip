@@ -117,6 +117,7 @@ struct Design {
     std::vector<float> proto;        // h[L*T] in prototype order (f32)
     DevBuf d_taps;                   // [L][kRow]
     banded::Plan plan;               // MFMA path when plan.ok
+    bool valu_ok = false;            // the thread-per-output kernel is set up as well
     banded::Plan plan2;              // same, interleaved stereo input downmixed while staged
     DevBuf d_afrag;
     int x_tile_cap = 0;
@@ -173,16 +174,20 @@ af_status make_design(uint32_t in_hz, uint32_t out_hz, Design& d, bool upload)
             AF_TRY(banded::build_afrag(d.plan, d_proto.as<float>(), d.d_afrag.as<float>(), nullptr));
             AF_HIP(hipStreamSynchronize(nullptr));
         }
-        return AF_OK;
     }
+    // The thread-per-output kernel's geometry as well: it serves the ratios the MFMA plan does not
+    // cover and the clips beyond its 32-bit offsets.
     // input span of one tile: ceil(kTileOut*M/L) + T + 2
     d.x_tile_cap = (int)(((uint64_t)kTileOut * d.M + d.L - 1) / d.L) + kT + 4;
     d.x_tile_cap = (d.x_tile_cap + 3) & ~3;
     const size_t taps_bytes = (size_t)d.L * kRow * sizeof(float);
     d.taps_in_lds = (d.x_tile_cap * sizeof(float) + taps_bytes) <= 150 * 1024 ? 1 : 0;
     d.smem = d.x_tile_cap * sizeof(float) + (d.taps_in_lds ? taps_bytes : 0);
-    if (d.x_tile_cap * sizeof(float) > 150 * 1024)
+    d.valu_ok = d.x_tile_cap * sizeof(float) <= 150 * 1024;
+    if (!d.valu_ok) {
+        if (d.plan.ok) return AF_OK;
         return fail(AF_ERR_UNSUPPORTED, "downsampling ratio %u/%u too steep for one LDS tile", d.L, d.M);
+    }
     if (upload) {
         std::vector<float> rows((size_t)d.L * kRow, 0.0f);
         for (uint32_t r = 0; r < d.L; ++r)
@@ -200,9 +205,12 @@ af_status launch(const Design& d, const float* x_dev, int64_t x_abs0, int64_t x_
                  hipStream_t stream)
 {
     if (n_out <= 0 || n_clips <= 0) return AF_OK;
-    if (d.plan.ok)
+    if (banded::fits(d.plan, x_len))
         return banded::launch(d.plan, d.d_afrag.as<float>(), x_dev, x_abs0, x_len, x_stride, y_dev,
                               y_stride, m0, n_out, n_clips, stream);
+    if (!d.valu_ok)
+        return fail(AF_ERR_UNSUPPORTED, "clips of %lld samples at ratio %u/%u: beyond the MFMA kernel's 32-bit offsets "
+                    "and too steep for the thread-per-output kernel", (long long)x_len, d.L, d.M);
     Geometry g{};
     g.x = x_dev;
     g.y = y_dev;

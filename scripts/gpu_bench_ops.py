@@ -94,7 +94,16 @@ try:
         assert st == 0
     run_pinned()
     t0 = time.perf_counter(); run_pinned(); dt = time.perf_counter() - t0
-    out["features_host_buffers_64clips_pinned"] = dict(ms=dt * 1e3, frames_per_s=mel.shape[0] / dt, note="H2D + kernel + D2H, page-locked host memory")
+    out["features_host_buffers_64clips_pinned"] = dict(ms=dt * 1e3, frames_per_s=mel.shape[0] / dt, note="H2D + kernel + D2H, page-locked host memory, chunks on three streams")
+    # what the copies alone cost on this box: H2D of the same PCM, D2H of the same rows (torch, pinned)
+    dbuf = torch.empty(hp.numel(), device=dev); dm = torch.empty(mp.shape, device=dev)
+    def h2d(): dbuf.copy_(hp, non_blocking=True); torch.cuda.synchronize()
+    def d2h(): mp.copy_(dm, non_blocking=True); torch.cuda.synchronize()
+    h2d(); t0 = time.perf_counter(); h2d(); t_h2d = time.perf_counter() - t0
+    d2h(); t0 = time.perf_counter(); d2h(); t_d2h = time.perf_counter() - t0
+    out["features_host_buffers_64clips_pinned"].update(
+        h2d_only_ms=t_h2d * 1e3, d2h_only_ms=t_d2h * 1e3, h2d_GBps=hp.numel() * 4 / t_h2d / 1e9,
+        end_to_end_over_h2d_only=t_h2d / dt)
 except Exception as e:
     out["features_host_buffers_64clips_pinned"] = dict(ms=0.0, note="failed: %r" % (e,))
 print(json.dumps(out, indent=1))
