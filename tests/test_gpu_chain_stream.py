@@ -218,3 +218,50 @@ def test_feature_stream_ten_minutes_bit_equal_to_one_shot(af):
           f"median {np.median(dev_ms):.2f} max {np.max(dev_ms):.2f}; wall ms/step median {np.median(wall_ms):.2f}; "
           f"real-time factor {step / sr / (np.median(wall_ms) * 1e-3):.0f}x")
     assert np.median(wall_ms) * 1e-3 < step / sr / 100            # far faster than real time
+
+
+def test_feature_stream_eight_hours_config5(af):
+    """BASELINE config 5 at its full length: ONE 8 h stereo 48 kHz stream (1.3824e9 frames, 11 GB of f32)
+    through af_stream_* in 2^20-frame steps (1318 hipGraph replays + the flush) against one-shot framing of
+    the same signal on the device, bit for bit; the 8-GPU form of the config shards this stream in time
+    (shard.stream_shards), every rank running the same loop on its span."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    sr, step = 48000, 1 << 20
+    n = 8 * 3600 * sr
+    piece = 4 * step                                                  # the feeder hands over 87 s at a time
+    gen = torch.Generator().manual_seed(2024)
+    base = torch.rand(piece + 7919, 2, generator=gen).mul_(0.6).sub_(0.3)     # 34 MB of noise, reused at
+    t = torch.arange(piece, dtype=torch.float32)                               # shifting offsets + a slow sweep
+    st = af.FeatureStream(step_frames=step)
+    one = af.FeaturePipeline()
+    total = one.set_batch_uniform(1, n)
+    assert total == st.total_rows(n) == 1 + (n - 1024) // 256 == 5399997
+    pcm = torch.empty(n, 2, device=dev)                               # the same stream, resident for the one-shot run
+    rows = torch.empty(total, 80)
+    pos = row = 0
+    wall = []
+    k = 0
+    while pos < n:
+        m = min(piece, n - pos)
+        off = (k * 977) % 7919
+        x = base[off:off + m].clone()
+        x[:, 0] += 0.2 * torch.sin(t[:m] * (2 * np.pi * (200.0 + 3.0 * k) / sr))
+        pcm[pos:pos + m].copy_(x)
+        r = st.push(x.numpy())
+        rows[row:row + r.shape[0]] = torch.from_numpy(r)
+        row += r.shape[0]
+        if r.shape[0]:
+            wall.append(st.stats()["wall_ms"])
+        pos += m
+        k += 1
+    tail = st.flush()
+    rows[row:row + tail.shape[0]] = torch.from_numpy(tail)
+    row += tail.shape[0]
+    assert row == total and st.stats()["steps"] == (n - 768) // step == 1318
+    full = torch.empty(total, 80, device=dev)
+    one.run_device(pcm.data_ptr(), full.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(rows, full.cpu())
+    print(f"\n8 h stream: {st.stats()['steps']} steps, wall ms per step median {np.median(wall):.2f}, "
+          f"{n / sr / (np.median(wall) * 1e-3 * st.stats()['steps']):.0f}x real time on the step path alone")
