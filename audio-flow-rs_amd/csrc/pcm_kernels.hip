@@ -207,8 +207,8 @@ __global__ __launch_bounds__(kBlock) void pcm16_base64_kernel(const float* __res
 }
 
 // ---- VAD energy ----------------------------------------------------------------
-// one wave64 per frame: lanes stride the frame (16-byte loads when the frames are 16-byte
-// aligned), wavefront-shuffle tree sum.
+// frame_sweep (level meter): one wave64 per window, lanes stride it (16-byte loads when the
+// windows are 16-byte aligned).
 template <class F>
 __device__ __forceinline__ void frame_sweep(const float* __restrict__ x, size_t len, int lane, bool vec, F&& f)
 {
@@ -225,18 +225,54 @@ __device__ __forceinline__ void frame_sweep(const float* __restrict__ x, size_t 
     for (size_t i = done + lane; i < len; i += 64) f(x[i]);
 }
 
-__global__ void vad_energy_kernel(const float* __restrict__ in, size_t n_frames, size_t frame_len,
-                                  float* __restrict__ energy, int vec)
+// The reference folds left in f32 (`frame.iter().map(|&x| x * x).sum()`, vad.rs:163-165: no FMA, one
+// rounding per product and per add), so a tree sum differs in the last bits and a frame within
+// rounding of the threshold could flip the VAD state.  Here ONE LANE folds ONE FRAME, in order:
+// bit-identical to the reference.  A workgroup owns 256 consecutive frames and walks them in slices
+// of 32 samples: the slice is loaded coalesced (8 lanes x 16 B per frame run) into an LDS tile with a
+// 33-dword row stride, then every lane reads its own row (conflict-free) and folds it.
+constexpr int kVadFrames = 256, kVadSlice = 32, kVadStride = kVadSlice + 1;
+__global__ __launch_bounds__(kVadFrames) void vad_energy_kernel(const float* __restrict__ in, size_t n_frames,
+                                                                size_t frame_len, float* __restrict__ energy, int vec)
 {
-    const int lane = threadIdx.x & 63;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t f = wave; f < n_frames; f += n_waves) {
+#pragma clang fp contract(off)
+    __shared__ float tile[kVadFrames * kVadStride];
+    const int tid = threadIdx.x;
+    for (size_t fb = (size_t)blockIdx.x * kVadFrames; fb < n_frames; fb += (size_t)gridDim.x * kVadFrames) {
+        const int nf = (int)(n_frames - fb < (size_t)kVadFrames ? n_frames - fb : (size_t)kVadFrames);
+        const float* x = in + fb * frame_len;
         float s = 0.0f;
-        frame_sweep(in + f * frame_len, frame_len, lane, vec != 0, [&](float v) { s += v * v; });
+        for (size_t i0 = 0; i0 < frame_len; i0 += kVadSlice) {
+            const int tcur = (int)(frame_len - i0 < (size_t)kVadSlice ? frame_len - i0 : (size_t)kVadSlice);
+            __syncthreads();                                         // the previous slice has been folded
+            if (vec && tcur == kVadSlice) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) energy[f] = frame_len ? s / (float)frame_len : 0.0f;   // vad.rs:158,167
+                for (int k = 0; k < kVadSlice / 4; ++k) {
+                    const int q = tid + kVadFrames * k, r = q >> 3, part = q & 7;
+                    if (r < nf) {
+                        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * frame_len + i0 + 4 * part);
+                        float* d = tile + r * kVadStride + 4 * part;
+                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    }
+                }
+            } else {
+                for (int q = tid; q < nf * tcur; q += kVadFrames) {
+                    const int r = q / tcur, e = q - r * tcur;
+                    tile[r * kVadStride + e] = x[(size_t)r * frame_len + i0 + e];
+                }
+            }
+            __syncthreads();
+            if (tid < nf) {
+                const float* row = tile + tid * kVadStride;
+                if (tcur == kVadSlice) {
+#pragma unroll
+                    for (int e = 0; e < kVadSlice; ++e) { const float p = row[e] * row[e]; s = s + p; }
+                } else {
+                    for (int e = 0; e < tcur; ++e) { const float p = row[e] * row[e]; s = s + p; }
+                }
+            }
+        }
+        if (tid < nf) energy[fb + tid] = frame_len ? s / (float)frame_len : 0.0f;   // vad.rs:158,167
     }
 }
 
@@ -394,10 +430,10 @@ af_status af_vad_energy_device(const float* in_dev, size_t n_frames, size_t fram
 {
     if (n_frames == 0) return AF_OK;
     AF_REQUIRE(energy_dev && (in_dev || frame_len == 0), "vad_energy: null buffer");
-    size_t g = (n_frames * 64 + kBlock - 1) / kBlock;
+    size_t g = (n_frames + kVadFrames - 1) / kVadFrames;      // one lane per frame, 256 frames per workgroup
     if (g > 4096) g = 4096;
     const int vec = frame_len % 4 == 0 && reinterpret_cast<uintptr_t>(in_dev) % 16 == 0;
-    hipLaunchKernelGGL(vad_energy_kernel, dim3((int)g), dim3(kBlock), 0, as_stream(stream), in_dev,
+    hipLaunchKernelGGL(vad_energy_kernel, dim3((int)g), dim3(kVadFrames), 0, as_stream(stream), in_dev,
                        n_frames, frame_len, energy_dev, vec);
     AF_HIP(hipGetLastError());
     return AF_OK;
