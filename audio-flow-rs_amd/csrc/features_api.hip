@@ -28,6 +28,7 @@ struct af_features {
     const float* d_tabs2 = nullptr;
     const float* d_wfrag8 = nullptr;
     const int* d_meta8 = nullptr;
+    DevBuf d_mono;                   // channels > 2: the downmixed batch the fused kernel reads
     DevBuf d_units;                  // v2::UnitDesc per 16-frame unit (hop 256 only)
     bool units_ok = false;
     // the batch tables are rewritten by set_batch*: the last launch that reads them must be done first
@@ -232,6 +233,14 @@ size_t bytes_per_frame(const af_features_config& c)
     return (size_t)c.channels * (c.sample_format == AF_PCM_I16 ? 2 : 4);
 }
 
+// More than two channels (capture.rs:30-42 downmixes any count): af_to_mono_device runs first and the
+// fused kernel reads its mono output, so the kernel sees 4-byte frames.
+int kernel_channels(const af_features_config& c) { return c.channels > 2 ? 1 : (int)c.channels; }
+size_t kernel_bytes_per_frame(const af_features_config& c)
+{
+    return c.channels > 2 ? 4 : bytes_per_frame(c);
+}
+
 // spans: clip c = PCM frames [start[c], start[c] + len[c]) of the buffer (may overlap)
 af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
                         const std::vector<int64_t>& len_in)
@@ -259,7 +268,7 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     int64_t* unit_off = out_off + (n + 1);
     out_off[0] = 0;
     unit_off[0] = 0;
-    const size_t bpf = bytes_per_frame(p->cfg);
+    const size_t bpf = kernel_bytes_per_frame(p->cfg);
     bool aligned = (p->cfg.hop * bpf) % 16 == 0;
     int64_t end = 0;
     for (size_t c = 0; c < n; ++c) {
@@ -284,6 +293,7 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     p->total_frames = out_off[n];
     p->total_units = unit_off[n];
     p->offsets_aligned = aligned;
+    if (p->cfg.channels > 2) AF_TRY(p->d_mono.reserve((size_t)end * sizeof(float) + 64));
     AF_TRY(p->d_tables.reserve((tab.size() ? tab.size() : 1) * sizeof(int64_t)));
     AF_HIP(hipMemcpy(p->d_tables.p, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     // hop-256 kernel: one 32-byte record per 16-frame unit
@@ -342,8 +352,9 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     AF_REQUIRE(cfg && out, "af_features_create: null argument");
     *out = nullptr;
     AF_REQUIRE(cfg->n_fft == (uint32_t)kNfft, "n_fft must be %d (got %u)", kNfft, cfg->n_fft);
-    AF_REQUIRE(cfg->channels == 1 || cfg->channels == 2, "channels must be 1 or 2 (got %u)",
-               cfg->channels);
+    AF_REQUIRE(cfg->channels >= 1 && cfg->channels <= 16, "channels must be in [1, 16] (got %u)", cfg->channels);
+    if (cfg->channels > 2 && cfg->sample_format != AF_PCM_F32)
+        return fail(AF_ERR_UNSUPPORTED, "more than two channels are supported for f32 PCM only");
     AF_REQUIRE(cfg->hop >= 64 && cfg->hop <= 1024 && cfg->hop % 4 == 0,
                "hop must be a multiple of 4 in [64, 1024] (got %u)", cfg->hop);
     AF_REQUIRE(cfg->n_mels >= 1 && cfg->n_mels <= 128u, "n_mels must be in [1, %d]",
@@ -516,7 +527,7 @@ af_status af_features_set_batch_spans(af_features* p, const int64_t* starts, con
 }
 
 static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel_dev, void* stream,
-                                 int64_t u_begin = 0, int64_t u_count = -1);
+                                 int64_t u_begin = 0, int64_t u_count = -1, int64_t f_begin = 0, int64_t f_end = -1);
 
 af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel_dev, void* stream)
 {
@@ -534,13 +545,21 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     return AF_OK;
 }
 
-// units [u_begin, u_begin + u_count) of the batch (u_count < 0: all of it)
+// units [u_begin, u_begin + u_count) of the batch (u_count < 0: all of it), which read PCM frames
+// [f_begin, f_end) (f_end < 0: the whole batch)
 static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel_dev, void* stream,
-                                 int64_t u_begin, int64_t u_count)
+                                 int64_t u_begin, int64_t u_count, int64_t f_begin, int64_t f_end)
 {
     if (u_count < 0) u_count = p->total_units - u_begin;
     if (p->total_units == 0 || u_count <= 0) return AF_OK;
     AF_REQUIRE(pcm_dev && mel_dev, "af_features_run_device: null buffer");
+    if (p->cfg.channels > 2) {                   // to_mono first (capture.rs:30-42), then the mono kernel
+        if (f_end < 0) f_end = p->total_pcm_frames;
+        const size_t ch = p->cfg.channels;
+        AF_TRY(af_to_mono_device(static_cast<const float*>(pcm_dev) + (size_t)f_begin * ch, (size_t)(f_end - f_begin) * ch,
+                                 (uint16_t)ch, p->d_mono.as<float>() + f_begin, stream));
+        pcm_dev = p->d_mono.p;
+    }
     Params prm{};
     prm.pcm = pcm_dev;
     prm.mel = mel_dev;
@@ -581,7 +600,7 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         int64_t grid2 = (int64_t)p->n_cus * 2;
         if (wg_knob == 1) grid2 = (int64_t)p->n_cus;
         if (grid2 > u_count) grid2 = u_count;
-        return v2::launch(q, (int)p->cfg.channels, p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
+        return v2::launch(q, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
                           (int)grid2, as_stream(stream));
     }
     const size_t smem = features_smem_bytes(prm.hop);
@@ -593,7 +612,7 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     if (wg_knob >= 1 && wg_knob <= 8) per_cu = wg_knob;
     int64_t grid = (int64_t)p->n_cus * per_cu;
     if (grid > u_count) grid = u_count;
-    return launch_features(prm, (int)p->cfg.channels, p->cfg.sample_format == AF_PCM_I16,
+    return launch_features(prm, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16,
                            (int)grid, smem, as_stream(stream));
 }
 
@@ -663,7 +682,7 @@ af_status af_features_run(af_features* p, const void* pcm, size_t pcm_len, float
                               hipMemcpyHostToDevice, p->s_in));
         AF_HIP(hipEventRecord(p->ev_in[k], p->s_in));
         AF_HIP(hipStreamWaitEvent(p->s_run, p->ev_in[k], 0));
-        AF_TRY(run_device_impl(p, p->d_pcm.p, p->d_mel.as<float>(), p->s_run, c.u0, c.u1 - c.u0));
+        AF_TRY(run_device_impl(p, p->d_pcm.p, p->d_mel.as<float>(), p->s_run, c.u0, c.u1 - c.u0, c.f0, c.f1));
         AF_HIP(hipEventRecord(p->ev_run[k], p->s_run));
         AF_HIP(hipStreamWaitEvent(p->s_out, p->ev_run[k], 0));
         if (c.r1 > c.r0)

@@ -221,7 +221,7 @@ af_status af_fir_apply_batch_device(const af_fir* f, const float* in_dev, size_t
 typedef struct af_features af_features;
 typedef struct {
     uint32_t sample_rate;    /* Hz, of the PCM handed in */
-    uint32_t channels;       /* 1 or 2 (interleaved) */
+    uint32_t channels;       /* 1..16, interleaved; more than 2 (f32 only): af_to_mono_device first, then the mono kernel */
     uint32_t n_fft;          /* 1024 */
     uint32_t hop;            /* 64..1024, multiple of 4 */
     uint32_t n_mels;         /* 1..128 */

@@ -93,6 +93,24 @@ def test_hop256_kernel_aligned_ragged(af, po, ch, fmt):
     assert row == mel.shape[0] and np.all(np.isfinite(mel))
 
 
+@pytest.mark.parametrize("ch", [3, 4, 6])
+def test_more_than_two_channels(af, po, ch):
+    # AudioFrame::to_mono (capture.rs:30-42) takes any channel count: to_mono runs first, then the mono kernel
+    lens = [20000, 1024, 4864 + 256 * 20, 0, 7777]
+    clips = [synth_clip(800 + i, n, ch, 48000) for i, n in enumerate(lens)]
+    pipe, mel = run_clips(af, clips, ch)
+    row = 0
+    for n, x in zip(lens, clips):
+        ref = po.features(x, ch, 48000.0)
+        nf = ref.shape[0]
+        assert nf == pipe.n_frames(n)
+        assert frame_rel_err(mel[row:row + nf], ref) < TOL
+        row += nf
+    assert row == mel.shape[0]
+    with pytest.raises(af.AudioError):
+        af.FeaturePipeline(channels=4, sample_format=af._ffi.AF_PCM_I16)
+
+
 def test_unaligned_clip_offsets_take_the_scalar_path(af, po):
     # odd frame offsets break 16-byte alignment of the clip bases: same results required
     lens = [3001, 2047, 4099]
@@ -145,7 +163,7 @@ def test_too_wide_filters_are_reported_not_miscomputed(af):
 
 
 def test_invalid_configs_are_rejected(af):
-    for kw in [dict(n_fft=512), dict(channels=3), dict(hop=30), dict(hop=258), dict(n_mels=0),
+    for kw in [dict(n_fft=512), dict(channels=17), dict(channels=0), dict(hop=30), dict(hop=258), dict(n_mels=0),
                dict(n_mels=200), dict(sample_rate=0), dict(f_min=30000.0)]:
         with pytest.raises(af.AudioError):
             af.FeaturePipeline(**kw)
