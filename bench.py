@@ -354,8 +354,9 @@ def main() -> None:
         m["cpu_baseline"] = cpu_baseline(pcm[:k].cpu().numpy(), k, n_frames_pcm)
 
     if rank == 0:
-        print(json.dumps(make_result(m)))
+        print(json.dumps(make_result(m)), flush=True)
     if world > 1:
+        dist.barrier()                       # rank 0 was checking its rows: leave together
         dist.destroy_process_group()
 
 
