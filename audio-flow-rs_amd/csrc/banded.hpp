@@ -54,7 +54,28 @@ af_status build_afrag(const Plan& p, const float* proto_dev, float* afrag_dev, h
 // absolute output 0, so a sample's summation order does not depend on m0 / chunking.
 af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int64_t x_abs0,
                  int64_t x_len, int64_t x_stride, float* y_dev, int64_t y_stride, int64_t m0,
-                 int64_t n_out, int64_t n_clips, hipStream_t stream);
+                 int64_t n_out, int64_t n_clips, hipStream_t stream, bool accumulate = false);
+
+// A FIR as a sum of banded passes: K <= 177 taps is one pass; a longer filter is cut into parts of
+// 176 taps, part j being the FIR of taps [176 j, 176 j + 176) applied to x delayed by 176 j samples;
+// pass 0 writes y, the others accumulate into it (each output's summation order stays independent of
+// how a stream was chunked: every pass anchors its tiles at absolute output 0).
+constexpr int kFirPartTaps = 176;
+constexpr int kFirMaxParts = 6;               // 1024 taps
+struct FirParts {
+    int n = 0;                                // 0: not on the MFMA path
+    Plan plan[kFirMaxParts];
+    size_t afrag_off[kFirMaxParts] = {};      // floats
+    int tap0[kFirMaxParts] = {};
+    size_t afrag_floats = 0;
+    bool ok() const { return n > 0; }
+};
+FirParts make_fir_parts(int K);
+bool fits(const FirParts& p, int64_t x_len);
+af_status build_fir_afrag(const FirParts& p, const float* taps_dev, float* afrag_dev, hipStream_t stream);
+af_status launch_fir(const FirParts& p, const float* afrag_dev, const float* x_dev, int64_t x_abs0, int64_t x_len,
+                     int64_t x_stride, float* y_dev, int64_t y_stride, int64_t m0, int64_t n_out,
+                     int64_t n_clips, hipStream_t stream);
 
 }  // namespace banded
 }  // namespace af

@@ -35,6 +35,7 @@ struct Geom {
     uint32_t L, M;
     int lo_off;                      // c - (T - 1): first window sample relative to q(16 b)
     int nb, S, G, wpp, gpw, seg_len, seg_stride;
+    int accumulate;                  // 1: y += (a later pass of a long FIR)
 };
 
 __device__ __forceinline__ int w_of(int t, int g4, int nk)
@@ -183,6 +184,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             const float* t0p = xs + base_tail + off0;
             const float* t1p = t0p + g.S;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const int o0 = out_lane + gi * out_step, o1 = o0 + out_step;
+            if (g.accumulate) {                                 // wave-uniform: start from the earlier passes' sum
+                if (whole) {
+                    acc0 = *reinterpret_cast<const f32x4*>(yc + o0);
+                    acc1 = *reinterpret_cast<const f32x4*>(yc + o1);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (o0 + j >= lo && o0 + j < hi) acc0[j] = yc[o0 + j];
+                        if (o1 + j >= lo && o1 + j < hi) acc1[j] = yc[o1 + j];
+                    }
+                }
+            }
             // hand-pipelined: the window samples of step t + kAhead are read before the MFMAs of
             // step t, one prefetch load goes out per step; sched_barrier keeps hipcc from
             // clustering the loads at the end of the chain
@@ -211,7 +225,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const int o0 = out_lane + gi * out_step, o1 = o0 + out_step;
             if (whole) {
                 *reinterpret_cast<f32x4*>(yc + o0) = acc0;
                 *reinterpret_cast<f32x4*>(yc + o1) = acc1;
@@ -307,7 +320,7 @@ af_status build_afrag(const Plan& p, const float* proto_dev, float* afrag_dev, h
 
 af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int64_t x_abs0,
                  int64_t x_len, int64_t x_stride, float* y_dev, int64_t y_stride, int64_t m0,
-                 int64_t n_out, int64_t n_clips, hipStream_t stream)
+                 int64_t n_out, int64_t n_clips, hipStream_t stream, bool accumulate)
 {
     if (n_out <= 0 || n_clips <= 0) return AF_OK;
     if (!p.ok) return fail(AF_ERR_UNSUPPORTED, "banded::launch without a plan");
@@ -338,6 +351,7 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
     g.gpw = p.G / p.wpp;
     g.seg_len = p.seg_len;
     g.seg_stride = p.seg_stride;
+    g.accumulate = accumulate ? 1 : 0;
     const int wg_per_cu = (2 * 64 * p.nwaves <= 2048 && 2 * p.smem <= 150 * 1024) ? 2 : 1;
     int64_t grid = g.n_tiles;
     const int64_t n_cus = device_cu_count(current_device());
@@ -358,6 +372,50 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
     default: return fail(AF_ERR_UNSUPPORTED, "no banded kernel for NK=%d", p.NK);
     }
     AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+FirParts make_fir_parts(int K)
+{
+    FirParts fp;
+    if (K < 1) return fp;
+    const Plan whole = make_plan(1, 1, K, 0);
+    if (whole.ok) {
+        fp.n = 1;
+        fp.plan[0] = whole;
+        fp.afrag_floats = whole.afrag_floats();
+        return fp;
+    }
+    const int n = (K + kFirPartTaps - 1) / kFirPartTaps;
+    if (n > kFirMaxParts) return fp;
+    for (int j = 0; j < n; ++j) {
+        const int t0 = j * kFirPartTaps, tj = K - t0 < kFirPartTaps ? K - t0 : kFirPartTaps;
+        fp.plan[j] = make_plan(1, 1, tj, -t0);               // taps [t0, t0 + tj) see x delayed by t0
+        if (!fp.plan[j].ok) return FirParts{};
+        fp.tap0[j] = t0;
+        fp.afrag_off[j] = fp.afrag_floats;
+        fp.afrag_floats += fp.plan[j].afrag_floats();
+    }
+    fp.n = n;
+    return fp;
+}
+
+bool fits(const FirParts& p, int64_t x_len) { return p.ok() && fits(p.plan[0], x_len); }
+
+af_status build_fir_afrag(const FirParts& p, const float* taps_dev, float* afrag_dev, hipStream_t stream)
+{
+    for (int j = 0; j < p.n; ++j)
+        AF_TRY(build_afrag(p.plan[j], taps_dev + p.tap0[j], afrag_dev + p.afrag_off[j], stream));
+    return AF_OK;
+}
+
+af_status launch_fir(const FirParts& p, const float* afrag_dev, const float* x_dev, int64_t x_abs0, int64_t x_len,
+                     int64_t x_stride, float* y_dev, int64_t y_stride, int64_t m0, int64_t n_out,
+                     int64_t n_clips, hipStream_t stream)
+{
+    for (int j = 0; j < p.n; ++j)
+        AF_TRY(launch(p.plan[j], afrag_dev + p.afrag_off[j], x_dev, x_abs0, x_len, x_stride, y_dev, y_stride, m0,
+                      n_out, n_clips, stream, j > 0));
     return AF_OK;
 }
 

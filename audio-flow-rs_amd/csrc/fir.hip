@@ -82,15 +82,15 @@ __global__ __launch_bounds__(kBlock) void fir_kernel(const Geometry g)
     }
 }
 
-// `plan`/`afrag_dev`: the MFMA path when plan.ok (afrag built from the same taps).
-af_status launch(const banded::Plan& plan, const float* afrag_dev, const float* taps_dev, int K,
+// `plan`/`afrag_dev`: the MFMA path when plan.ok() (afrag built from the same taps).
+af_status launch(const banded::FirParts& plan, const float* afrag_dev, const float* taps_dev, int K,
                  const float* x_dev, int64_t x_abs0, int64_t x_len, int64_t x_stride, float* y_dev,
                  int64_t y_stride, int64_t m0, int64_t n_out, int64_t n_clips, hipStream_t stream)
 {
     if (n_out <= 0 || n_clips <= 0) return AF_OK;
     if (banded::fits(plan, x_len))
-        return banded::launch(plan, afrag_dev, x_dev, x_abs0, x_len, x_stride, y_dev, y_stride, m0,
-                              n_out, n_clips, stream);
+        return banded::launch_fir(plan, afrag_dev, x_dev, x_abs0, x_len, x_stride, y_dev, y_stride, m0,
+                                  n_out, n_clips, stream);
     Geometry g{};
     g.x = x_dev;
     g.y = y_dev;
@@ -122,7 +122,7 @@ struct af_fir {
     std::vector<float> taps;
     std::vector<float> hist;     // K-1 most recent input samples (zeros initially)
     int64_t n_total = 0;         // samples consumed so far (anchors the MFMA tile grid)
-    banded::Plan plan;
+    banded::FirParts plan;
     DevBuf d_taps, d_afrag, d_x, d_y;
 };
 
@@ -168,13 +168,13 @@ af_status af_fir_create(const float* taps, size_t n_taps, af_fir** out)
     if (!f) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
     f->taps.assign(taps, taps + n_taps);
     f->hist.assign(n_taps - 1, 0.0f);
-    f->plan = banded::make_plan(1, 1, (int)n_taps, 0);
+    f->plan = banded::make_fir_parts((int)n_taps);
     af_status st = f->d_taps.reserve(n_taps * sizeof(float));
     if (st == AF_OK && hipMemcpy(f->d_taps.p, taps, n_taps * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         st = fail(AF_ERR_HIP, "uploading FIR taps failed");
-    if (st == AF_OK && f->plan.ok) {
-        st = f->d_afrag.reserve(f->plan.afrag_floats() * sizeof(float));
-        if (st == AF_OK) st = banded::build_afrag(f->plan, f->d_taps.as<float>(), f->d_afrag.as<float>(), nullptr);
+    if (st == AF_OK && f->plan.ok()) {
+        st = f->d_afrag.reserve(f->plan.afrag_floats * sizeof(float));
+        if (st == AF_OK) st = banded::build_fir_afrag(f->plan, f->d_taps.as<float>(), f->d_afrag.as<float>(), nullptr);
         if (st == AF_OK && hipStreamSynchronize(nullptr) != hipSuccess)
             st = fail(AF_ERR_HIP, "building the FIR fragments failed");
     }
@@ -237,11 +237,11 @@ af_status af_fir_batch_device(const float* taps_dev, size_t n_taps, const float*
                firk::kMaxTaps, n_taps);
     if (n_clips == 0 || n == 0) return AF_OK;
     AF_REQUIRE(taps_dev && in_dev && out_dev, "af_fir_batch_device: null buffer");
-    const banded::Plan plan = banded::make_plan(1, 1, (int)n_taps, 0);
+    const banded::FirParts plan = banded::make_fir_parts((int)n_taps);
     float* afrag = nullptr;
-    if (plan.ok) {
-        AF_TRY(scratch_afrag(as_stream(stream), plan.afrag_floats(), &afrag));
-        AF_TRY(banded::build_afrag(plan, taps_dev, afrag, as_stream(stream)));
+    if (plan.ok()) {
+        AF_TRY(scratch_afrag(as_stream(stream), plan.afrag_floats, &afrag));
+        AF_TRY(banded::build_fir_afrag(plan, taps_dev, afrag, as_stream(stream)));
     }
     return firk::launch(plan, afrag, taps_dev, (int)n_taps, in_dev, 0, (int64_t)n, (int64_t)n, out_dev,
                         (int64_t)n, 0, (int64_t)n, (int64_t)n_clips, as_stream(stream));

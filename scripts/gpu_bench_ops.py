@@ -36,6 +36,15 @@ taps = torch.rand(129, device=dev) / 129; z = torch.empty_like(y)
 ms = timeit(lambda: lib.af_fir_batch_device(P(taps.data_ptr()), 129, P(y.data_ptr()), nc, nout, P(z.data_ptr()), None), k=5)
 b = 2 * y.numel() * 4
 out["fir129_cfg4"] = dict(ms=ms, alg_GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / 8000, tflops=2 * 129 * y.numel() / ms / 1e9)
+# a long FIR (K = 1024): six MFMA passes of 176 taps against the thread-per-output kernel
+taps_l = torch.rand(1024, device=dev) / 1024
+nl = 256
+ms = timeit(lambda: lib.af_fir_batch_device(P(taps_l.data_ptr()), 1024, P(y.data_ptr()), nl, nout, P(z.data_ptr()), None), k=3)
+out["fir1024_256clips"] = dict(ms=ms, tflops=2 * 1024 * nl * nout / ms / 1e9, note="6 banded MFMA passes")
+lib.af_debug_set(b"banded.off", 1)
+ms = timeit(lambda: lib.af_fir_batch_device(P(taps_l.data_ptr()), 1024, P(y.data_ptr()), nl, nout, P(z.data_ptr()), None), k=3)
+lib.af_debug_set(b"banded.off", 0)
+out["fir1024_256clips_valu"] = dict(ms=ms, tflops=2 * 1024 * nl * nout / ms / 1e9, note="thread-per-output kernel")
 # quantise / base64 / vad energy on the same buffer
 q = torch.empty(y.numel(), dtype=torch.int16, device=dev)
 ms = timeit(lambda: lib.af_quantize_pcm16_device(P(y.data_ptr()), y.numel(), P(q.data_ptr()), None))

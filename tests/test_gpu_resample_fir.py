@@ -212,14 +212,26 @@ def test_fir_rejects_bad_tap_counts(af):
 
 
 # ---- banded-MFMA path specifics (audio-flow-rs_amd/csrc/banded_mfma.hip) -----------------------
-@pytest.mark.parametrize("K", [40, 161, 177, 178, 200])
+@pytest.mark.parametrize("K", [40, 161, 177, 178, 200, 352, 353, 529, 1024])
 def test_fir_mfma_boundary(af, po, K):
-    # <= 177 taps run on the MFMA kernel (NK <= 48), 178 and up on the VALU kernel
+    # <= 177 taps are one MFMA pass (NK <= 48); longer filters are cut into passes of 176 taps that
+    # accumulate into y (banded.hpp FirParts); "banded.off" = the thread-per-output kernel, same results
     rng = np.random.default_rng(K)
     taps = (rng.standard_normal(K) / K).astype(np.float32)
     x = synth_clip(K, 30011, 1, 16000)
     y = af.fir_batch(x.reshape(1, -1), taps)[0]
-    assert rel_err(y, po.fir(x, taps)) < 1e-5
+    ref = po.fir(x, taps)
+    assert rel_err(y, ref) < 1e-5
+    lib = af.library()
+    try:
+        assert lib.af_debug_set(b"banded.off", 1) == 0
+        assert rel_err(af.fir_batch(x.reshape(1, -1), taps)[0], ref) < 1e-5
+    finally:
+        lib.af_debug_set(b"banded.off", 0)
+    # streaming through the handle: chunking does not change a bit of the multi-pass result
+    f = af.FirFilter.new(taps)
+    got = np.concatenate([f.process(x[a:b]) for a, b in [(0, 5000), (5000, 5001), (5001, 20000), (20000, x.size)]])
+    assert rel_err(got, ref) < 1e-5 and np.max(np.abs(got - y)) <= 2e-6 * np.max(np.abs(y))
 
 
 @pytest.mark.parametrize("fi,fo", [(44100, 16000), (48000, 16000), (44100, 48000), (8000, 16000)])
