@@ -446,7 +446,6 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             }
         }
 
-        AF_STAMP2(5);
         if (!p.out_power) {
             // mel: banded W (A, registers) x P^T (B, bins x 16 frames from the power rows) on
             // v_mfma_f32_16x16x4_f32; all B operands first, then the chain; a slot that ends a group
@@ -460,6 +459,12 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
 #pragma unroll
                     for (int i = 0; i < kSlotSteps; ++i) bop[q * kSlotSteps + i] = bq[4 * i];
                 }
+            }
+            if constexpr (STAMPS) {                                  // diagnostics: operands and fragments landed
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                AF_STAMP2(6);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                AF_STAMP2(7);
             }
             float* obase = p.out + ud.out0 * n_mels;                // wave-uniform
             const bool fvalid = (lane & 15) < ud.n_rows;
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        AF_STAMP2(6);
+        AF_STAMP2(5);
         ++u;
         fresh = !has_next;
     }

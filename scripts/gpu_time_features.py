@@ -42,7 +42,7 @@ check(lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), stream)); to
 out = np.zeros(32, np.uint64)
 check(lib.af_features_debug_stamps(h, 0, out.ctypes.data))
 units = tot.value / 16
-names = ["desc load", "fresh+B1", "pf issue+part1", "wf issue+part2", "B2 wait", "tile write", "mel", "-"] if not GENERAL else ["B1 wait", "prefetch issue", "FFT phase", "B2 wait", "tile write", "mel operands", "mel mfma+store", "loop tail"]
+names = ["desc load", "fresh+B1", "pf issue+part1", "wf issue+part2", "B2 wait", "mel mfma+stores", "tile write+B reads", "wf landed"] if not GENERAL else ["B1 wait", "prefetch issue", "FFT phase", "B2 wait", "tile write", "mel operands", "mel mfma+store", "loop tail"]
 per = out.reshape(4, 8).astype(np.float64) / units
 print("cycles per unit (iteration), per wave:")
 for i, nm in enumerate(names): print(f"  {nm:15s}", " ".join(f"{per[w, i]:9.0f}" for w in range(4)))
