@@ -247,8 +247,10 @@ def main() -> None:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # the chip ramps its clocks over the first ~25 launches after idle (1.6 -> 1.2 ms per step under
+    # rocprofv3, profiles/r02_kernel_trace_ramp.txt): the defaults warm up past that
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (weak scaling)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --clips per GPU (BASELINE config 2 per GPU); strong: --total-clips split "

@@ -6,7 +6,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O="$GRAFT_REPO_ROOT/gpurun_out/r02p"
 rm -rf "$O" && mkdir -p "$O"
-B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary"
+B="python3 bench.py --no-cpu-baseline --no-secondary"          # the default steps / warmup
 R="python3 scripts/gpu_run_features.py 256 3"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- $B > "$O/kt.log" 2>&1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex af_features --output-format csv -d "$O/fetch" -- $R > "$O/fetch.log" 2>&1
