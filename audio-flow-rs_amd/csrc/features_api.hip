@@ -719,8 +719,9 @@ af_status af_features_mel_weights(const af_features* p, float* W, size_t cap)
 
 const char* af_features_kernel_name(void) { return "af_features_v2_kernel"; }   // the BASELINE configuration (hop 256); other hops: af_features_kernel
 
-// diagnostics, host only: the mel plans -- info[17] = {groups, K-steps, slots of wave 0..3} of the
-// general kernel, then {waves (0: not in use), groups, K-steps, slots of wave 0..7} of the hop-256 kernel
+// diagnostics, host only: the mel plans -- info[81] = {groups, K-steps, slots of wave 0..3} of the
+// general kernel, then {waves (0: not in use), groups, K-steps, slots of wave 0..7} of the hop-256 kernel,
+// then its slot_end words [8 waves][8 slots] (0: the group continues; else 0x10000 | filters << 8 | first filter)
 int af_features_plan_describe(const af_features* p, int32_t* info)
 {
     if (!p || !info) return 0;
@@ -731,6 +732,8 @@ int af_features_plan_describe(const af_features* p, int32_t* info)
     info[7] = p->plan8.n_groups;
     info[8] = p->plan8.n_steps;
     for (int w = 0; w < v2::kW; ++w) info[9 + w] = p->plan8.wave_nslots[w];
+    for (int w = 0; w < v2::kW; ++w)
+        for (int q = 0; q < 8; ++q) info[17 + 8 * w + q] = p->plan8.slot_end[w][q];
     return 1;
 }
 

@@ -290,9 +290,10 @@ af_status af_pipeline_run(const af_batch_desc* batch, const void* pcm, size_t pc
 af_status af_features_mel_weights(const af_features* p, float* W, size_t cap);
 /* name and launch geometry of the fused kernel, for profiling harnesses */
 const char* af_features_kernel_name(void);
-/* diagnostics, host only: the mel plans of a handle, info[17] = {filter groups, MFMA K-steps,
+/* diagnostics, host only: the mel plans of a handle, info[81] = {filter groups, MFMA K-steps,
  * 4-step slots of wave 0..3} of the general kernel, then {waves (0: not in use), groups, K-steps,
- * slots of wave 0..7} of the hop-256 kernel */
+ * slots of wave 0..7} of the hop-256 kernel, then that kernel's per-slot group ends [8 waves][8 slots]
+ * (0: the group continues; else 0x10000 | filters << 8 | first filter) */
 int       af_features_plan_describe(const af_features* p, int32_t* info);
 /* diagnostics: enable/disable in-kernel phase stamps; out[32] (optional) receives the
  * [wave][phase] shader-cycle sums recorded since they were enabled */
