@@ -125,7 +125,7 @@ size_t af_ring_capacity(const af_ring* r) { return r ? r->capacity : 0; }
 
 size_t af_ring_write(af_ring* r, const float* data, size_t n)
 {
-    if (!r || (!data && n)) return 0;
+    if (!r || !data || n == 0) return 0;
     std::lock_guard<std::mutex> lock(r->mu);
     if (r->capacity == 0) return 0;                                 // (the reference would divide by zero)
     const size_t available = r->capacity - r->used();               // capture.rs:108-110
