@@ -1,11 +1,15 @@
 """A/B timings of the banded MFMA kernel (config 3 resample, 48k->16k, FIR 129)."""
-import ctypes as C, os, sys, json
+import ctypes as C, os, sys, json, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import audio_flow_rs_amd as af
 lib = af.library(); dev = torch.device("cuda:0"); P = C.c_void_p
 def timeit(fn, k=5, w=2):
+    # the chip ramps its clocks for ~25 launches / ~50 ms after idle: warm up past that, whatever w says
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.15: fn(); torch.cuda.synchronize()
     for _ in range(w): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
