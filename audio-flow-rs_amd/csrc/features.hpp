@@ -48,8 +48,8 @@ struct Plan {
 
 // ---- hop-256 kernel (features_v2.hip) ---------------------------------------------------------
 // One wave64 owns one frame pair (f, f+1) packed as one 1024-point complex FFT done as
-// 16 x 16 x 4 with 16 register-resident points per lane and two transpositions through a
-// wave-private LDS buffer; 8 waves = one 16-frame unit, two workgroups per CU = 4 waves per SIMD.
+// 16 x 16 x 4 with 16 register-resident points per lane, one transposition through a wave-private
+// LDS buffer and one in registers; 8 waves = one 16-frame unit, two workgroups per CU = 4 waves per SIMD.
 namespace v2 {
 constexpr int kW = 8;                     // waves per workgroup
 constexpr int kT = 64 * kW;               // threads per workgroup
@@ -60,7 +60,6 @@ constexpr int kWb = 1284;                 // per-wave LDS buffer in dwords (== 4
                                           // k-groups of a mel operand read fall into 32 different banks)
 constexpr int kT1Row = 66;                // first transposition: row k1 = 64 columns + 2 (bank-conflict-free
                                           // column reads by lanes (k1, c): 2 k1 + c)
-constexpr int kT2Plane = 80;              // second transposition: plane b = 64 columns + 16
 constexpr int kWinRow2 = 20;              // window table row (lane n2): 16 values + 4 pad
 constexpr int kTw1Row = 36;               // twiddle table row (lane n2): 16 (cos, sin) + 4 pad
 constexpr int kTw2Row = 36;               // second twiddle table row (c = 0..3): 16 (cos, sin) + 4 pad

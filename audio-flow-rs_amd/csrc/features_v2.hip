@@ -18,7 +18,8 @@
 //   * split of the packed spectrum: Z[1024 - k] sits in lane (64 - L) % 64, register 15 - t
 //     (lane 0: 16 - t), exchanged through the same buffer; power rows [frame][514] in LDS.
 //   * mel: the banded filterbank groups are dealt to the 8 waves (features_api.hip build_plan),
-//     v_mfma_f32_16x16x4_f32, A fragments resident in registers for the whole launch.
+//     v_mfma_f32_16x16x4_f32; a wave's A fragments (L2-resident) are fetched once per unit, after
+//     stage 1, where the register pressure has dropped.
 //   * every unit is described by one 32-byte record (UnitDesc, built on the host): no clip search,
 //     no 64-bit index arithmetic in the loop.
 #include "features_dev.hpp"
