@@ -35,6 +35,7 @@ enum DebugKnob {
     kKnobFeaturesKernel = 0,   // 1: the general fused kernel also at hop 256
     kKnobFeaturesWgPerCu,      // 1, 2: workgroups per CU of the fused kernels
     kKnobBandedOff,            // 1: resampler / FIR on the thread-per-output kernels
+    kKnobChainUnfused,         // 1: the chain runs resampler and FIR as two launches
     kKnobCount
 };
 int debug_knob(DebugKnob k);

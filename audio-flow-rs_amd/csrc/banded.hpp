@@ -77,5 +77,30 @@ af_status launch_fir(const FirParts& p, const float* afrag_dev, const float* x_d
                      int64_t x_stride, float* y_dev, int64_t y_stride, int64_t m0, int64_t n_out,
                      int64_t n_clips, hipStream_t stream);
 
+// The resampler followed by a FIR (BASELINE config 4's middle stages) as ONE launch: the resampled
+// signal only exists in LDS.  Covered: ratios with a single block matrix (L divides 16: 48 k / 32 k ->
+// 16 k, 48 k -> 24 k ...), FIRs of at most 129 taps; everything else runs the two kernels above.
+struct FusedPlan {
+    bool ok = false;
+    Plan a;                    // the resampler's plan (a.ch = 2: stereo input, downmixed while staged)
+    int K = 0;                 // FIR taps
+    int NKB = 0;               // MFMA steps of the FIR chain (20 or 36)
+    int H2 = 0, pad = 0;       // resampled samples recomputed per tile (multiple of 16), H2 - (K - 1)
+    int P2 = 0;                // FIR block periods per column and tile
+    int seg_len_b = 0, seg_stride_b = 0;
+    int64_t z_per_tile = 0;    // 256 * P2
+    size_t smem = 0;
+    size_t afrag_b_floats() const { return (size_t)NKB * 64; }
+};
+FusedPlan make_fused_plan(const Plan& resampler, int K);
+af_status build_fused_fir_afrag(const FusedPlan& f, const float* taps_dev, float* afrag_dev, hipStream_t stream);
+// z[clip][n] = FIR(resample(x[clip]))[n], n < n_res = the resampler's output length for x_len frames
+af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* afrag_b, const float* x_dev,
+                       int64_t x_len, int64_t x_stride, float* z_dev, int64_t z_stride, int64_t n_res,
+                       int64_t n_clips, hipStream_t stream);
+
 }  // namespace banded
+
+// resample.hip: MFMA plan (ch = 1 | 2) and device fragments of the cached design for a rate pair.
+af_status resampler_fragments(uint32_t in_hz, uint32_t out_hz, int ch, banded::Plan* plan, const float** afrag_dev);
 }  // namespace af

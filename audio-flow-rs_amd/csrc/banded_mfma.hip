@@ -241,6 +241,230 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     }
 }
 
+// ---- resampler + FIR of BASELINE config 4 in one launch -----------------------------------------
+// Phase A is the banded resampler above (one block matrix, 8 waves) writing its 256 G outputs of a
+// tile into LDS instead of HBM, already cut into the 16 column segments of phase B; phase B is the
+// banded FIR over those segments.  A FIR output needs K - 1 resampled samples of history, so
+// consecutive tiles overlap by H2 = 16 ceil((K - 1) / 16) resampled samples (recomputed, 1 / G of the
+// phase-A work) and a tile yields P2 = G - 1 FIR block periods per column.  Block alignment, k-slot
+// mapping and chain order are those of the stand-alone kernels, so with the same NK the output is
+// theirs bit for bit.
+struct FusedGeom {
+    const float* x;                  // [clip][frame][CH]
+    float* z;                        // [clip][n_res]
+    const float* afrag_a;            // resampler fragments [NKA][64]
+    const float* afrag_b;            // FIR fragments [NKB][64]
+    int64_t x_len, x_stride, z_stride, n_res;
+    int64_t tiles_per_clip, n_tiles;
+    int lo_off;                      // resampler: c - (T - 1)
+    int S, G, gpw, seg_len, seg_stride;
+    int H2, pad, P2, seg_len_b, seg_stride_b, ys_off;
+    float inv_colz;                  // 1 / (16 P2)
+};
+
+// One pair of MFMA chains over two block periods; `issue(t)` may put global loads between the steps.
+template <int NK, class Issue>
+__device__ __forceinline__ void chain2(const float (&a)[NK], const float* b0p, const float* b1p, const float* t0p,
+                                       const float* t1p, f32x4& acc0, f32x4& acc1, Issue&& issue)
+{
+    constexpr int FULL = NK / 16;
+    constexpr int kAhead = 3;
+    float w0[kAhead + 1], w1[kAhead + 1];
+    auto read_b = [&](int t) {
+        w0[t % (kAhead + 1)] = t < 16 * FULL ? b0p[64 * (t / 16) + (t % 16)] : t0p[t - 16 * FULL];
+        w1[t % (kAhead + 1)] = t < 16 * FULL ? b1p[64 * (t / 16) + (t % 16)] : t1p[t - 16 * FULL];
+    };
+#pragma unroll
+    for (int t = 0; t < kAhead && t < NK; ++t) read_b(t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NK; ++t) {
+        if (t + kAhead < NK) read_b(t + kAhead);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w0[t % (kAhead + 1)], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w1[t % (kAhead + 1)], acc1, 0, 0, 0);
+        issue(t);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NKA, int NKB, int CH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void resfir_kernel(const FusedGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    float* ys = xs + g.ys_off;
+    constexpr int FULLA = NKA / 16, TAILA = NKA % 16, FULLB = NKB / 16, TAILB = NKB % 16;
+    constexpr int nthreads = 512;
+    constexpr int kGpw = 2;                                         // G = 16: one chain pair per wave and phase
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g4 = lane >> 4;
+
+    const int wave_off_a = wave * kGpw * g.S;
+    const int base_full_a = col * g.seg_stride + 16 * g4 + wave_off_a;
+    const int base_tail_a = col * g.seg_stride + TAILA * g4 + 64 * FULLA + wave_off_a;
+    const int wave_off_b = wave * kGpw * 16;
+    const int base_full_b = col * g.seg_stride_b + 16 * g4 + wave_off_b;
+    const int base_tail_b = col * g.seg_stride_b + TAILB * g4 + 64 * FULLB + wave_off_b;
+    const int y_lane = 16 * (col * g.G + wave * kGpw) + 4 * g4;     // tile-relative resampled index of acc0[0]
+    const int z_lane = 16 * (col * g.P2 + wave * kGpw) + 4 * g4;    // tile-relative FIR output of acc0[0]
+    const int colz = 16 * g.P2, z_per_tile = 16 * colz, y_per_tile = 256 * g.G;
+    const int col_span = g.G * g.S;
+    const bool first = tid < g.seg_len;
+    const bool second = tid + nthreads < g.seg_len;
+    const uint32_t tpc = (uint32_t)g.tiles_per_clip, n_tiles = (uint32_t)g.n_tiles;
+
+    // Register plan (128 per lane, 4 waves per SIMD): a phase only holds its own fragments -- they are
+    // fetched again (L2) per tile, the resampler's before the first barrier, the FIR's while the
+    // resampled samples go to LDS.  The next tile's x is requested in two halves: slot 0 (CH = 1: all
+    // of it) in the first half of phase A, slot 1 in the back half of phase B where the FIR fragments
+    // are dying, so at most 32 staging registers are live next to a full set of fragments.
+    float a1[NKA], a2[NKB];
+    auto load_a1 = [&](int oz) {
+#pragma unroll
+        for (int t = 0; t < NKA; ++t) a1[t] = g.afrag_a[t * 64 + lane + oz];
+    };
+    auto load_a2 = [&](int oz) {
+#pragma unroll
+        for (int t = 0; t < NKB; ++t) a2[t] = g.afrag_b[t * 64 + lane + oz];
+    };
+
+    constexpr uint32_t kOob = 0xFFF00000u;
+    float pf[kCols * kPfSlots * CH];
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[kPfSlots];
+    auto prep_tile = [&](uint32_t tile, bool live) {
+        const uint32_t clip = tile / tpc;
+        const int64_t t = tile - clip * tpc;
+        // x index of the first window sample of the tile: q(y0) + lo_off, y0 = t z_per_tile - H2
+        const int64_t base = (t * (int64_t)(16 * g.P2) - g.H2 / 16) * g.S + g.lo_off;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride * CH), 0,
+                                                 (int)(uint32_t)(g.x_len * 4 * CH), 0x00020000);
+        const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * (4u * CH);
+        voff[0] = live && first ? v0 : kOob;
+        voff[1] = live && second ? v0 + (uint32_t)nthreads * (4u * CH) : kOob;
+    };
+    auto issue_load = [&](int s) {                                  // s = h * 16 + cc
+        const int cc = s % kCols, h = s / kCols;
+        if constexpr (CH == 1) {
+            pf[cc * kPfSlots + h] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
+        } else {
+            const int off = (int)(voff[h] + (uint32_t)(cc * col_span) * 8u);
+            pf[(cc * kPfSlots + h) * 2] =
+                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+            pf[(cc * kPfSlots + h) * 2 + 1] =
+                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0));
+        }
+    };
+    constexpr int kLoads = kCols * kPfSlots;
+    constexpr int kLoadsA = CH == 1 ? kLoads : kCols;               // requested during phase A
+
+    uint32_t tile = blockIdx.x;
+    if (tile < n_tiles) {
+        prep_tile(tile, true);
+#pragma unroll
+        for (int s2 = 0; s2 < kLoads; ++s2) issue_load(s2);
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
+        // No barrier here: xs was last read in phase A and ys in phase B of the previous tile; a wave
+        // writes xs before, and ys after, the next barrier, which every wave reaches after its phase B.
+        {
+            float* dst = xs + tid + opaque_zero();
+            auto staged = [&](int cc, int h) {
+                if constexpr (CH == 1) return pf[cc * kPfSlots + h];
+                else return (pf[(cc * kPfSlots + h) * 2] + pf[(cc * kPfSlots + h) * 2 + 1]) * 0.5f;
+            };
+            if (first) {
+#pragma unroll
+                for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = staged(cc, 0);
+            }
+            if (second) {
+#pragma unroll
+                for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = staged(cc, 1);
+            }
+        }
+        load_a1(opaque_zero());
+        __syncthreads();
+        const uint32_t clip = tile / tpc;
+        const int64_t t_in_clip = tile - clip * tpc;
+        {
+            const bool live = tile + gridDim.x < n_tiles;
+            prep_tile(live ? tile + gridDim.x : tile, live);
+        }
+
+        // ---- phase A: resampled samples [y0, y0 + 256 G) into the FIR's column segments ----
+        const int64_t z0 = t_in_clip * z_per_tile;                   // first FIR output of the tile
+        {
+            const int64_t y0 = z0 - g.H2;
+            // resampled samples outside [0, n_res) are the FIR's zero initial state / never used
+            const int y_lo = y0 >= 0 ? 0 : (int)-y0;
+            const int64_t y_left = g.n_res - y0;
+            const int y_hi = y_left > y_per_tile ? y_per_tile : (int)y_left;
+            const float* b0p = xs + base_full_a;
+            const float* t0p = xs + base_tail_a;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            chain2<NKA>(a1, b0p, b0p + g.S, t0p, t0p + g.S, acc0, acc1, [&](int t) {
+                constexpr int kSpan = (NKA + 1) / 2;
+                if (t < kSpan) {
+#pragma unroll
+                    for (int s2 = (kLoadsA * t) / kSpan; s2 < (kLoadsA * (t + 1)) / kSpan; ++s2) issue_load(s2);
+                }
+            });
+            load_a2(opaque_zero());
+            // branch-free: a sample that belongs to no segment (or to only one) goes to this lane's
+            // spare word behind the segments
+            const int spare = kCols * g.seg_stride_b + lane;
+            auto put_y = [&](int yi, float v) {
+                v = (yi >= y_lo && yi < y_hi) ? v : 0.0f;
+                const int e = yi - g.pad;
+                const int c = (int)(((float)e + 0.5f) * g.inv_colz);    // e / colz for e >= 0
+                const int pos = e - c * colz;
+                const int at = c * g.seg_stride_b + pos;
+                ys[(e >= 0 && c < kCols) ? at : spare] = v;
+                ys[(e >= colz && c <= kCols && pos + colz < g.seg_len_b) ? at - g.seg_stride_b + colz : spare] = v;
+            };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                put_y(y_lane + j, acc0[j]);
+                put_y(y_lane + 16 + j, acc1[j]);
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: the FIR over the segments, P2 valid block periods per column ----
+        {
+            float* zc = g.z + (int64_t)clip * g.z_stride + z0;
+            const int64_t z_left = g.n_res - z0;
+            const int z_hi = z_left > z_per_tile ? z_per_tile : (int)z_left;
+            const bool whole = z_hi == z_per_tile && ((reinterpret_cast<uintptr_t>(zc) >> 2) & 3) == 0;
+            const float* b0p = ys + base_full_b;
+            const float* t0p = ys + base_tail_b;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            chain2<NKB>(a2, b0p, b0p + 16, t0p, t0p + 16, acc0, acc1, [&](int t) {
+                constexpr int kFrom = NKB / 2, kSpan = NKB - kFrom - 2;
+                if (kLoadsA < kLoads && t >= kFrom && t < kFrom + kSpan) {
+#pragma unroll
+                    for (int s2 = kLoadsA + ((kLoads - kLoadsA) * (t - kFrom)) / kSpan;
+                         s2 < kLoadsA + ((kLoads - kLoadsA) * (t - kFrom + 1)) / kSpan; ++s2)
+                        issue_load(s2);
+                }
+            });
+            const int pr0 = wave * kGpw;                             // block period of acc0 (wave-uniform)
+            const int o0 = z_lane, o1 = o0 + 16;
+            if (whole) {
+                if (pr0 < g.P2) *reinterpret_cast<f32x4*>(zc + o0) = acc0;
+                if (pr0 + 1 < g.P2) *reinterpret_cast<f32x4*>(zc + o1) = acc1;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (pr0 < g.P2 && o0 + j < z_hi) zc[o0 + j] = acc0[j];
+                    if (pr0 + 1 < g.P2 && o1 + j < z_hi) zc[o1 + j] = acc1[j];
+                }
+            }
+        }
+    }
+}
+
 const int kNkInstances[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 48};
 
 template <int NK>
@@ -417,6 +641,110 @@ af_status launch_fir(const FirParts& p, const float* afrag_dev, const float* x_d
         AF_TRY(launch(p.plan[j], afrag_dev + p.afrag_off[j], x_dev, x_abs0, x_len, x_stride, y_dev, y_stride, m0,
                       n_out, n_clips, stream, j > 0));
     return AF_OK;
+}
+
+// ---- fused resampler + FIR ------------------------------------------------------------------------
+namespace {
+
+template <int NKA, int NKB, int CH>
+af_status launch_resfir(const FusedGeom& g, unsigned grid, size_t smem, hipStream_t s)
+{
+    static bool attr_set[kMaxDevices] = {};
+    AF_HIP(allow_big_lds(resfir_kernel<NKA, NKB, CH>, 160 * 1024, attr_set));
+    hipLaunchKernelGGL((resfir_kernel<NKA, NKB, CH>), dim3(grid), dim3(512), smem, s, g);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+template <int NKA, int CH>
+af_status launch_resfir_b(int nkb, const FusedGeom& g, unsigned grid, size_t smem, hipStream_t s)
+{
+    switch (nkb) {
+    case 20: return launch_resfir<NKA, 20, CH>(g, grid, smem, s);
+    case 36: return launch_resfir<NKA, 36, CH>(g, grid, smem, s);
+    default: return fail(AF_ERR_UNSUPPORTED, "no fused kernel for a FIR of %d steps", nkb);
+    }
+}
+
+}  // namespace
+
+FusedPlan make_fused_plan(const Plan& a, int K)
+{
+    FusedPlan f;
+    f.a = a;
+    f.K = K;
+    if (!a.ok || a.nb != 1 || a.nwaves != 8 || K < 1) return f;
+    if (a.NK != 24 && a.NK != 28) return f;                    // the instances built below
+    const int need = 16 * ((K + 15) / 64) + (((K + 15) % 64) + 3) / 4;
+    f.NKB = need <= 20 ? 20 : need <= 36 ? 36 : 0;
+    if (!f.NKB) return f;
+    f.H2 = 16 * ((K - 1 + 15) / 16);
+    f.pad = f.H2 - (K - 1);
+    f.P2 = a.G - 1;
+    if (a.G != 16 || f.H2 > 256) return f;                    // one chain pair per wave and phase
+    f.seg_len_b = (a.G - 1) * 16 + 4 * f.NKB;
+    f.seg_stride_b = f.seg_len_b | 1;
+    if (f.seg_len_b - 16 * f.P2 > 16 * f.P2) return f;         // a sample lands in at most two segments
+    // every window sample phase B reads is a resampled sample of this tile
+    if (15 * 16 * f.P2 + f.pad + f.seg_len_b > 256 * a.G) return f;
+    f.z_per_tile = (int64_t)256 * f.P2;
+    f.smem = ((size_t)kCols * (a.seg_stride + f.seg_stride_b) + 64) * sizeof(float);   // + one spare word per lane
+    if (2 * f.smem > 160 * 1024) return f;                     // two workgroups per CU or not at all
+    f.ok = true;
+    return f;
+}
+
+af_status build_fused_fir_afrag(const FusedPlan& f, const float* taps_dev, float* afrag_dev, hipStream_t stream)
+{
+    const int n = f.NKB * 64;
+    hipLaunchKernelGGL(build_afrag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, taps_dev, afrag_dev, 1u, 1u,
+                       f.K, 1, f.NKB);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* afrag_b, const float* x_dev,
+                       int64_t x_len, int64_t x_stride, float* z_dev, int64_t z_stride, int64_t n_res,
+                       int64_t n_clips, hipStream_t stream)
+{
+    if (n_res <= 0 || n_clips <= 0) return AF_OK;
+    if (!f.ok) return fail(AF_ERR_UNSUPPORTED, "banded::launch_fused without a plan");
+    if (!fits(f.a, x_len))
+        return fail(AF_ERR_UNSUPPORTED, "clips of %lld frames are beyond the banded kernel's 32-bit offsets",
+                    (long long)x_len);
+    FusedGeom g{};
+    g.x = x_dev;
+    g.z = z_dev;
+    g.afrag_a = afrag_a;
+    g.afrag_b = afrag_b;
+    g.x_len = x_len;
+    g.x_stride = x_stride;
+    g.z_stride = z_stride;
+    g.n_res = n_res;
+    g.tiles_per_clip = (n_res + f.z_per_tile - 1) / f.z_per_tile;
+    g.n_tiles = g.tiles_per_clip * n_clips;
+    if (g.n_tiles >= (1ll << 31)) return fail(AF_ERR_UNSUPPORTED, "banded::launch_fused: too many tiles");
+    g.lo_off = f.a.c - (f.a.T - 1);
+    g.S = f.a.S;
+    g.G = f.a.G;
+    g.gpw = f.a.G / f.a.wpp;
+    g.seg_len = f.a.seg_len;
+    g.seg_stride = f.a.seg_stride;
+    g.H2 = f.H2;
+    g.pad = f.pad;
+    g.P2 = f.P2;
+    g.seg_len_b = f.seg_len_b;
+    g.seg_stride_b = f.seg_stride_b;
+    g.ys_off = kCols * f.a.seg_stride;
+    g.inv_colz = 1.0f / (float)(16 * f.P2);
+    int64_t grid = g.n_tiles;
+    const int64_t cap = 2 * (int64_t)device_cu_count(current_device());
+    if (grid > cap) grid = cap;
+    if (f.a.NK == 24)
+        return f.a.ch == 2 ? launch_resfir_b<24, 2>(f.NKB, g, (unsigned)grid, f.smem, stream)
+                           : launch_resfir_b<24, 1>(f.NKB, g, (unsigned)grid, f.smem, stream);
+    return f.a.ch == 2 ? launch_resfir_b<28, 2>(f.NKB, g, (unsigned)grid, f.smem, stream)
+                       : launch_resfir_b<28, 1>(f.NKB, g, (unsigned)grid, f.smem, stream);
 }
 
 }  // namespace banded

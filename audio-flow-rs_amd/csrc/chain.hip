@@ -1,14 +1,17 @@
 // chain.hip -- the full feature chain of BASELINE config 4 as one handle:
 //   interleaved PCM -> to_mono [R capture.rs:30-42] -> polyphase resample [B]
 //   -> FIR [B] -> Hann STFT -> |X|^2 -> mel [B]
-// Every stage is the corresponding device entry point of this library, enqueued
-// back to back on the caller's stream; all intermediate buffers are allocated
-// when the batch is described, so af_chain_run_device() only launches kernels
-// (it can be captured into a hipGraph and replayed per streaming step).
+// Two launches where the shapes allow it (banded::FusedPlan: downmix + resampler + FIR in one kernel,
+// the 16 kHz signal before the FIR only exists in LDS; then the fused STFT / mel kernel), otherwise
+// every stage is the corresponding device entry point of this library, enqueued back to back on the
+// caller's stream.  All intermediate buffers are allocated when the batch is described, so
+// af_chain_run_device() only launches kernels (it can be captured into a hipGraph and replayed per
+// streaming step).
 #include <new>
 #include <vector>
 
 #include "af_common.hpp"
+#include "banded.hpp"
 
 using namespace af;
 
@@ -16,9 +19,32 @@ struct af_chain {
     af_chain_config cfg{};
     af_features* feat = nullptr;
     af_fir* fir = nullptr;           // taps + MFMA fragments, built once
+    banded::FusedPlan fused;         // ok: resampler + FIR are one launch
+    const float* afrag_res = nullptr;
+    DevBuf d_afrag_fir;
     DevBuf d_mono, d_res, d_fir, d_pcm, d_mel;
     size_t n_clips = 0, n_in = 0, n_res = 0, total_frames = 0;
 };
+
+namespace {
+
+// Resampler and FIR as one launch when the shapes are covered (banded.hpp, FusedPlan).
+af_status plan_fused(af_chain* c, const float* taps)
+{
+    banded::Plan rp;
+    AF_TRY(resampler_fragments(c->cfg.input_rate, c->cfg.output_rate, (int)c->cfg.channels, &rp, &c->afrag_res));
+    c->fused = banded::make_fused_plan(rp, (int)c->cfg.n_fir_taps);
+    if (!c->fused.ok) return AF_OK;
+    DevBuf d_taps;
+    AF_TRY(d_taps.reserve(c->cfg.n_fir_taps * sizeof(float)));
+    AF_TRY(c->d_afrag_fir.reserve(c->fused.afrag_b_floats() * sizeof(float)));
+    AF_HIP(hipMemcpy(d_taps.p, taps, c->cfg.n_fir_taps * sizeof(float), hipMemcpyHostToDevice));
+    AF_TRY(banded::build_fused_fir_afrag(c->fused, d_taps.as<float>(), c->d_afrag_fir.as<float>(), nullptr));
+    AF_HIP(hipStreamSynchronize(nullptr));
+    return AF_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -63,6 +89,7 @@ af_status af_chain_create(const af_chain_config* cfg, af_chain** out)
     // everything run_device needs is built here, so that it only launches kernels
     if (st == AF_OK && cfg->n_fir_taps) st = af_fir_create(cfg->fir_taps, cfg->n_fir_taps, &c->fir);
     if (st == AF_OK) st = af_resample_prepare(cfg->input_rate, cfg->output_rate);
+    if (st == AF_OK && cfg->n_fir_taps && cfg->input_rate != cfg->output_rate) st = plan_fused(c, cfg->fir_taps);
     if (st != AF_OK) { af_chain_destroy(c); return st; }
     *out = c;
     return AF_OK;
@@ -107,6 +134,12 @@ af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev,
     AF_REQUIRE(pcm_dev && (mel_dev || c->total_frames == 0), "af_chain_run_device: null buffer");
     const float* cur = pcm_dev;
     const bool resample = c->cfg.input_rate != c->cfg.output_rate;
+    if (c->fused.ok && !debug_knob(kKnobChainUnfused) && banded::fits(c->fused.a, (int64_t)c->n_in)) {
+        AF_TRY(banded::launch_fused(c->fused, c->afrag_res, c->d_afrag_fir.as<float>(), cur, (int64_t)c->n_in,
+                                    (int64_t)c->n_in, c->d_fir.as<float>(), (int64_t)c->n_res, (int64_t)c->n_res,
+                                    (int64_t)c->n_clips, as_stream(stream)));
+        return af_features_run_device(c->feat, c->d_fir.as<float>(), mel_dev, stream);
+    }
     if (c->cfg.channels == 2 && resample &&
         af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate)) {
         // downmix fused into the resampler's loads: the mono signal never reaches HBM

@@ -50,7 +50,8 @@ af_status ensure_device(int device)
 
 namespace {
 std::atomic<int> g_knobs[kKnobCount];
-const char* const kKnobNames[kKnobCount] = {"features.kernel", "features.wg_per_cu", "banded.off"};
+const char* const kKnobNames[kKnobCount] = {"features.kernel", "features.wg_per_cu", "banded.off",
+                                            "chain.unfused"};
 }  // namespace
 
 int debug_knob(DebugKnob k) { return g_knobs[k].load(std::memory_order_relaxed); }

@@ -409,6 +409,20 @@ af_status cached_design(uint32_t in_hz, uint32_t out_hz, rs::Design** out)
 
 }  // namespace
 
+namespace af {
+
+// The cached design's MFMA plan and fragments for the fused chain stage (chain.hip).
+af_status resampler_fragments(uint32_t in_hz, uint32_t out_hz, int ch, banded::Plan* plan, const float** afrag_dev)
+{
+    rs::Design* d = nullptr;
+    AF_TRY(cached_design(in_hz, out_hz, &d));
+    *plan = ch == 2 ? d->plan2 : d->plan;
+    *afrag_dev = d->d_afrag.as<float>();
+    return AF_OK;
+}
+
+}  // namespace af
+
 extern "C" {
 
 af_status af_resample_batch_device(uint32_t input_rate, uint32_t output_rate, const float* in_dev,

@@ -54,7 +54,8 @@ int         af_device_count(void);
  * profiling scripts; value 0 restores the product behaviour.
  *   "features.kernel"     1: the general fused STFT+mel kernel also where the hop-256 kernel applies
  *   "features.wg_per_cu"  workgroups per CU of the fused kernels
- *   "banded.off"          1: resampler / FIR on the thread-per-output kernels instead of MFMA */
+ *   "banded.off"          1: resampler / FIR on the thread-per-output kernels instead of MFMA
+ *   "chain.unfused"       1: af_chain_* runs resampler and FIR as two launches instead of one */
 af_status   af_debug_set(const char* key, int value);
 
 /* ------------------------------------------------------------------ [R] */
