@@ -123,6 +123,8 @@ SIGNATURES = {
     "af_resample_has_stereo_path": (C.c_int, [_u32, _u32]),
     "af_resample_prepare": (_st, [_u32, _u32]),
     "af_resample_plan_describe": (C.c_int, [_u32, _u32, _u32, _vp]),
+    "af_chain_fused_plan_describe": (C.c_int, [_u32, _u32, _u32, _sz, _vp]),
+    "af_chain_n_launches": (C.c_int, [_vp]),
     "af_resample_taps": (_st, [_u32, _u32, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32),
                                C.POINTER(_u32)]),
     # BatchResampler

@@ -727,6 +727,10 @@ class ChainPipeline:
         _check(self._lib.af_chain_run_device(self._h, C.c_void_p(pcm_ptr), C.c_void_p(mel_ptr),
                                              C.c_void_p(stream)))
 
+    def n_launches(self) -> int:
+        """Kernels one run_device() enqueues for the batch described (2 with the fused resampler + FIR stage)."""
+        return int(self._lib.af_chain_n_launches(self._h))
+
     def run(self, pcm) -> np.ndarray:
         x = np.ascontiguousarray(pcm, np.float32).reshape(-1)
         mel = np.empty((self.total_frames, self.cfg.n_mels), np.float32)

@@ -19,6 +19,8 @@
 namespace af {
 namespace banded {
 
+constexpr int kResamplerTaps = 64;   // taps per phase of the polyphase resampler (docs/OPS.md)
+
 struct Plan {
     bool ok = false;          // false: shape not covered, the caller runs its VALU kernel
     uint32_t L = 1, M = 1;

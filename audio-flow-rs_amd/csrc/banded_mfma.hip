@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // Register plan (128 per lane, 4 waves per SIMD): a phase only holds its own fragments -- they are
     // fetched again (L2) per tile, the resampler's before the first barrier, the FIR's while the
     // resampled samples go to LDS.  The next tile's x is requested in two halves: slot 0 (CH = 1: all
-    // of it) in the first half of phase A, slot 1 in the back half of phase B where the FIR fragments
+    // of it) in the first half of phase A, slot 1 step by step through phase B while the FIR fragments
     // are dying, so at most 32 staging registers are live next to a full set of fragments.
     float a1[NKA], a2[NKB];
     auto load_a1 = [&](int oz) {
@@ -441,7 +441,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const float* t0p = ys + base_tail_b;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             chain2<NKB>(a2, b0p, b0p + 16, t0p, t0p + 16, acc0, acc1, [&](int t) {
-                constexpr int kFrom = NKB / 2, kSpan = NKB - kFrom - 2;
+                // one request per step from the start: a fragment register dies per step, and the
+                // earlier a load goes out the more of the phase covers its latency
+                constexpr int kFrom = 2, kSpan = NKB - 4;
                 if (kLoadsA < kLoads && t >= kFrom && t < kFrom + kSpan) {
 #pragma unroll
                     for (int s2 = kLoadsA + ((kLoads - kLoadsA) * (t - kFrom)) / kSpan;

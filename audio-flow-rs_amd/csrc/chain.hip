@@ -8,6 +8,7 @@
 // af_chain_run_device() only launches kernels (it can be captured into a hipGraph and replayed per
 // streaming step).
 #include <new>
+#include <numeric>
 #include <vector>
 
 #include "af_common.hpp"
@@ -162,6 +163,40 @@ af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev,
         cur = c->d_fir.as<float>();
     }
     return af_features_run_device(c->feat, cur, mel_dev, stream);
+}
+
+int af_chain_n_launches(const af_chain* c)
+{
+    if (!c) return 0;
+    const bool resample = c->cfg.input_rate != c->cfg.output_rate;
+    if (c->fused.ok && !debug_knob(kKnobChainUnfused) && banded::fits(c->fused.a, (int64_t)c->n_in)) return 2;
+    int n = 1;                                                  // the STFT / mel kernel
+    if (c->cfg.n_fir_taps) {
+        const banded::FirParts fp = banded::make_fir_parts((int)c->cfg.n_fir_taps);
+        n += fp.ok() ? fp.n : 1;
+    }
+    if (resample) n += 1;
+    if (c->cfg.channels == 2 &&
+        !(resample && af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate)))
+        n += 1;                                                 // stand-alone to_mono
+    return n;
+}
+
+int af_chain_fused_plan_describe(uint32_t input_rate, uint32_t output_rate, uint32_t channels, size_t n_fir_taps,
+                                 int32_t* info)
+{
+    if (!info || !input_rate || !output_rate || (channels != 1 && channels != 2)) return 0;
+    for (int i = 0; i < 10; ++i) info[i] = 0;
+    if (input_rate == output_rate || n_fir_taps == 0 || n_fir_taps > 1024) return 0;
+    const uint32_t g = std::gcd(input_rate, output_rate);
+    const banded::Plan rp = banded::make_plan(output_rate / g, input_rate / g, banded::kResamplerTaps,
+                                              banded::kResamplerTaps / 2, (int)channels);
+    const banded::FusedPlan f = banded::make_fused_plan(rp, (int)n_fir_taps);
+    const int32_t v[10] = {f.ok ? 1 : 0, f.a.NK, f.NKB, f.H2, f.pad, f.P2, f.seg_len_b, f.seg_stride_b,
+                           (int32_t)f.z_per_tile, (int32_t)f.smem};
+    if (f.ok)
+        for (int i = 0; i < 10; ++i) info[i] = v[i];
+    return f.ok ? 1 : 0;
 }
 
 af_status af_chain_run(af_chain* c, const float* pcm, size_t pcm_len, float* mel, size_t mel_cap)

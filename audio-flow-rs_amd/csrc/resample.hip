@@ -30,7 +30,7 @@
 namespace af {
 namespace rs {
 
-constexpr int kT = 64;                  // taps per phase
+constexpr int kT = banded::kResamplerTaps;   // taps per phase
 constexpr int kRow = kT + 4;            // padded LDS row
 constexpr int kBlock = 256;
 constexpr int kOutPerThread = 4;

@@ -224,11 +224,13 @@ def chain_secondary(torch, af, dev, pcm, n_clips: int, n_frames_pcm: int, stream
     chain = af.ChainPipeline(input_rate=SR, channels=CHANNELS, output_rate=16000, fir_taps=taps)
     total = chain.set_batch_uniform(n_clips, n_frames_pcm)
     out = torch.empty(total, N_MELS, device=dev, dtype=torch.float32)
-    for _ in range(2):
+    # the chip is back at idle clocks after the host-side oracle check: warm up past the ramp first
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.2:
         chain.run_device(pcm.data_ptr(), out.data_ptr(), stream)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
+    reps = 20
     e0.record()
     for _ in range(reps):
         chain.run_device(pcm.data_ptr(), out.data_ptr(), stream)
@@ -240,7 +242,7 @@ def chain_secondary(torch, af, dev, pcm, n_clips: int, n_frames_pcm: int, stream
                       "ms": ms, "frames": total, "rtf": n_clips * CLIP_SECONDS / (ms * 1e-3),
                       "algorithmic_bytes": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9,
                       "frac_hbm": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "launches": chain.n_launches() if hasattr(chain, "n_launches") else None}}
+                      "launches": chain.n_launches()}}
 
 
 def main() -> None:

@@ -346,7 +346,11 @@ af_status af_mel_apply(af_mel* m, const float* power, size_t n_frames, float* me
  * interleaved PCM -> to_mono (capture.rs:30-42) -> polyphase resample -> FIR -> STFT -> mel,
  * every stage a kernel of this library enqueued on the caller's stream.  Equal-length clips;
  * intermediates are allocated by set_batch, so run_device only launches (hipGraph-capturable).
- * input_rate == output_rate skips the resampler, n_fir_taps == 0 skips the FIR. */
+ * input_rate == output_rate skips the resampler, n_fir_taps == 0 skips the FIR.
+ * Where af_chain_fused_plan_describe() says so, downmix + resampler + FIR are ONE launch (the
+ * resampled signal before the FIR stays in LDS) and the chain is two launches; the values are
+ * those of the separate launches bit for bit when both use the same MFMA step layout
+ * (FIRs of 34..65 and 98..129 taps), and within the tolerance of docs/OPS.md otherwise. */
 typedef struct af_chain af_chain;
 typedef struct {
     uint32_t input_rate;     /* Hz of the PCM handed in */
@@ -367,6 +371,16 @@ af_status af_chain_set_batch_uniform(af_chain* c, size_t n_clips, size_t frames_
                                      size_t* total_frames_out);
 af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev, void* stream);
 af_status af_chain_run(af_chain* c, const float* pcm, size_t pcm_len, float* mel, size_t mel_cap);
+/* kernels af_chain_run_device enqueues per call for the configuration and batch described (2 when the
+ * fused resampler + FIR launch applies; e.g. 3 for config 4 without it: resampler, FIR, STFT / mel) */
+int       af_chain_n_launches(const af_chain* c);
+/* diagnostics, host only: the shape of the fused resampler + FIR launch for a configuration.
+ * info[10] = {ok, resampler MFMA steps, FIR MFMA steps, resampled samples recomputed per tile,
+ * padding in front of the FIR history, FIR block periods per column and tile, FIR segment
+ * length, FIR segment stride, FIR outputs per tile, LDS bytes}; returns 0 when the chain runs the
+ * resampler and the FIR as separate launches. */
+int       af_chain_fused_plan_describe(uint32_t input_rate, uint32_t output_rate, uint32_t channels,
+                                       size_t n_fir_taps, int32_t* info);
 
 /* ------------------------------------------------------------------ [R]
  * RingBuffer, modules/audio/capture.rs:84-161 (tests :426-561): mutex-guarded f32 ring between

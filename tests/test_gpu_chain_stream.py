@@ -42,6 +42,53 @@ def test_chain_vs_oracle(af, po, ch, fi, fo, with_fir):
         assert frame_rel_err(mel[i * nf:(i + 1) * nf], ref) < 2e-5
 
 
+@pytest.mark.parametrize("ch,fi,fo,K,n_clips,n", [
+    (2, 48000, 16000, 129, 3, 40000),      # config 4's stages
+    (1, 48000, 16000, 129, 2, 123457),     # mono, ragged length
+    (2, 48000, 16000, 129, 1, 11520 * 3 + 5),   # a few samples into the fourth tile
+    (2, 48000, 16000, 129, 300, 50000),    # more tiles than workgroups
+    (1, 32000, 16000, 129, 3, 70001), (2, 48000, 24000, 129, 3, 50000),
+    (2, 48000, 16000, 100, 3, 40000),      # history not a multiple of 16: padded segments
+    (2, 48000, 16000, 66, 2, 40000), (2, 48000, 16000, 65, 2, 40000), (1, 48000, 16000, 33, 2, 40000),
+    (1, 48000, 16000, 1, 2, 40000)])
+def test_chain_fused_stage_equals_separate_launches(af, ch, fi, fo, K, n_clips, n):
+    """The one-launch downmix + resampler + FIR (banded::launch_fused) against the stand-alone kernels
+    (af_debug_set "chain.unfused"): the same block alignment and MFMA step order, so bit for bit whenever the
+    FIR chains have the same step layout (34..65 and 98..129 taps: 16/20 and 32/36 steps differ only in
+    all-zero tail steps); other lengths are judged on the per-frame error."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    lib = af.library()
+    info = (C.c_int32 * 10)()
+    assert lib.af_chain_fused_plan_describe(fi, fo, ch, K, info) == 1
+    dev = torch.device("cuda:0")
+    k = np.arange(K) - (K - 1) / 2
+    taps = (0.9 * np.sinc(0.9 * k) * np.hamming(K)).astype(np.float32)
+    chain = af.ChainPipeline(input_rate=fi, channels=ch, output_rate=fo, fir_taps=taps)
+    total = chain.set_batch_uniform(n_clips, n)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(K + n)
+    pcm = torch.rand(n_clips, n, ch, device=dev, generator=gen) - 0.5
+    stream = torch.cuda.current_stream().cuda_stream
+    out = []
+    try:
+        for unfused in (0, 1):
+            assert lib.af_debug_set(b"chain.unfused", unfused) == 0
+            mel = torch.full((total, 80), float("nan"), device=dev)
+            chain.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+            torch.cuda.synchronize()
+            out.append(mel)
+    finally:
+        lib.af_debug_set(b"chain.unfused", 0)
+    assert bool(torch.isfinite(out[0]).all())
+    assert chain.n_launches() == 2
+    if 34 <= K <= 65 or 98 <= K <= 129 or K == 1:
+        assert torch.equal(out[0], out[1])
+    else:
+        rel = (out[0] - out[1]).norm(dim=1) / out[1].norm(dim=1).clamp_min(1e-30)
+        assert float(rel.max()) < 2e-6
+
+
 def test_chain_config4_per_gpu_share(af, po):
     # BASELINE config 4's share of one GPU: 1024 clips x 30 s stereo 48 kHz (11.8 GB) through the whole
     # chain; every row written, duplicates identical, determinism, sampled clips against the oracle chain

@@ -170,3 +170,44 @@ def test_banded_plan_invariants(af):
             # segments may be shorter than the workgroup (the kernel masks the lanes beyond them)
             short += p["seg_len"] < 64 * p["nwaves"]
     assert short >= 2                                          # the L = 15 ratios exercise that mask
+
+
+def test_chain_fused_plan_invariants(af):
+    """Host-side shape of the chain's fused resampler + FIR launch (banded_mfma.hip make_fused_plan): no GPU."""
+    import ctypes as C
+    lib = af.library()
+    names = ["ok", "NKA", "NKB", "H2", "pad", "P2", "seg_len_b", "seg_stride_b", "z_per_tile", "smem"]
+
+    def plan(fi, fo, ch, K):
+        info = (C.c_int32 * 10)()
+        ok = lib.af_chain_fused_plan_describe(fi, fo, ch, K, info)
+        d = dict(zip(names, list(info)))
+        assert ok == d["ok"]
+        return d
+
+    # BASELINE config 4: stereo 48 kHz -> 16 kHz, 129 taps
+    p = plan(48000, 16000, 2, 129)
+    assert (p["ok"], p["NKA"], p["NKB"], p["H2"], p["pad"], p["P2"], p["z_per_tile"]) == (1, 28, 36, 128, 0, 15, 3840)
+    assert 2 * p["smem"] <= 160 * 1024                        # two workgroups per CU
+    covered = 0
+    for fi, fo in [(48000, 16000), (32000, 16000), (48000, 24000), (16000, 8000), (44100, 22050)]:
+        for ch in (1, 2):
+            for K in (1, 2, 16, 17, 33, 64, 65, 66, 100, 128, 129):
+                p = plan(fi, fo, ch, K)
+                assert p["ok"] == 1, (fi, fo, ch, K)
+                covered += 1
+                assert p["H2"] % 16 == 0 and p["H2"] >= K - 1 and p["pad"] == p["H2"] - (K - 1) and 0 <= p["pad"] < 16
+                assert 4 * p["NKB"] >= K + 15                 # the FIR window of a 16-output block fits the chain
+                assert p["NKB"] == (20 if K <= 65 else 36)
+                assert p["P2"] == 15 and p["z_per_tile"] == 256 * p["P2"]
+                assert p["seg_len_b"] == 16 * p["P2"] + 4 * p["NKB"] and p["seg_stride_b"] % 2 == 1
+                # every window sample phase B reads was produced by phase A of the same tile (4096 samples)
+                assert 15 * 16 * p["P2"] + p["pad"] + p["seg_len_b"] <= 4096
+                # a resampled sample belongs to at most two column segments
+                assert p["seg_len_b"] <= 2 * 16 * p["P2"]
+    assert covered == 110
+    # not covered: long FIRs, ratios with several block matrices or another tile shape, no resampling, no FIR
+    assert plan(48000, 16000, 2, 130)["ok"] == 0 and plan(48000, 16000, 1, 1024)["ok"] == 0
+    assert plan(44100, 16000, 1, 129)["ok"] == 0 and plan(48000, 32000, 2, 129)["ok"] == 0
+    assert plan(16000, 48000, 1, 129)["ok"] == 0
+    assert plan(16000, 16000, 1, 129)["ok"] == 0 and plan(48000, 16000, 2, 0)["ok"] == 0
