@@ -90,6 +90,7 @@ struct FusedPlan {
     int H2 = 0, pad = 0;       // resampled samples recomputed per tile (multiple of 16), H2 - (K - 1)
     int P2 = 0;                // FIR block periods per column and tile
     int seg_len_b = 0, seg_stride_b = 0;
+    int shift = 0, seg_stride_a = 0;   // x segments in LDS (stereo: one frame early when the origin is odd)
     int64_t z_per_tile = 0;    // 256 * P2
     size_t smem = 0;
     size_t afrag_b_floats() const { return (size_t)NKB * 64; }

@@ -126,13 +126,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             pf[cc * kPfSlots + h] = __builtin_bit_cast(
                 float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
         } else {
-            // two dword loads: hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b64 to a single
-            // dword load and duplicates it
+            // one 8-byte load per frame (cast the whole vector: hipcc 7.2 reads element 0 for
+            // __builtin_bit_cast(float, v[i]))
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
             const int off = (int)(voff[h] + (uint32_t)(cc * col_span) * 8u);
-            pf[(cc * kPfSlots + h) * 2] =
-                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
-            pf[(cc * kPfSlots + h) * 2 + 1] =
-                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0));
+            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+            pf[(cc * kPfSlots + h) * 2] = v[0];
+            pf[(cc * kPfSlots + h) * 2 + 1] = v[1];
         }
     };
     constexpr int kLoads = kCols * kPfSlots;
@@ -258,6 +258,7 @@ struct FusedGeom {
     int64_t tiles_per_clip, n_tiles;
     int lo_off;                      // resampler: c - (T - 1)
     int S, G, gpw, seg_len, seg_stride;
+    int shift;                       // CH = 2: frames in front of a segment so that (L, R) pairs load 16-byte aligned
     int H2, pad, P2, seg_len_b, seg_stride_b, ys_off;
     float inv_colz;                  // 1 / (16 P2)
 };
@@ -300,8 +301,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int col = lane & 15, g4 = lane >> 4;
 
     const int wave_off_a = wave * kGpw * g.S;
-    const int base_full_a = col * g.seg_stride + 16 * g4 + wave_off_a;
-    const int base_tail_a = col * g.seg_stride + TAILA * g4 + 64 * FULLA + wave_off_a;
+    const int base_full_a = col * g.seg_stride + 16 * g4 + wave_off_a + g.shift;
+    const int base_tail_a = col * g.seg_stride + TAILA * g4 + 64 * FULLA + wave_off_a + g.shift;
     const int wave_off_b = wave * kGpw * 16;
     const int base_full_b = col * g.seg_stride_b + 16 * g4 + wave_off_b;
     const int base_tail_b = col * g.seg_stride_b + TAILB * g4 + 64 * FULLB + wave_off_b;
@@ -309,8 +310,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int z_lane = 16 * (col * g.P2 + wave * kGpw) + 4 * g4;    // tile-relative FIR output of acc0[0]
     const int colz = 16 * g.P2, z_per_tile = 16 * colz, y_per_tile = 256 * g.G;
     const int col_span = g.G * g.S;
-    const bool first = tid < g.seg_len;
-    const bool second = tid + nthreads < g.seg_len;
+    // CH = 1: a thread stages samples tid and tid + 512 of every column segment, one dword load each.
+    // CH = 2: a thread stages the frame pair (2 tid, 2 tid + 1) of every segment with ONE 16-byte load
+    // (L0 R0 L1 R1); the segment starts `shift` frames early so that a pair never straddles the clip
+    // start (the buffer's range check then zeroes whole dwords only).
+    const bool first = CH == 2 ? 2 * tid < g.seg_len + g.shift : tid < g.seg_len;
+    const bool second = CH == 1 && tid + nthreads < g.seg_len;
     const uint32_t tpc = (uint32_t)g.tiles_per_clip, n_tiles = (uint32_t)g.n_tiles;
 
     // Register plan (128 per lane, 4 waves per SIMD): a phase only holds its own fragments -- they are
@@ -329,35 +334,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
 
     constexpr uint32_t kOob = 0xFFF00000u;
-    float pf[kCols * kPfSlots * CH];
+    constexpr int kLoads = CH == 2 ? kCols : kCols * kPfSlots;       // load instructions per thread and tile
+    constexpr int kLoadsA = CH == 2 ? kCols / 2 : kLoads;            // requested during phase A
+    constexpr int kRegs = CH == 2 ? kCols * 4 : kCols * kPfSlots;
+    float pf[kRegs];
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[kPfSlots];
     auto prep_tile = [&](uint32_t tile, bool live) {
         const uint32_t clip = tile / tpc;
         const int64_t t = tile - clip * tpc;
-        // x index of the first window sample of the tile: q(y0) + lo_off, y0 = t z_per_tile - H2
-        const int64_t base = (t * (int64_t)(16 * g.P2) - g.H2 / 16) * g.S + g.lo_off;
+        // x index of the first staged sample of the tile: q(y0) + lo_off - shift, y0 = t z_per_tile - H2
+        const int64_t base = (t * (int64_t)(16 * g.P2) - g.H2 / 16) * g.S + g.lo_off - g.shift;
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride * CH), 0,
                                                  (int)(uint32_t)(g.x_len * 4 * CH), 0x00020000);
-        const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * (4u * CH);
-        voff[0] = live && first ? v0 : kOob;
-        voff[1] = live && second ? v0 + (uint32_t)nthreads * (4u * CH) : kOob;
-    };
-    auto issue_load = [&](int s) {                                  // s = h * 16 + cc
-        const int cc = s % kCols, h = s / kCols;
-        if constexpr (CH == 1) {
-            pf[cc * kPfSlots + h] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
+        if constexpr (CH == 2) {
+            const uint32_t v0 = ((uint32_t)base + 2u * (uint32_t)(tid + opaque_zero())) * 8u;
+            voff[0] = live && first ? v0 : kOob;
         } else {
-            const int off = (int)(voff[h] + (uint32_t)(cc * col_span) * 8u);
-            pf[(cc * kPfSlots + h) * 2] =
-                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
-            pf[(cc * kPfSlots + h) * 2 + 1] =
-                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0));
+            const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * 4u;
+            voff[0] = live && first ? v0 : kOob;
+            voff[1] = live && second ? v0 + (uint32_t)nthreads * 4u : kOob;
         }
     };
-    constexpr int kLoads = kCols * kPfSlots;
-    constexpr int kLoadsA = CH == 1 ? kLoads : kCols;               // requested during phase A
+    auto issue_load = [&](int s) {
+        if constexpr (CH == 1) {                                    // s = h * 16 + cc
+            const int cc = s % kCols, h = s / kCols;
+            pf[cc * kPfSlots + h] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
+        } else {                                                    // s = cc
+            // (cast the whole vector: hipcc 7.2 reads element 0 for __builtin_bit_cast(float, v[i]))
+            const f32x4 v = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 8u), 0, 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[s * 4 + i] = v[i];
+        }
+    };
 
     uint32_t tile = blockIdx.x;
     if (tile < n_tiles) {
@@ -369,18 +380,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // No barrier here: xs was last read in phase A and ys in phase B of the previous tile; a wave
         // writes xs before, and ys after, the next barrier, which every wave reaches after its phase B.
         {
-            float* dst = xs + tid + opaque_zero();
-            auto staged = [&](int cc, int h) {
-                if constexpr (CH == 1) return pf[cc * kPfSlots + h];
-                else return (pf[(cc * kPfSlots + h) * 2] + pf[(cc * kPfSlots + h) * 2 + 1]) * 0.5f;
-            };
-            if (first) {
+            if constexpr (CH == 2) {
+                float* dst = xs + 2 * (tid + opaque_zero());
+                if (first) {
 #pragma unroll
-                for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = staged(cc, 0);
-            }
-            if (second) {
+                    for (int cc = 0; cc < kCols; ++cc) {            // downmix: (L + R) * 0.5, exact
+                        dst[cc * g.seg_stride] = (pf[cc * 4] + pf[cc * 4 + 1]) * 0.5f;
+                        dst[cc * g.seg_stride + 1] = (pf[cc * 4 + 2] + pf[cc * 4 + 3]) * 0.5f;
+                    }
+                }
+            } else {
+                float* dst = xs + tid + opaque_zero();
+                if (first) {
 #pragma unroll
-                for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = staged(cc, 1);
+                    for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = pf[cc * kPfSlots];
+                }
+                if (second) {
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = pf[cc * kPfSlots + 1];
+                }
             }
         }
         load_a1(opaque_zero());
@@ -690,7 +708,14 @@ FusedPlan make_fused_plan(const Plan& a, int K)
     // every window sample phase B reads is a resampled sample of this tile
     if (15 * 16 * f.P2 + f.pad + f.seg_len_b > 256 * a.G) return f;
     f.z_per_tile = (int64_t)256 * f.P2;
-    f.smem = ((size_t)kCols * (a.seg_stride + f.seg_stride_b) + 64) * sizeof(float);   // + one spare word per lane
+    if (a.ch == 2) {
+        if (a.S % 2) return f;                                 // frame pairs need an even tile origin
+        f.shift = (a.c - (a.T - 1)) & 1;
+        f.seg_stride_a = ((a.seg_len + f.shift + 1) / 2 * 2) | 1;
+    } else {
+        f.seg_stride_a = a.seg_stride;
+    }
+    f.smem = ((size_t)kCols * (f.seg_stride_a + f.seg_stride_b) + 64) * sizeof(float);   // + one spare word per lane
     if (2 * f.smem > 160 * 1024) return f;                     // two workgroups per CU or not at all
     f.ok = true;
     return f;
@@ -731,13 +756,14 @@ af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* af
     g.G = f.a.G;
     g.gpw = f.a.G / f.a.wpp;
     g.seg_len = f.a.seg_len;
-    g.seg_stride = f.a.seg_stride;
+    g.seg_stride = f.seg_stride_a;
+    g.shift = f.shift;
     g.H2 = f.H2;
     g.pad = f.pad;
     g.P2 = f.P2;
     g.seg_len_b = f.seg_len_b;
     g.seg_stride_b = f.seg_stride_b;
-    g.ys_off = kCols * f.a.seg_stride;
+    g.ys_off = kCols * f.seg_stride_a;
     g.inv_colz = 1.0f / (float)(16 * f.P2);
     int64_t grid = g.n_tiles;
     const int64_t cap = 2 * (int64_t)device_cu_count(current_device());
