@@ -127,6 +127,7 @@ extern "C" {
     pub fn af_chain_n_frames(c: *const af_chain, n_pcm_frames: usize) -> usize;
     pub fn af_chain_set_batch_uniform(c: *mut af_chain, n_clips: usize, frames_per_clip: usize, total_frames_out: *mut usize) -> af_status;
     pub fn af_chain_run(c: *mut af_chain, pcm: *const f32, pcm_len: usize, mel: *mut f32, mel_cap: usize) -> af_status;
+    pub fn af_chain_n_launches(c: *const af_chain) -> c_int;
     // RingBuffer, capture.rs:84-161
     pub fn af_ring_create(capacity_samples: usize, out: *mut *mut af_ring) -> af_status;
     pub fn af_ring_destroy(r: *mut af_ring);

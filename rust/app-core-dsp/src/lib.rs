@@ -480,6 +480,8 @@ impl ChainPipeline {
         check(unsafe { ffi::af_chain_run(self.h, pcm.as_ptr(), pcm.len(), mel.as_mut_ptr(), mel.len()) })?;
         Ok(mel)
     }
+    /// kernels one pass enqueues for the batch described last (2 with the fused resampler + FIR stage)
+    pub fn n_launches(&self) -> usize { unsafe { ffi::af_chain_n_launches(self.h) as usize } }
 }
 impl Drop for ChainPipeline { fn drop(&mut self) { unsafe { ffi::af_chain_destroy(self.h) } } }
 
