@@ -2,9 +2,10 @@
 //   to_mono        modules/audio/capture.rs:30-42
 //   PCM16 quantise modules/network/websocket.rs:246-251 (+ :254 base64)
 //   VAD energy     modules/audio/vad.rs:157-168
-// All are pure streaming kernels: 16-byte loads/stores per lane, grid-stride
-// over at most 2048 workgroups, no LDS except the wave reduction of the energy.
+// All are pure streaming kernels: 16-byte loads/stores per lane, a grid that covers the array
+// (the grid-stride loops only run for more than 2^30 workgroups), no LDS except the VAD slice tile.
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "af_common.hpp"
@@ -14,18 +15,21 @@ namespace {
 
 constexpr int kBlock = 256;
 
-inline int grid_for(size_t work_items)
+// One pass of the kernel's (unrolled) loop per thread: a grid that covers the whole array moves
+// 6.4-6.6 TB/s through a 2:1 kernel of to_mono's shape where 2048 persistent workgroups looping over it reach
+// 5.4-5.7 (scripts/ubench/stream_sweep.hip: block size, loads in flight and walk order matter far less).
+inline int grid_for(size_t work_items, int per_thread = 1)
 {
-    size_t g = (work_items + kBlock - 1) / kBlock;
-    if (g > 2048) g = 2048;
+    const size_t per_wg = (size_t)kBlock * per_thread;
+    size_t g = (work_items + per_wg - 1) / per_wg;
+    if (g > (1u << 30)) g = 1u << 30;                    // the kernels loop over what is left
     if (g < 1) g = 1;
     return (int)g;
 }
 
 // ---- to_mono ---------------------------------------------------------------
-// stereo fast path: one float4 (two frames) per lane and load, four loads in flight per lane
-// (a lane that keeps a single 16-byte load in flight leaves HBM a third idle)
-constexpr int kUnroll = 4;
+// stereo fast path: one float4 (two frames) per lane and load, two loads in flight per lane
+constexpr int kUnroll = 2;
 typedef float vf4 __attribute__((ext_vector_type(4)));
 typedef float vf2 __attribute__((ext_vector_type(2)));
 typedef unsigned vu2 __attribute__((ext_vector_type(2)));
@@ -216,7 +220,15 @@ __device__ __forceinline__ void frame_sweep(const float* __restrict__ x, size_t 
     if (vec) {
         const float4* x4 = reinterpret_cast<const float4*>(x);
         const size_t n4 = len / 4;
-        for (size_t i = lane; i < n4; i += 64) {
+        size_t i = lane;
+        for (; i + 192 < n4; i += 256) {                  // four loads in flight, folded in index order
+            const float4 a = x4[i], b = x4[i + 64], c = x4[i + 128], d = x4[i + 192];
+            f(a.x); f(a.y); f(a.z); f(a.w);
+            f(b.x); f(b.y); f(b.z); f(b.w);
+            f(c.x); f(c.y); f(c.z); f(c.w);
+            f(d.x); f(d.y); f(d.z); f(d.w);
+        }
+        for (; i < n4; i += 64) {
             const float4 v = x4[i];
             f(v.x); f(v.y); f(v.z); f(v.w);
         }
@@ -228,42 +240,57 @@ __device__ __forceinline__ void frame_sweep(const float* __restrict__ x, size_t 
 // The reference folds left in f32 (`frame.iter().map(|&x| x * x).sum()`, vad.rs:163-165: no FMA, one
 // rounding per product and per add), so a tree sum differs in the last bits and a frame within
 // rounding of the threshold could flip the VAD state.  Here ONE LANE folds ONE FRAME, in order:
-// bit-identical to the reference.  A workgroup owns 256 consecutive frames and walks them in slices
-// of 32 samples: the slice is loaded coalesced (8 lanes x 16 B per frame run) into an LDS tile with a
-// 33-dword row stride, then every lane reads its own row (conflict-free) and folds it.
+// bit-identical to the reference.  A wave owns 64 consecutive frames and walks them in slices of 32
+// samples: the slice is loaded coalesced (8 lanes x 16 B per frame run) into the wave's own LDS tile
+// with a 33-dword row stride, then every lane reads its own row (conflict-free) and folds it.  The
+// four waves of a workgroup never wait for each other (no s_barrier: a tile has one writer wave).
+// (slices of 16 or 64 samples, or 128 frames per workgroup, measured 10-35 % slower)
 constexpr int kVadFrames = 256, kVadSlice = 32, kVadStride = kVadSlice + 1;
+__device__ __forceinline__ void vad_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(kVadFrames) void vad_energy_kernel(const float* __restrict__ in, size_t n_frames,
                                                                 size_t frame_len, float* __restrict__ energy, int vec)
 {
 #pragma clang fp contract(off)
     __shared__ float tile[kVadFrames * kVadStride];
-    const int tid = threadIdx.x;
-    for (size_t fb = (size_t)blockIdx.x * kVadFrames; fb < n_frames; fb += (size_t)gridDim.x * kVadFrames) {
-        const int nf = (int)(n_frames - fb < (size_t)kVadFrames ? n_frames - fb : (size_t)kVadFrames);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* wt = tile + w * 64 * kVadStride;
+    for (size_t fb = (size_t)blockIdx.x * kVadFrames + 64 * w; fb < n_frames; fb += (size_t)gridDim.x * kVadFrames) {
+        const int nf = (int)(n_frames - fb < (size_t)64 ? n_frames - fb : (size_t)64);   // frames of this wave
         const float* x = in + fb * frame_len;
         float s = 0.0f;
         for (size_t i0 = 0; i0 < frame_len; i0 += kVadSlice) {
             const int tcur = (int)(frame_len - i0 < (size_t)kVadSlice ? frame_len - i0 : (size_t)kVadSlice);
-            __syncthreads();                                         // the previous slice has been folded
+            vad_wave_sync();                                         // the previous slice has been folded
             if (vec && tcur == kVadSlice) {
+                float4 v[kVadSlice / 4];
 #pragma unroll
                 for (int k = 0; k < kVadSlice / 4; ++k) {
-                    const int q = tid + kVadFrames * k, r = q >> 3, part = q & 7;
+                    const int q = lane + 64 * k, r = q / (kVadSlice / 4), part = q % (kVadSlice / 4);
+                    if (r < nf) v[k] = *reinterpret_cast<const float4*>(x + (size_t)r * frame_len + i0 + 4 * part);
+                }
+#pragma unroll
+                for (int k = 0; k < kVadSlice / 4; ++k) {
+                    const int q = lane + 64 * k, r = q / (kVadSlice / 4), part = q % (kVadSlice / 4);
                     if (r < nf) {
-                        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * frame_len + i0 + 4 * part);
-                        float* d = tile + r * kVadStride + 4 * part;
-                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                        float* d = wt + r * kVadStride + 4 * part;
+                        d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
                     }
                 }
             } else {
-                for (int q = tid; q < nf * tcur; q += kVadFrames) {
+                for (int q = lane; q < nf * tcur; q += 64) {
                     const int r = q / tcur, e = q - r * tcur;
-                    tile[r * kVadStride + e] = x[(size_t)r * frame_len + i0 + e];
+                    wt[r * kVadStride + e] = x[(size_t)r * frame_len + i0 + e];
                 }
             }
-            __syncthreads();
-            if (tid < nf) {
-                const float* row = tile + tid * kVadStride;
+            vad_wave_sync();
+            if (lane < nf) {
+                const float* row = wt + lane * kVadStride;
                 if (tcur == kVadSlice) {
 #pragma unroll
                     for (int e = 0; e < kVadSlice; ++e) { const float p = row[e] * row[e]; s = s + p; }
@@ -272,7 +299,7 @@ __global__ __launch_bounds__(kVadFrames) void vad_energy_kernel(const float* __r
                 }
             }
         }
-        if (tid < nf) energy[fb + tid] = frame_len ? s / (float)frame_len : 0.0f;   // vad.rs:158,167
+        if (lane < nf) energy[fb + lane] = frame_len ? s / (float)frame_len : 0.0f;   // vad.rs:158,167
     }
 }
 
@@ -292,11 +319,25 @@ __global__ void level_meter_kernel(const float* __restrict__ in, size_t n_window
             s += v * v;
             m = fmaxf(m, fabsf(v));
         });
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            s += __shfl_xor(s, off, 64);
-            m = fmaxf(m, __shfl_xor(m, off, 64));
-        }
+        // wave reduction on the DPP path (quad swaps, half-row and row mirrors: every lane of a row of 16
+        // ends with the row's result), then the four rows through readlane -- no LDS round trips
+        auto dpp = [](float v, auto ctrl) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
+                                                                        0xF, 0xF, false));
+        };
+        auto step = [&](auto ctrl) {
+            s += dpp(s, ctrl);
+            m = fmaxf(m, dpp(m, ctrl));
+        };
+        step(std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+        step(std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+        step(std::integral_constant<int, 0x141>{});      // row_half_mirror
+        step(std::integral_constant<int, 0x140>{});      // row_mirror
+        auto row = [](float v, int l) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+        };
+        s = (row(s, 0) + row(s, 16)) + (row(s, 32) + row(s, 48));
+        m = fmaxf(fmaxf(row(m, 0), row(m, 16)), fmaxf(row(m, 32), row(m, 48)));
         if (lane == 0) {
             const float r = window_len ? sqrtf(s / (float)window_len) : 0.0f;
             rms[f] = r;
@@ -337,7 +378,7 @@ af_status af_to_mono_device(const float* in_dev, size_t n_samples, uint16_t chan
         reinterpret_cast<uintptr_t>(out_dev) % 8 == 0) {
         const size_t n_pairs = (n_samples / 2) / 2;        // whole frames, two per lane
         if (n_pairs) {
-            hipLaunchKernelGGL(to_mono2_kernel, dim3(grid_for(n_pairs)), dim3(kBlock), 0, s, in_dev,
+            hipLaunchKernelGGL(to_mono2_kernel, dim3(grid_for(n_pairs, kUnroll)), dim3(kBlock), 0, s, in_dev,
                                n_pairs, out_dev);
             done = n_pairs * 2;
         }
@@ -374,7 +415,7 @@ af_status af_quantize_pcm16_device(const float* in_dev, size_t n, int16_t* out_d
     AF_REQUIRE(in_dev && out_dev, "quantize: null buffer");
     const int vec_ok = reinterpret_cast<uintptr_t>(in_dev) % 16 == 0 &&
                        reinterpret_cast<uintptr_t>(out_dev) % 8 == 0;
-    hipLaunchKernelGGL(quantize_kernel, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, as_stream(stream),
+    hipLaunchKernelGGL(quantize_kernel, dim3(grid_for((n + 3) / 4, kUnroll)), dim3(kBlock), 0, as_stream(stream),
                        in_dev, n, out_dev, vec_ok);
     AF_HIP(hipGetLastError());
     return AF_OK;
@@ -431,7 +472,7 @@ af_status af_vad_energy_device(const float* in_dev, size_t n_frames, size_t fram
     if (n_frames == 0) return AF_OK;
     AF_REQUIRE(energy_dev && (in_dev || frame_len == 0), "vad_energy: null buffer");
     size_t g = (n_frames + kVadFrames - 1) / kVadFrames;      // one lane per frame, 256 frames per workgroup
-    if (g > 4096) g = 4096;
+    if (g > (1u << 30)) g = 1u << 30;
     const int vec = frame_len % 4 == 0 && reinterpret_cast<uintptr_t>(in_dev) % 16 == 0;
     hipLaunchKernelGGL(vad_energy_kernel, dim3((int)g), dim3(kVadFrames), 0, as_stream(stream), in_dev,
                        n_frames, frame_len, energy_dev, vec);
@@ -464,7 +505,7 @@ af_status af_level_meter_device(const float* in_dev, size_t n_windows, size_t wi
     if (n_windows == 0) return AF_OK;
     AF_REQUIRE(rms_dev && peak_dev && dbfs_dev && (in_dev || window_len == 0), "level_meter: null buffer");
     size_t g = (n_windows * 64 + kBlock - 1) / kBlock;
-    if (g > 4096) g = 4096;
+    if (g > (1u << 30)) g = 1u << 30;
     const int vec = window_len % 4 == 0 && reinterpret_cast<uintptr_t>(in_dev) % 16 == 0;
     hipLaunchKernelGGL(level_meter_kernel, dim3((int)g), dim3(kBlock), 0, as_stream(stream), in_dev,
                        n_windows, window_len, rms_dev, peak_dev, dbfs_dev, vec);

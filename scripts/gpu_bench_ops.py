@@ -60,7 +60,12 @@ out["pcm16_base64"] = dict(ms=ms, alg_GBps=bb / ms / 1e6, frac_hbm=bb / ms / 1e6
 en = torch.empty(y.numel() // 320, device=dev)
 ms = timeit(lambda: lib.af_vad_energy_device(P(y.data_ptr()), y.numel() // 320, 320, P(en.data_ptr()), None))
 out["vad_energy_320"] = dict(ms=ms, alg_GBps=y.numel() * 4 / ms / 1e6, frac_hbm=y.numel() * 4 / ms / 1e6 / 8000)
-del x, y, z, q, b64, en
+# level meter: 50 ms windows (800 samples at 16 kHz) over the same buffer
+nw = y.numel() // 800
+lv = [torch.empty(nw, device=dev) for _ in range(3)]
+ms = timeit(lambda: lib.af_level_meter_device(P(y.data_ptr()), nw, 800, P(lv[0].data_ptr()), P(lv[1].data_ptr()), P(lv[2].data_ptr()), None))
+out["level_meter_800"] = dict(ms=ms, alg_GBps=nw * 800 * 4 / ms / 1e6, frac_hbm=nw * 800 * 4 / ms / 1e6 / 8000)
+del x, y, z, q, b64, en, lv
 # to_mono on config 2's input
 s = torch.rand(256 * 1440000, 2, device=dev); m = torch.empty(256 * 1440000, device=dev)
 ms = timeit(lambda: lib.af_to_mono_device(P(s.data_ptr()), s.numel(), 2, P(m.data_ptr()), None))
@@ -88,7 +93,8 @@ melc = torch.empty(totc, 80, device=dev)
 ms = timeit(lambda: ch.run_device(s.data_ptr(), melc.data_ptr(), torch.cuda.current_stream().cuda_stream), k=5)
 bb = s.numel() * 4 + melc.numel() * 4
 out["chain_cfg4_256clips"] = dict(ms=ms, alg_GBps=bb / ms / 1e6, frac_hbm=bb / ms / 1e6 / 8000, rtf=256 * 30 / ms * 1e3,
-                                  note="5 kernels, intermediates stay in HBM; algorithmic bytes = PCM in + mel out")
+                                  launches=ch.n_launches(),
+                                  note="algorithmic bytes = PCM in + mel out")
 del melc
 # PCIe-inclusive fused features (host buffers), 64 clips
 k = 64
