@@ -435,4 +435,43 @@ private:
     uint32_t channels_ = 2;
 };
 
+// BASELINE config 4: interleaved PCM -> to_mono -> polyphase resample -> FIR -> STFT -> mel on a batch of
+// equal-length clips (af_chain_*).  Two kernel launches where the fused resampler + FIR stage applies.
+class ChainPipeline {
+public:
+    ChainPipeline(uint32_t input_rate, uint32_t channels, uint32_t output_rate, const std::vector<float>& fir_taps,
+                  uint32_t n_mels = 80)
+    {
+        af_chain_config cfg;
+        af_chain_default_config(&cfg);
+        cfg.input_rate = input_rate;
+        cfg.channels = channels;
+        cfg.output_rate = output_rate;
+        cfg.fir_taps = fir_taps.empty() ? nullptr : fir_taps.data();
+        cfg.n_fir_taps = fir_taps.size();
+        cfg.n_mels = n_mels;
+        n_mels_ = n_mels;
+        detail::check(af_chain_create(&cfg, &h_));
+    }
+    ChainPipeline(const ChainPipeline&) = delete;
+    ChainPipeline& operator=(const ChainPipeline&) = delete;
+    ~ChainPipeline() { af_chain_destroy(h_); }
+
+    size_t n_frames(size_t n_pcm_frames) const { return af_chain_n_frames(h_, n_pcm_frames); }
+    // rows [clip][frame][n_mels], clips back to back
+    std::vector<float> run(const std::vector<float>& pcm, size_t n_clips, size_t frames_per_clip)
+    {
+        size_t total = 0;
+        detail::check(af_chain_set_batch_uniform(h_, n_clips, frames_per_clip, &total));
+        std::vector<float> mel(total * n_mels_);
+        detail::check(af_chain_run(h_, pcm.data(), pcm.size(), mel.data(), mel.size()));
+        return mel;
+    }
+    int n_launches() const { return af_chain_n_launches(h_); }
+
+private:
+    af_chain* h_ = nullptr;
+    uint32_t n_mels_ = 80;
+};
+
 }  // namespace audioflow

@@ -172,6 +172,29 @@ int main()
         auto full = one.process_batch({AudioFrame::new_(x, 48000, 2, 0)});
         CHECK(full.size() == 1 && rows.size() == st.total_rows(n) * 80 && rows == full[0].data);
     }
+    // ChainPipeline (BASELINE config 4's stages): two launches, and the mel rows of a 1 kHz tone peak where
+    // they should after 48 -> 16 kHz and a low-pass FIR
+    {
+        const size_t n = 48000;
+        std::vector<float> x(2 * n), taps(129);
+        for (size_t i = 0; i < n; ++i) x[2 * i] = x[2 * i + 1] = 0.5f * std::sin(2.0f * 3.14159265f * 1000.0f * (float)i / 48000.0f);
+        double sum = 0.0;
+        for (int k = 0; k < 129; ++k) {
+            const double t = (k - 64) * 0.9, sinc = k == 64 ? 1.0 : std::sin(3.14159265358979 * t) / (3.14159265358979 * t);
+            taps[k] = (float)(sinc * (0.54 - 0.46 * std::cos(2.0 * 3.14159265358979 * k / 128.0)));
+            sum += taps[k];
+        }
+        for (auto& t : taps) t = (float)(t / sum);
+        ChainPipeline chain(48000, 2, 16000, taps);
+        auto mel = chain.run(x, 1, n);
+        const size_t nf = chain.n_frames(n);
+        CHECK(nf == 1 + (16000 - 1024) / 256 && mel.size() == nf * 80 && chain.n_launches() == 2);
+        size_t arg = 0;
+        for (size_t m = 1; m < 80; ++m)
+            if (mel[10 * 80 + m] > mel[10 * 80 + arg]) arg = m;
+        // HTK mel of 1 kHz is 1000.0; 82 edges over mel(0..8 kHz) = 2840.0 -> filter centre index ~ 27.5
+        CHECK(arg >= 26 && arg <= 29);
+    }
     std::printf(failures ? "%d check(s) failed\n" : "harness ok\n", failures);
     return failures ? 1 : 0;
 }
