@@ -50,7 +50,11 @@ def test_chain_vs_oracle(af, po, ch, fi, fo, with_fir):
     (1, 32000, 16000, 129, 3, 70001), (2, 48000, 24000, 129, 3, 50000),
     (2, 48000, 16000, 100, 3, 40000),      # history not a multiple of 16: padded segments
     (2, 48000, 16000, 66, 2, 40000), (2, 48000, 16000, 65, 2, 40000), (1, 48000, 16000, 33, 2, 40000),
-    (1, 48000, 16000, 1, 2, 40000)])
+    (1, 48000, 16000, 1, 2, 40000),
+    # tile edges of the fused launch (3840 FIR outputs = 11520 input frames per tile): exact, one over, one under
+    (2, 48000, 16000, 129, 2, 2 * 11520), (2, 48000, 16000, 129, 2, 2 * 11520 + 3), (2, 48000, 16000, 129, 2, 2 * 11520 - 3),
+    (1, 48000, 16000, 129, 3, 3100),       # shorter than the FIR history + one frame
+    (2, 32000, 16000, 129, 2, 2 * 7680 + 2)])
 def test_chain_fused_stage_equals_separate_launches(af, ch, fi, fo, K, n_clips, n):
     """The one-launch downmix + resampler + FIR (banded::launch_fused) against the stand-alone kernels
     (af_debug_set "chain.unfused"): the same block alignment and MFMA step order, so bit for bit whenever the
