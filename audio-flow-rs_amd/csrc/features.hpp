@@ -58,10 +58,10 @@ constexpr int kTile = 15 * kHop + kNfft;  // mono samples of one unit (4864)
 constexpr int kTail = kNfft - kHop;       // samples shared with the next unit (768)
 constexpr int kWb = 1284;                 // per-wave LDS buffer in dwords (== 4 mod 32: the 16 frames x 2
                                           // k-groups of a mel operand read fall into 32 different banks)
-constexpr int kT1Row = 66;                // first transposition: row k1 = 64 columns + 2 (bank-conflict-free
-                                          // column reads by lanes (k1, c): 2 k1 + c)
-constexpr int kWinRow2 = 20;              // window table row (lane n2): 16 values + 4 pad
-constexpr int kTw1Row = 36;               // twiddle table row (lane n2): 16 (cos, sin) + 4 pad
+constexpr int kT1Row = 68;                // first transposition: row k1 = 64 columns + 4: the 16 lanes (k1, c) of a
+                                          // ds_read_b128 phase start 4 k1 banks apart and cover all 64
+constexpr int kWinRow2 = 20;              // window table row (one per lane): 16 values + 4 pad
+constexpr int kTw1Row = 36;               // twiddle table row (one per lane): 16 (cos, sin) + 4 pad
 constexpr int kTw2Row = 36;               // second twiddle table row (c = 0..3): 16 (cos, sin) + 4 pad
 constexpr int kTabFloats = 64 * kWinRow2 + 64 * kTw1Row + 4 * kTw2Row;
 constexpr int kLdsFloats = kW * kWb + kTile + kTabFloats + kW * kMaxSlotsW;

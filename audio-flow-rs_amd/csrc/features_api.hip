@@ -414,23 +414,26 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
             twtab[n2 * kTwRow + 2 * k1] = (float)std::cos(a);
             twtab[n2 * kTwRow + 2 * k1 + 1] = (float)std::sin(a);
         }
-    // hop-256 kernel tables: window [64][kWinRow2] (lane n2, n1 = 0..15: 0.5 hann[64 n1 + n2]),
-    // twiddles [64][kTw1Row] (lane n2: (cos, sin)(2 pi n2 k1 / 1024), k1 = 0..15) and
+    // hop-256 kernel tables: window [64][kWinRow2] (row = lane, its n2; n1 = 0..15: 0.5 hann[64 n1 + n2]),
+    // twiddles [64][kTw1Row] (row = lane: (cos, sin)(2 pi n2 k1 / 1024), k1 = 0..15) and
     // [4][kTw2Row] (c: (cos, sin)(2 pi c b / 64), b = 0..15)
     std::vector<float> tabs2(v2::kTabFloats, 0.0f);
     {
         float* win2 = tabs2.data();
         float* tw1 = win2 + 64 * v2::kWinRow2;
         float* tw2 = tw1 + 64 * v2::kTw1Row;
-        for (int n2 = 0; n2 < 64; ++n2)
+        // rows are indexed by LANE: lane l = 16 c + m runs stage 1 for n2 = c + 4 m (features_v2.hip, T1)
+        for (int l = 0; l < 64; ++l) {
+            const int n2 = (l >> 4) + 4 * (l & 15);
             for (int n1 = 0; n1 < 16; ++n1) {
                 const int i = 64 * n1 + n2;
                 const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)kNfft);
-                win2[n2 * v2::kWinRow2 + n1] = 0.5f * (float)w;
+                win2[l * v2::kWinRow2 + n1] = 0.5f * (float)w;
                 const double a = 2.0 * kPi * (double)(n1 * n2) / (double)kNfft;   // n1 plays k1
-                tw1[n2 * v2::kTw1Row + 2 * n1] = (float)std::cos(a);
-                tw1[n2 * v2::kTw1Row + 2 * n1 + 1] = (float)std::sin(a);
+                tw1[l * v2::kTw1Row + 2 * n1] = (float)std::cos(a);
+                tw1[l * v2::kTw1Row + 2 * n1 + 1] = (float)std::sin(a);
             }
+        }
         for (int c = 0; c < 4; ++c)
             for (int b = 0; b < 16; ++b) {
                 const double a = 2.0 * kPi * (double)(c * b) / 64.0;

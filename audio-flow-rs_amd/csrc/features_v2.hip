@@ -7,8 +7,9 @@
 //     (2w, 2w+1), packed as the real / imaginary part of ONE 1024-point complex FFT.
 //   * the FFT is 16 x 16 x 4 with 16 complex points per lane (32 data VGPRs instead of the 64 of
 //     the 32 x 32 scheme), so the kernel fits 128 VGPRs and two workgroups (16 waves) share a CU:
-//       stage 1   lane n2 = 0..63:  radix-16 over n1  (n = 64 n1 + n2), twiddle W1024^(n2 k1)
-//       T1        through LDS: row k1, column n2;  lane (k1, c) reads columns c + 4m
+//       stage 1   lane 16 c + m takes n2 = c + 4 m:  radix-16 over n1  (n = 64 n1 + n2), twiddle W1024^(n2 k1)
+//       T1        through LDS: row k1, position = writing lane;  lane (k1, c) reads its columns c + 4m as
+//                 positions 16 c .. 16 c + 15 (four ds_read_b128)
 //       stage 2a  radix-16 over m -> b, twiddle W64^(c b)
 //       T2        in registers (v_permlane32_swap / v_permlane16_swap): lane (k1, j) gets b = j + 4b' of its four c lanes
 //       stage 2b  four radix-4 over c -> a;  lane L = k1 + 16 j then holds Z[L + 64 t], t = b' + 4a
@@ -121,13 +122,17 @@ __device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float
                                            const float* __restrict__ tw1, float (&ur)[16], float (&ui)[16])
 {
     const int k1 = lane & 15, hi = lane >> 4;
+    // lane l = 16 c + m runs stage 1 for column n2 = c + 4 m, so that the 16 columns c + 4 m' a lane (k1, c)
+    // reads after the transposition sit next to each other (positions 16 c .. 16 c + 15 of a row: four
+    // ds_read_b128 instead of sixteen ds_read_b32).  The window / twiddle table rows are stored per lane.
+    const int n2 = hi + 4 * k1;
     float re[16], im[16];
 
-    // ---- stage 1: lane n2 = lane; z[64 n1 + n2] = w * (a + i b); frame b = frame a shifted by
+    // ---- stage 1: z[64 n1 + n2] = w * (a + i b); frame b = frame a shifted by
     // kHop samples = 4 registers.  The window multiply is fused into the twiddle-free first DIT
     // stage (element e holds input brev4(e): elements (e, e + 1) are inputs (na, na + 8)).
     {
-        const float* src = tile + (2 * w) * kHop + lane;
+        const float* src = tile + (2 * w) * kHop + n2;
         float s[20];
 #pragma unroll
         for (int j = 0; j < 20; ++j) s[j] = src[64 * j];
@@ -150,7 +155,7 @@ __device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float
     }
     fftr::dit_fft<16, 2>(re, im);                  // Y[k1] at element k1
 
-    // twiddle W1024^(n2 k1): row n2 of the table holds (cos, sin) for k1 = 0..15
+    // twiddle W1024^(n2 k1): this lane's row of the table holds (cos, sin) for k1 = 0..15
     {
         const float4* trow = reinterpret_cast<const float4*>(tw1 + lane * kTw1Row);
 #pragma unroll
@@ -167,18 +172,25 @@ __device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float
         }
     }
 
-    // ---- T1: row k1, column n2; lane (k1, c = hi) reads columns c + 4m into element brev4(m)
+    // ---- T1: row k1, position = writing lane; lane (k1, c = hi) reads positions 16 c + m (= columns
+    // c + 4m) into element brev4(m)
     {
-        const float* rd = wb + k1 * kT1Row + hi;
+        const float4* rd = reinterpret_cast<const float4*>(wb + k1 * kT1Row + 16 * hi);
         addtid_store16<4 * kT1Row, 0>(wv, re);
         lds_order();
 #pragma unroll
-        for (int m = 0; m < 16; ++m) ur[brev4(m)] = rd[4 * m];
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = rd[q];
+            ur[brev4(4 * q)] = v.x; ur[brev4(4 * q + 1)] = v.y; ur[brev4(4 * q + 2)] = v.z; ur[brev4(4 * q + 3)] = v.w;
+        }
         lds_order();
         addtid_store16<4 * kT1Row, 0>(wv, im);
         lds_order();
 #pragma unroll
-        for (int m = 0; m < 16; ++m) ui[brev4(m)] = rd[4 * m];
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = rd[q];
+            ui[brev4(4 * q)] = v.x; ui[brev4(4 * q + 1)] = v.y; ui[brev4(4 * q + 2)] = v.z; ui[brev4(4 * q + 3)] = v.w;
+        }
         lds_order();
     }
 
