@@ -299,7 +299,7 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     // hop-256 kernel: one 32-byte record per 16-frame unit
     p->units_ok = false;
     if (p->plan8.n_waves == v2::kW && aligned && p->total_units > 0 && p->total_units < (1ll << 26)) {
-        std::vector<v2::UnitDesc> units((size_t)p->total_units);
+        std::vector<v2::UnitDesc> units((size_t)p->total_units + 1);   // + one zero record: the kernel reads a unit ahead
         const bool sep = p->cfg.channel_mode == AF_CH_SEPARATE;
         size_t k = 0;
         for (size_t c = 0; c < n; ++c) {

@@ -291,12 +291,12 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
 typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ UnitDesc load_desc(const UnitDesc* units, unsigned u)
 {
-    // through the scalar cache: a vector load would make every unit wait for vmcnt(0), i.e. for
-    // the previous unit's mel stores.  The wait is inside: hipcc does not track loads issued
-    // from inline asm.
-    const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(u) * 32u;
-    u32x8 r;
-    asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(units), "s"(off) : "memory");
+    // Through the scalar cache (a vector load would make every unit wait for vmcnt(0), i.e. for the previous
+    // unit's mel stores), and as a load the compiler tracks: the record is read through a constant-address-space
+    // pointer with a wave-uniform index, which hipcc turns into s_load_dwordx8 and waits for where the fields are
+    // first used -- so the next unit's record can be requested a whole unit ahead.
+    typedef const __attribute__((address_space(4))) u32x8* cptr;
+    const u32x8 r = reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(units))[__builtin_amdgcn_readfirstlane(u)];
     UnitDesc d;
     d.pcm0 = (int64_t)(((unsigned long long)r[1] << 32) | r[0]);
     d.out0 = (int64_t)(((unsigned long long)r[3] << 32) | r[2]);
@@ -367,8 +367,9 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memtime() : 0;
     bool fresh = true;
+    UnitDesc ud_next = load_desc(p.units, u);
     while (u < u_end) {
-        const UnitDesc ud = load_desc(p.units, u);
+        const UnitDesc ud = ud_next;
         AF_STAMP2(0);
         const int sel = SEP ? ud.sel : -1;
         const int64_t n_avail = ud.n_avail;
@@ -387,6 +388,9 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         }
         __syncthreads();                             // B1: tile ready, previous mel phase done
         AF_STAMP2(1);
+        // the next unit's record, a unit ahead (the table ends with one spare record)
+        ud_next = load_desc(p.units, u + 1);
+        __builtin_amdgcn_sched_barrier(0);
 
         const bool has_next = (u + 1 < u_end) && (ud.flags & 1);
         uint4 pf[PFU];
