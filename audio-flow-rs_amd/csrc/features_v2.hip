@@ -112,6 +112,47 @@ __device__ __forceinline__ void addtid_store16(const WaveBuf& b, const float (&v
     addtid_store8<STRIDE, BASE + 8 * STRIDE>(b, v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
 }
 
+// The signal tile is stored with the dword pairs of every odd 32-sample block swapped (index ^ 2).  Stage 1
+// reads it with lane 16 c + m on sample c + 4 m (+ 64 j): within a 32-lane half of a ds_read_b32 the samples
+// n2 and n2 + 32 would share a bank; with the swap the odd block's pairs land on the banks the even block
+// leaves free (brute-forced: one lane per bank).
+__device__ __forceinline__ int tile_swz(int idx) { return idx ^ (((idx >> 5) & 1) << 1); }
+
+// tid through a register the compiler cannot see through (see the prefetch in the unit loop)
+__device__ __forceinline__ int opaque_tid(int tid)
+{
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return tid + z;
+}
+
+// MS consecutive samples (idx a multiple of MS = 2, 4 or 8: they stay inside one 32-sample block)
+template <int MS>
+__device__ __forceinline__ void tile_store(float* tile, int idx, const float (&m)[MS])
+{
+    const bool odd = (idx >> 5) & 1;
+    if constexpr (MS == 2) {
+        float* d = tile + (idx ^ (odd ? 2 : 0));
+        d[0] = m[0];
+        d[1] = m[1];
+    } else {
+        float* d = tile + idx;
+#pragma unroll
+        for (int g = 0; g < MS; g += 4) {
+            d[g] = odd ? m[g + 2] : m[g];
+            d[g + 1] = odd ? m[g + 3] : m[g + 1];
+            d[g + 2] = odd ? m[g] : m[g + 2];
+            d[g + 3] = odd ? m[g + 1] : m[g + 3];
+        }
+    }
+}
+// where those MS samples physically start (for raw copies between blocks of equal parity)
+template <int MS>
+__device__ __forceinline__ int tile_phys(int idx)
+{
+    return MS == 2 ? tile_swz(idx) : idx;
+}
+
 // ---------------------------------------------------------------------------
 // One frame pair: signal tile -> two power rows in this wave's buffer wb.
 //   tile   mono samples of the unit, frame f starts at tile[f * kHop]
@@ -132,7 +173,7 @@ __device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float
     // kHop samples = 4 registers.  The window multiply is fused into the twiddle-free first DIT
     // stage (element e holds input brev4(e): elements (e, e + 1) are inputs (na, na + 8)).
     {
-        const float* src = tile + (2 * w) * kHop + n2;
+        const float* src = tile + (2 * w) * kHop + tile_swz(n2);
         float s[20];
 #pragma unroll
         for (int j = 0; j < 20; ++j) s[j] = src[64 * j];
@@ -172,11 +213,18 @@ __device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float
         }
     }
 
-    // ---- T1: row k1, position = writing lane; lane (k1, c = hi) reads positions 16 c + m (= columns
-    // c + 4m) into element brev4(m)
+    // ---- T1: stage-1 element k1 goes to row rho(k1), position = writing lane; lane (k1, c = hi) reads positions
+    // 16 c + m (= columns c + 4m) of row rho(k1) into element brev4(m).  rho makes the ds_read_b128 conflict-free:
+    // its 16-lane groups are {0-3, 12-15 of c} + {4-11 of c + 1} (and the complement), the row stride is 68
+    // dwords = 17 slots of 16 bytes, so slot = rho(k1) + 4 c (mod 16); rho maps k1 = 4..11 onto
+    // {0, 4, 8, 12, 1, 5, 9, 13}, a set invariant under + 4, and the other k1 onto its complement.
     {
-        const float4* rd = reinterpret_cast<const float4*>(wb + k1 * kT1Row + 16 * hi);
-        addtid_store16<4 * kT1Row, 0>(wv, re);
+        constexpr unsigned long long kRho = 0xfb73d951c840ea62ull;   // rho(k1) = nibble k1
+        const int row = (int)((kRho >> (4 * k1)) & 15);
+        const float4* rd = reinterpret_cast<const float4*>(wb + row * kT1Row + 16 * hi);
+        // row r holds element inv(r): 4, 8, 0, 12, 5, 9, 1, 13, 6, 10, 2, 14, 7, 11, 3, 15
+        addtid_store8<4 * kT1Row, 0>(wv, re[4], re[8], re[0], re[12], re[5], re[9], re[1], re[13]);
+        addtid_store8<4 * kT1Row, 8 * 4 * kT1Row>(wv, re[6], re[10], re[2], re[14], re[7], re[11], re[3], re[15]);
         lds_order();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -184,7 +232,8 @@ __device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float
             ur[brev4(4 * q)] = v.x; ur[brev4(4 * q + 1)] = v.y; ur[brev4(4 * q + 2)] = v.z; ur[brev4(4 * q + 3)] = v.w;
         }
         lds_order();
-        addtid_store16<4 * kT1Row, 0>(wv, im);
+        addtid_store8<4 * kT1Row, 0>(wv, im[4], im[8], im[0], im[12], im[5], im[9], im[1], im[13]);
+        addtid_store8<4 * kT1Row, 8 * 4 * kT1Row>(wv, im[6], im[10], im[2], im[14], im[7], im[11], im[3], im[15]);
         lds_order();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -327,6 +376,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     constexpr int MS = St::MS;                       // mono samples per 16-byte staging unit
     constexpr int PFU = 16 * kHop / MS / kT;         // staging units per thread and unit of work
     static_assert(PFU >= 1 && PFU * MS * kT == 16 * kHop, "prefetch shape");
+    static_assert((16 * kHop) % 64 == 0 && kTail % 64 == 0, "tile moves keep the pair order");
     constexpr int kFreshIters = (kTile / MS + kT - 1) / kT;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -382,7 +432,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                 if (v * MS < kTile) {
                     float m[MS];
                     St::load(p.pcm, ud.pcm0, (int64_t)v * MS, n_avail, true, m, sel);
-                    St::store(tile + v * MS, m);
+                    tile_store<MS>(tile, v * MS, m);
                 }
             }
         }
@@ -395,16 +445,19 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         const bool has_next = (u + 1 < u_end) && (ud.flags & 1);
         uint4 pf[PFU];
         if (has_next) {
+            // (lane offsets from an opaque copy of tid: hoisted out of the unit loop they end up in scratch,
+            // and a scratch reload waits for every outstanding vector memory operation)
+            const int t0 = opaque_tid(tid);
             if (n_avail >= kTile + 16 * kHop) {      // wave-uniform: the new region lies inside the clip
                 const char* src = static_cast<const char*>(p.pcm) +
                                   (ud.pcm0 + kTile) * St::kBytesPerFrame;
 #pragma unroll
                 for (int i = 0; i < PFU; ++i)
-                    pf[i] = *reinterpret_cast<const uint4*>(src + (unsigned)(tid + i * kT) * 16u);
+                    pf[i] = *reinterpret_cast<const uint4*>(src + (unsigned)(t0 + i * kT) * 16u);
             } else {
 #pragma unroll
                 for (int i = 0; i < PFU; ++i)
-                    pf[i] = St::load_raw(p.pcm, ud.pcm0, kTile + (int64_t)(tid + i * kT) * MS, n_avail, true);
+                    pf[i] = St::load_raw(p.pcm, ud.pcm0, kTile + (int64_t)(t0 + i * kT) * MS, n_avail, true);
             }
         }
 
@@ -448,23 +501,26 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             // The next tile is this one shifted by 16 hops: the last kTail samples move to the front,
             // the new samples follow.  A staging unit that lands on part of the old tail is handled by
             // one thread: read the old samples, store the new ones there, store the old ones at the front.
+            const int t0 = opaque_tid(tid);
 #pragma unroll
             for (int i = 0; i < PFU; ++i) {
-                const int v = tid + i * kT;
+                const int v = t0 + i * kT;
                 float m[MS];
                 St::convert(pf[i], m, sel);
-                float* dst = tile + kTail + v * MS;
                 if ((i + 1) * kT * MS > 16 * kHop - kTail) {        // compile time: this round reaches the tail
                     if (v * MS >= 16 * kHop - kTail) {
+                        // (the old samples move down by 16 kHop, an even number of 32-sample blocks: source and
+                        // destination have the same pair order, the move is a raw copy)
+                        float* dst = tile + tile_phys<MS>(kTail + v * MS);
                         float old[MS];
 #pragma unroll
                         for (int e = 0; e < MS; ++e) old[e] = dst[e];
-                        St::store(dst, m);
-                        St::store(tile + v * MS - (16 * kHop - kTail), old);
+                        tile_store<MS>(tile, kTail + v * MS, m);
+                        St::store(dst - 16 * kHop, old);
                         continue;
                     }
                 }
-                St::store(dst, m);
+                tile_store<MS>(tile, kTail + v * MS, m);
             }
         }
 
