@@ -502,9 +502,73 @@ af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate, const flo
     if (n_clips == 0 || n_in == 0) return AF_OK;
     AF_REQUIRE(in && out, "af_resample_batch: null buffer");
     AF_TRY(ensure_device(-1));
-    DevBuf din, dout;
+    // Device staging of this convenience entry point: kept per device (grow-only) between calls -- allocating and
+    // freeing a few hundred MB per call costs more than the kernel.  One caller at a time per process.
+    struct Staging { DevBuf in, out; };
+    static std::mutex mu;
+    static Staging staging[kMaxDevices];
+    std::lock_guard<std::mutex> lock(mu);
+    const int dev_ix = current_device() < kMaxDevices ? current_device() : 0;
+    DevBuf& din = staging[dev_ix].in;
+    DevBuf& dout = staging[dev_ix].out;
     AF_TRY(din.reserve(n_clips * n_in * sizeof(float)));
     AF_TRY(dout.reserve(n_clips * n_out * sizeof(float)));
+    // Page-locked input of some size: chunks of whole clips (about 32 MB each) with the H2D copy of chunk
+    // k + 1, the kernel on chunk k and the D2H copy of chunk k - 1 on three streams -- the output is a third
+    // of the input's size or more, so hiding its way back is worth 20-30 % end to end.  Pageable memory goes
+    // through the runtime's own staging, which is fastest as ONE copy each way.
+    hipPointerAttribute_t pa;
+    const bool pinned = hipPointerGetAttributes(&pa, in) == hipSuccess && pa.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();
+    const size_t clip_bytes = n_in * sizeof(float);
+    size_t per = clip_bytes ? (((size_t)32 << 20) + clip_bytes - 1) / clip_bytes : n_clips;
+    if (per < 1) per = 1;
+    if (pinned && n_clips * clip_bytes >= ((size_t)64 << 20) && per < n_clips) {
+        AF_TRY(af_resample_prepare(input_rate, output_rate));       // tables before the first async launch
+        hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+        std::vector<hipEvent_t> ev;
+        auto cleanup = [&]() {
+            for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+            if (s_in) (void)hipStreamDestroy(s_in);
+            if (s_run) (void)hipStreamDestroy(s_run);
+            if (s_out) (void)hipStreamDestroy(s_out);
+        };
+        af_status st = AF_OK;
+        auto hip_ok = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && st == AF_OK) st = fail(AF_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+            return e == hipSuccess;
+        };
+        bool ok = hip_ok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "hipStreamCreate") &&
+                  hip_ok(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking), "hipStreamCreate") &&
+                  hip_ok(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "hipStreamCreate");
+        for (size_t c0 = 0; ok && c0 < n_clips; c0 += per) {
+            const size_t nc = n_clips - c0 < per ? n_clips - c0 : per;
+            hipEvent_t e_in = nullptr, e_run = nullptr;
+            ok = hip_ok(hipEventCreateWithFlags(&e_in, hipEventDisableTiming), "hipEventCreate");
+            if (ok) ev.push_back(e_in);
+            ok = ok && hip_ok(hipEventCreateWithFlags(&e_run, hipEventDisableTiming), "hipEventCreate");
+            if (ok) ev.push_back(e_run);
+            ok = ok && hip_ok(hipMemcpyAsync(din.as<float>() + c0 * n_in, in + c0 * n_in, nc * clip_bytes,
+                                             hipMemcpyHostToDevice, s_in), "hipMemcpyAsync") &&
+                 hip_ok(hipEventRecord(e_in, s_in), "hipEventRecord") &&
+                 hip_ok(hipStreamWaitEvent(s_run, e_in, 0), "hipStreamWaitEvent");
+            if (ok) {
+                const af_status k = af_resample_batch_device(input_rate, output_rate, din.as<float>() + c0 * n_in, nc,
+                                                             n_in, dout.as<float>() + c0 * n_out, s_run);
+                if (k != AF_OK) { st = k; ok = false; }
+            }
+            ok = ok && hip_ok(hipEventRecord(e_run, s_run), "hipEventRecord") &&
+                 hip_ok(hipStreamWaitEvent(s_out, e_run, 0), "hipStreamWaitEvent") &&
+                 hip_ok(hipMemcpyAsync(out + c0 * n_out, dout.as<float>() + c0 * n_out, nc * n_out * sizeof(float),
+                                       hipMemcpyDeviceToHost, s_out), "hipMemcpyAsync");
+        }
+        // drain everything that was enqueued before the buffers and streams go away, error or not
+        if (s_in) (void)hipStreamSynchronize(s_in);
+        if (s_run) (void)hipStreamSynchronize(s_run);
+        if (s_out) hip_ok(hipStreamSynchronize(s_out), "hipStreamSynchronize");
+        cleanup();
+        return st;
+    }
     AF_HIP(hipMemcpy(din.p, in, n_clips * n_in * sizeof(float), hipMemcpyHostToDevice));
     AF_TRY(af_resample_batch_device(input_rate, output_rate, din.as<float>(), n_clips, n_in,
                                     dout.as<float>(), nullptr));

@@ -150,7 +150,10 @@ af_status af_resampler_flush(af_resampler* r, float* out, size_t out_cap,
 void      af_resampler_reset(af_resampler* r);
 
 /* One-shot batch resample [B] (BASELINE config 3): n_clips mono clips of
- * n_in samples each, contiguous; out gets n_clips * af_resample_out_len(). */
+ * n_in samples each, contiguous; out gets n_clips * af_resample_out_len().
+ * af_resample_batch (host buffers) keeps its device staging per device between calls (grow-only)
+ * and serialises concurrent callers; from page-locked memory it overlaps H2D, kernel and D2H in
+ * chunks of whole clips. */
 size_t    af_resample_out_len(uint32_t input_rate, uint32_t output_rate, size_t n_in);
 af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate,
                             const float* in, size_t n_clips, size_t n_in,

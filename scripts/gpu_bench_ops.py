@@ -114,6 +114,32 @@ try:
     run_pinned()
     t0 = time.perf_counter(); run_pinned(); dt = time.perf_counter() - t0
     out["features_host_buffers_64clips_pinned"] = dict(ms=dt * 1e3, frames_per_s=mel.shape[0] / dt, note="H2D + kernel + D2H, page-locked host memory, chunks on three streams")
+    # resampler and chain through their host-buffer entry points, page-locked memory
+    nr = 64; nri = 1440000; nro = lib.af_resample_out_len(48000, 16000, nri)
+    rin = torch.empty(nr * nri, dtype=torch.float32).pin_memory(); rin.numpy()[:] = host.reshape(-1)[: nr * nri]
+    rout = torch.empty(nr * nro, dtype=torch.float32).pin_memory()
+    def run_res():
+        assert lib.af_resample_batch(48000, 16000, _C.c_void_p(rin.data_ptr()), nr, nri, _C.c_void_p(rout.data_ptr()), rout.numel()) == 0
+    run_res(); t0 = time.perf_counter(); run_res(); dt2 = time.perf_counter() - t0
+    dd = torch.empty(rin.numel(), device=dev); torch.cuda.synchronize()
+    dd.copy_(rin); torch.cuda.synchronize(); t0 = time.perf_counter(); dd.copy_(rin); torch.cuda.synchronize(); h2d_s = time.perf_counter() - t0
+    do = torch.empty(rout.numel(), device=dev); rout.copy_(do); torch.cuda.synchronize()
+    t0 = time.perf_counter(); rout.copy_(do); torch.cuda.synchronize(); d2h_s = time.perf_counter() - t0
+    del do
+    out["resample_host_buffers_64clips_pinned"] = dict(ms=dt2 * 1e3, h2d_alone_ms=h2d_s * 1e3, d2h_alone_ms=d2h_s * 1e3,
+                                                       slower_copy_over_end_to_end=max(h2d_s, d2h_s) / dt2,
+                                                       note="64 x 30 s mono 48 -> 16 kHz: H2D + kernel + D2H in clip chunks on three streams")
+    del dd
+    chp = af.ChainPipeline(input_rate=48000, channels=2, output_rate=16000, fir_taps=taps_h)
+    totp = chp.set_batch_uniform(k, 1440000)
+    melp = torch.empty(totp * 80, dtype=torch.float32).pin_memory()
+    def run_chain():
+        assert lib.af_chain_run(chp._h, _C.c_void_p(hp.data_ptr()), hp.numel(), _C.c_void_p(melp.data_ptr()), melp.numel()) == 0
+    run_chain(); t0 = time.perf_counter(); run_chain(); dt2 = time.perf_counter() - t0
+    dd = torch.empty(hp.numel(), device=dev); dd.copy_(hp); torch.cuda.synchronize(); t0 = time.perf_counter(); dd.copy_(hp); torch.cuda.synchronize(); h2d_s = time.perf_counter() - t0
+    out["chain_host_buffers_64clips_pinned"] = dict(ms=dt2 * 1e3, h2d_alone_ms=h2d_s * 1e3, frac_of_h2d=h2d_s / dt2,
+                                                    note="64 x 30 s stereo through af_chain_run: one copy in, two launches, one copy out (the mel rows are 5 % of the input)")
+    del dd
     # what the copies alone cost on this box: H2D of the same PCM, D2H of the same rows (torch, pinned)
     dbuf = torch.empty(hp.numel(), device=dev); dm = torch.empty(mp.shape, device=dev)
     def h2d(): dbuf.copy_(hp, non_blocking=True); torch.cuda.synchronize()

@@ -282,3 +282,23 @@ def test_fused_stereo_path_is_reported_per_ratio(af):
     lib = af.library()
     assert lib.af_resample_has_stereo_path(44100, 16000) == 0     # 10-wave shape: separate to_mono
     assert lib.af_resample_has_stereo_path(48000, 44100) == 0     # VALU kernel ratio
+
+
+def test_resample_batch_host_path_pipelined_from_pinned_memory(af):
+    """af_resample_batch from page-locked memory cuts the batch into clip chunks (H2D / kernel / D2H on three
+    streams); from pageable memory it is one copy each way.  Same bits either way, tail chunk included."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    lib = af.library()
+    n_clips, n_in = 45, 480000                                     # 86 MB in: 3 chunks of 17 + 11 clips
+    n_out = lib.af_resample_out_len(48000, 16000, n_in)
+    g = torch.Generator()
+    g.manual_seed(5)
+    x = torch.rand(n_clips, n_in, generator=g) - 0.5
+    ref = af.resample_batch(x.numpy(), 48000, 16000)               # pageable: the plain path
+    xp = x.pin_memory()
+    out = torch.empty(n_clips, n_out).pin_memory()
+    st = lib.af_resample_batch(48000, 16000, C.c_void_p(xp.data_ptr()), n_clips, n_in, C.c_void_p(out.data_ptr()),
+                               out.numel())
+    assert st == 0
+    assert np.array_equal(out.numpy(), ref)
