@@ -176,6 +176,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         const int64_t left = g.n_out - mbase;
         const int hi = left < 0 ? 0 : left > out_per_tile ? out_per_tile : (int)left;
 
+        // Two block periods per call (two independent accumulator chains) where the register budget allows it;
+        // the five-waves-per-SIMD shapes (96 VGPRs) run ONE chain at a time: with pairs hipcc spilled staging
+        // registers right behind their buffer_load, i.e. an s_waitcnt vmcnt(0) on an HBM load in every tile.
+        constexpr bool kPair = WPE != 5;
         auto chain_pair = [&](int gi, auto with_loads) {
             constexpr bool LOADS = decltype(with_loads)::value;
             const int off0 = gi * g.S;
@@ -188,12 +192,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             if (g.accumulate) {                                 // wave-uniform: start from the earlier passes' sum
                 if (whole) {
                     acc0 = *reinterpret_cast<const f32x4*>(yc + o0);
-                    acc1 = *reinterpret_cast<const f32x4*>(yc + o1);
+                    if (kPair) acc1 = *reinterpret_cast<const f32x4*>(yc + o1);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (o0 + j >= lo && o0 + j < hi) acc0[j] = yc[o0 + j];
-                        if (o1 + j >= lo && o1 + j < hi) acc1[j] = yc[o1 + j];
+                        if (kPair && o1 + j >= lo && o1 + j < hi) acc1[j] = yc[o1 + j];
                     }
                 }
             }
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             float w0[kAhead + 1], w1[kAhead + 1];            // rotating operand registers
             auto read_b = [&](int t) {
                 w0[t % (kAhead + 1)] = t < 16 * FULL ? b0p[64 * (t / 16) + (t % 16)] : t0p[t - 16 * FULL];
-                w1[t % (kAhead + 1)] = t < 16 * FULL ? b1p[64 * (t / 16) + (t % 16)] : t1p[t - 16 * FULL];
+                if (kPair) w1[t % (kAhead + 1)] = t < 16 * FULL ? b1p[64 * (t / 16) + (t % 16)] : t1p[t - 16 * FULL];
             };
 #pragma unroll
             for (int t = 0; t < kAhead && t < NK; ++t) read_b(t);
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             for (int t = 0; t < NK; ++t) {
                 if (t + kAhead < NK) read_b(t + kAhead);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w0[t % (kAhead + 1)], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w1[t % (kAhead + 1)], acc1, 0, 0, 0);
+                if (kPair) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w1[t % (kAhead + 1)], acc1, 0, 0, 0);
                 if (LOADS) {
                     // all of them in the first half of the chain: the later a load goes out, the
                     // less of the chain is left to cover its latency
@@ -227,17 +231,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             }
             if (whole) {
                 *reinterpret_cast<f32x4*>(yc + o0) = acc0;
-                *reinterpret_cast<f32x4*>(yc + o1) = acc1;
+                if (kPair) *reinterpret_cast<f32x4*>(yc + o1) = acc1;
             } else {                                            // clip edges, unaligned streams
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (o0 + j >= lo && o0 + j < hi) yc[o0 + j] = acc0[j];
-                    if (o1 + j >= lo && o1 + j < hi) yc[o1 + j] = acc1[j];
+                    if (kPair && o1 + j >= lo && o1 + j < hi) yc[o1 + j] = acc1[j];
                 }
             }
         };
         chain_pair(0, std::true_type{});
-        for (int gi = 2; gi < g.gpw; gi += 2) chain_pair(gi, std::false_type{});
+        for (int gi = kPair ? 2 : 1; gi < g.gpw; gi += kPair ? 2 : 1) chain_pair(gi, std::false_type{});
     }
 }
 
