@@ -369,7 +369,11 @@ __device__ __forceinline__ UnitDesc load_desc(const UnitDesc* units, unsigned u)
         }                                                                   \
     } while (0)
 
-template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS>
+// POWER (output = |X|^2 rows instead of mel rows) is a template parameter on purpose: as a runtime switch the
+// fragment loads sat in one `if (!out_power)` and the MFMAs that consume them in another; hipcc's wait-count
+// pass joins the paths, kept the six fragment loads "pending" around the loop, and made the next unit's first
+// LDS reads -- which reuse their registers -- wait for vmcnt(5..0): for the PCM prefetch requested just before.
+template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS, bool POWER>
 __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
 {
     using St = Stage<CH, I16>;
@@ -405,7 +409,6 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
 
     // this wave's share of the mel plan
     const float4* __restrict__ wfrag_w = reinterpret_cast<const float4*>(p.wfrag) + ((size_t)w * kMaxSlotsW) * 64 + lane;
-    const int n_slots_w = p.plan.wave_nslots[w];
     int slot_end_w[NSLOT];
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) slot_end_w[q] = p.plan.slot_end[w][q];
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             AF_STAMP2(2);
             // This wave's filterbank fragments (L2-resident, one float4 per slot), issued where the
             // register pressure has dropped and early enough to be back for the mel phase.
-            if (!p.out_power) {
+            if constexpr (!POWER) {
                 int opaque_zero;                     // pins the loads here (and defeats hoisting)
                 asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
                 const float4* wp = wfrag_w + opaque_zero;
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             }
         }
 
-        if (!p.out_power) {
+        if constexpr (!POWER) {
             // mel: banded W (A, registers) x P^T (B, bins x 16 frames from the power rows) on
             // v_mfma_f32_16x16x4_f32; all B operands first, then the chain; a slot that ends a group
             // sends the 16 frames x <= 16 filters accumulator to HBM (one 16-byte store per lane)
@@ -548,9 +551,13 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             const bool fvalid = (lane & 15) < ud.n_rows;
             const int i0 = 4 * (lane >> 4);
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            // Every compiled-in slot runs, also the ones this wave does not use (zero weights, no flush behind
+            // them): skipped slots left their fragment loads unconsumed, hipcc then made the next unit's first
+            // LDS reads -- which overwrite those registers -- wait for vmcnt(5..0), i.e. for the PCM prefetch
+            // that had just been requested, and the prefetch never overlapped the FFT.
 #pragma unroll
             for (int q = 0; q < NSLOT; ++q) {
-                if (q < n_slots_w) {
+                {
 #pragma unroll
                     for (int st = q * kSlotSteps; st < (q + 1) * kSlotSteps; st += 2) {
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], bop[st], acc0, 0, 0, 0);
@@ -600,10 +607,10 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     }
 }
 
-template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS = false>
-static af_status launch_k(const Params& p, int grid, hipStream_t stream)
+template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS, bool POWER>
+static af_status launch_kp(const Params& p, int grid, hipStream_t stream)
 {
-    auto kern = af_features_v2_kernel<CH, I16, SEP, NSLOT, STAMPS>;
+    auto kern = af_features_v2_kernel<CH, I16, SEP, NSLOT, STAMPS, POWER>;
     constexpr size_t smem = sizeof(float) * kLdsFloats;
     static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
     static bool attr_set[kMaxDevices] = {};
@@ -611,6 +618,14 @@ static af_status launch_k(const Params& p, int grid, hipStream_t stream)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kT), smem, stream, p);
     AF_HIP(hipGetLastError());
     return AF_OK;
+}
+
+template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS = false>
+static af_status launch_k(const Params& p, int grid, hipStream_t stream)
+{
+    // (the power-output rows need no mel slots: one instance per format there)
+    if (p.out_power) return launch_kp<CH, I16, SEP, 6, false, true>(p, grid, stream);
+    return launch_kp<CH, I16, SEP, NSLOT, STAMPS, false>(p, grid, stream);
 }
 
 template <int CH, bool I16>
