@@ -72,7 +72,10 @@ __device__ __forceinline__ int opaque_zero()
 // share a CU (96 VGPRs), 4 otherwise (128).
 // CH = 2: x is interleaved stereo and is downmixed on its way into LDS ((L + R) * 0.5, the
 // to_mono of capture.rs:30-42): the staging registers hold (L, R) pairs.
-template <int NK, int WPE, int CH>
+// ACC = 1: the accumulators start from y (a later pass of a long FIR).  A template parameter on purpose: as a
+// runtime branch its loads made hipcc's wait-count pass put s_waitcnt vmcnt(1) in front of every tile's first
+// MFMA -- a wait for the previous tile's output stores.
+template <int NK, int WPE, int CH, bool ACC = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void banded_kernel(const Geom g)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             const float* t1p = t0p + g.S;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const int o0 = out_lane + gi * out_step, o1 = o0 + out_step;
-            if (g.accumulate) {                                 // wave-uniform: start from the earlier passes' sum
+            if constexpr (ACC) {                                // start from the earlier passes' sum
                 if (whole) {
                     acc0 = *reinterpret_cast<const f32x4*>(yc + o0);
                     if (kPair) acc1 = *reinterpret_cast<const f32x4*>(yc + o1);
@@ -503,6 +506,10 @@ void launch_nk(const Geom& g, bool five, int ch, unsigned grid, unsigned block, 
             hipLaunchKernelGGL((banded_kernel<NK, 5, 1>), dim3(grid), dim3(block), smem, s, g);
             return;
         }
+    }
+    if (g.accumulate) {
+        hipLaunchKernelGGL((banded_kernel<NK, 4, 1, true>), dim3(grid), dim3(block), smem, s, g);
+        return;
     }
     hipLaunchKernelGGL((banded_kernel<NK, 4, 1>), dim3(grid), dim3(block), smem, s, g);
 }
