@@ -506,7 +506,7 @@ af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate, const flo
     // freeing a few hundred MB per call costs more than the kernel.  One caller at a time per process.
     struct Staging { DevBuf in, out; };
     static std::mutex mu;
-    static Staging staging[kMaxDevices];
+    static Staging* const staging = new Staging[kMaxDevices];   // never freed: no hipFree during static destruction
     std::lock_guard<std::mutex> lock(mu);
     const int dev_ix = current_device() < kMaxDevices ? current_device() : 0;
     DevBuf& din = staging[dev_ix].in;
