@@ -9,6 +9,11 @@ One "step" = one pass of that kernel over the whole batch.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): bench.py starts
+its own N ranks -- child processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+started BEFORE this process imports torch or touches a GPU -- passes rank 0's JSON line through and
+exits with the worst child's code.  It refuses (exit 2) when the node has fewer than N GPUs.
+
 N > 1: one process per GPU, every rank owns a contiguous clip range (clips are independent: no
 data-path collective).  --scaling weak (default): 256 clips per GPU; --scaling strong: --total-clips
 (8192 = BASELINE config 4) split over the GPUs.  The barrier, the max-over-ranks time and the unit
@@ -184,7 +189,11 @@ def make_result(m: dict) -> dict:
             "traffic_source": m.get("traffic_source"),
             "kernel": m["kernel"], "kernel_ms": m["kernel_ms"],
             "algorithmic_bytes_per_launch": alg_bytes,
+            # the path is above the ridge (46 flop/B at hop 256): the busy fractions of the other
+            # resources, recorded by separate rocprofv3 --pmc passes (profiles/pmc_resources.json)
+            "other": m.get("other"),
         },
+        "prewarm_s": m.get("prewarm_s"),
         # collectives timed apart from the kernel; "not measured" (null) at N = 1
         "ranks_seen": coll["ranks_seen"],
         "collective_backend": coll["backend"],
@@ -245,14 +254,17 @@ def chain_secondary(torch, af, dev, pcm, n_clips: int, n_frames_pcm: int, stream
                       "launches": chain.n_launches()}}
 
 
-def main() -> None:
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # the chip ramps its clocks over the first ~25 launches after idle (1.6 -> 1.2 ms per step under
-    # rocprofv3, profiles/r02_kernel_trace_ramp.txt): the defaults warm up past that
+    # rocprofv3, profiles/r02_kernel_trace_ramp.txt): the defaults warm up past that, and --prewarm-s
+    # seconds of untimed, uncounted launches in front of the counted warm-up do it for any --warmup
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--prewarm-s", type=float, default=0.3,
+                    help="seconds of launches before the counted warm-up (clock ramp after idle); "
+                         "reported as prewarm_s, never timed")
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (weak scaling)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --clips per GPU (BASELINE config 2 per GPU); strong: --total-clips split "
@@ -261,8 +273,144 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=256)
-    args = ap.parse_args()
+    ap.add_argument("--northstar-clips", type=int, default=1024,
+                    help="size of secondary.northstar_1024 (north_star's own 1024-clip batch at N = 1)")
+    return ap.parse_args(argv)
 
+
+def probe_gpu_count() -> int:
+    """GPUs of this node, counted in a throw-away child so that THIS process never loads the HIP
+    runtime (it is about to start the ranks; a process that has touched the GPU must not)."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def launch_ranks(args, argv) -> int:
+    """`bench.py --gpus N` without a launcher: become N ranks (one process per GPU, SURVEY.md 8(e):
+    every AudioResampler / VoiceActivityDetector owns its state, resampler.rs:12-21, vad.rs:60-70, so
+    the clip ranges are independent).  Children are plain subprocesses of this script; nothing here
+    imports torch or calls HIP.  Returns the exit code: 0 only when every rank returned 0."""
+    import socket
+    import subprocess
+    n = args.gpus
+    rehearse = os.environ.get("AF_BENCH_REHEARSE") == "1"     # every rank on device 0, gloo
+    dryrun = os.environ.get("AF_BENCH_DRYRUN") == "1"         # launcher + collectives only, no GPU
+    if not dryrun:
+        have = probe_gpu_count()
+        need = 1 if rehearse else n
+        if have < need:
+            print(f"bench.py: --gpus {n} needs {need} GPU(s) on this node, found {have}: refusing to print "
+                  f"numbers for fewer ranks than asked for", file=sys.stderr, flush=True)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc, pending = 0, set(range(n))
+    deadline = None
+    while pending:
+        for r in sorted(pending):
+            c = procs[r].poll()
+            if c is not None:
+                pending.discard(r)
+                if c != 0:
+                    print(f"bench.py: rank {r} exited with {c}", file=sys.stderr, flush=True)
+                    rc = rc or (c if c > 0 else 1)
+                    if deadline is None:
+                        deadline = time.time() + 30.0    # the others sit in a collective: do not wait for ever
+        if pending and deadline is not None and time.time() > deadline:
+            for r in pending:
+                procs[r].kill()                          # our own children, by PID
+        time.sleep(0.05)
+    return rc
+
+
+def northstar_secondary(torch, af, dev, n_clips: int, n_frames_pcm: int, stream, device_index: int) -> dict:
+    """north_star's own batch ("1024-clip 48 kHz batch at 1 GPU"): the headline kernel on 1024 x 30 s
+    stereo clips (11.8 GB of PCM resident in HBM), HIP events on the launch stream, three sampled clips
+    against the float64 oracle.  Reported beside the headline, never as `value`."""
+    pcm = synth_batch(torch, dev, 0, n_clips, n_frames_pcm)
+    pipe = af.FeaturePipeline(sample_rate=SR, channels=CHANNELS, n_fft=N_FFT, hop=HOP, n_mels=N_MELS,
+                              device=device_index)
+    total = pipe.set_batch_uniform(n_clips, n_frames_pcm)
+    mel = torch.empty(total, N_MELS, device=dev, dtype=torch.float32)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:
+        pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg = n_clips * n_frames_pcm * CHANNELS * 4 + total * N_MELS * 4
+    chk = oracle_check(pcm, mel, n_frames_pcm, pipe.n_frames(n_frames_pcm), n_clips)
+    return {"northstar_1024": {"workload": f"{n_clips} x {CLIP_SECONDS} s stereo {SR} Hz f32 -> STFT {N_FFT}/{HOP} -> {N_MELS} mel, 1 GPU",
+                               "ms": ms, "frames": total, "frames_per_s": total / (ms * 1e-3),
+                               "rtf": n_clips * CLIP_SECONDS / (ms * 1e-3),
+                               "frac_hbm": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "max_rel_err": chk["max_rel_err"], "checked_clips": chk["clips"], "ok": chk["ok"]}}
+
+
+def main() -> None:
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL)
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if os.environ.get("AF_BENCH_DRYRUN") == "1":
+        return dry_rank(args)
+    run_rank(args)
+
+
+def dry_rank(args) -> None:
+    """AF_BENCH_DRYRUN=1 (tests/test_bench_schema.py, no GPU): one rank of the launcher's job on the
+    CPU over gloo -- rendezvous, the barrier / max / sum collectives, the separately timed gather and
+    scatter, the rank-count check and the JSON line, with NO kernel and made-up times.  The line says
+    so ("dryrun": true, "data": "none"); it exists so that the N > 1 launcher is covered where no GPU is."""
+    import torch
+    import torch.distributed as dist
+    from audio_flow_rs_amd.shard import max_over_ranks, sum_over_ranks
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cpu")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    mel, pcm = torch.full((64, N_MELS), float(rank)), torch.full((2, 4096, CHANNELS), float(rank))
+    coll = time_collectives(torch, dist, dev, mel, pcm, world, rank)
+    m = {"steps": args.steps, "warmup": args.warmup, "world": world, "scaling": args.scaling,
+         "wall_s": max_over_ranks(1e-3 * args.steps, dev), "kernel_ms": max_over_ranks(1.0, dev),
+         "frames_all": sum_over_ranks(64.0, dev), "audio_seconds_all": sum_over_ranks(1.0, dev),
+         "clips_local": 2, "clips_total": 2 * world, "frames_local": 64, "pcm_frames_per_clip": 4096,
+         "kernel": "none (dry run)", "prewarm_s": 0.0, "collectives": coll}
+    ok = coll["ranks_seen"] == world
+    if rank == 0:
+        res = make_result(m)
+        res["dryrun"], res["data"] = True, "none (AF_BENCH_DRYRUN: launcher and collectives only, no kernel ran)"
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"communicator holds {coll['ranks_seen']} ranks, --gpus {world}")
+
+
+def run_rank(args) -> None:
     import torch
     import torch.distributed as dist
 
@@ -272,14 +420,17 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report {world} rank(s) as {args.gpus}")
     # AF_BENCH_REHEARSE=1: rehearse the N > 1 control flow on a one-GPU box (every rank on
     # device 0, gloo instead of RCCL); the numbers of such a run mean nothing
     rehearse = os.environ.get("AF_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: device {local_rank} does not exist ({torch.cuda.device_count()} GPU(s) on "
+                         f"this node, --gpus {args.gpus})")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -306,6 +457,14 @@ def main() -> None:
     def step():
         pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
 
+    # Untimed, uncounted pre-warm: the chip needs ~25 launches after idle to reach its steady clock
+    # (profiles/r02_kernel_trace_ramp.txt); a driver's small --warmup must not land the timed region on it.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_s:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+    prewarm_s = time.perf_counter() - t_pre if args.prewarm_s > 0 else 0.0
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -334,6 +493,7 @@ def main() -> None:
         "clips_local": n_clips, "clips_total": clips_total, "frames_local": total_frames,
         "pcm_frames_per_clip": n_frames_pcm,
         "kernel": af.library().af_features_kernel_name().decode(),
+        "prewarm_s": prewarm_s,
     }
     # HBM bytes by PMC come from a separate rocprofv3 run (profiles/): quoted only for the
     # configuration that run profiled, and labelled as recorded
@@ -349,10 +509,21 @@ def main() -> None:
 
     # ---- outside the timed region ----------------------------------------------------------
     m["collectives"] = time_collectives(torch, dist, dev, mel, pcm, world, rank)
+    if m["collectives"]["ranks_seen"] != args.gpus:
+        raise SystemExit(f"communicator holds {m['collectives']['ranks_seen']} ranks, --gpus {args.gpus}")
+    rp = os.path.join(ROOT, "profiles", "pmc_resources.json")
+    if os.path.exists(rp) and n_clips == CLIPS_PER_GPU:
+        try:
+            m["other"] = json.load(open(rp))
+        except Exception:
+            pass
     if rank == 0:
         m["check"] = oracle_check(pcm, mel, n_frames_pcm, pipe.n_frames(n_frames_pcm), n_clips)
     if rank == 0 and world == 1 and not args.no_secondary:
         m["secondary"] = chain_secondary(torch, af, dev, pcm, n_clips, n_frames_pcm, stream)
+        if args.northstar_clips > 0:
+            m["secondary"].update(northstar_secondary(torch, af, dev, args.northstar_clips, n_frames_pcm,
+                                                      stream, local_rank))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         k = max(1, min(args.cpu_clips, n_clips))
         m["cpu_baseline"] = cpu_baseline(pcm[:k].cpu().numpy(), k, n_frames_pcm)

@@ -86,3 +86,42 @@ def test_collectives_control_flow_world2_gloo():
     assert c["ranks_seen"] == 2 and c["backend"] == "gloo"
     assert c["gather_ms"] > 0 and c["scatter_ms"] > 0
     assert c["gather_bytes_per_rank"] == 2 * 50 * 80 * 4 and c["scatter_bytes_per_rank"] == 4 * 1000 * 2 * 4
+
+
+def _run_bench(args, extra_env, timeout=300):
+    import subprocess
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_launcher_spawns_its_own_ranks_dryrun():
+    """`bench.py --gpus 2` with no launcher around it starts 2 ranks itself (AF_BENCH_DRYRUN: gloo on
+    the CPU, no kernel) and rank 0 prints ONE line that says n_gpus 2 / ranks_seen 2."""
+    p = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"AF_BENCH_DRYRUN": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["dryrun"] is True
+    assert r["collective_backend"] == "gloo" and r["gather_ms"] > 0 and r["scatter_ms"] > 0
+    assert r["steps"] == 3 and r["warmup"] == 1
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 8, reason="needs a node with < 8 GPUs")
+def test_launcher_refuses_more_ranks_than_gpus():
+    """--gpus 8 on a node with fewer GPUs: non-zero exit and a message, never an N = 1 line."""
+    p = _run_bench(["--gpus", "8"], {})
+    assert p.returncode != 0
+    assert "refusing" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_rank_refuses_world_size_mismatch():
+    """A launcher that set WORLD_SIZE=1 around `--gpus 2` gets an error, not a mislabelled line."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", AF_BENCH_DRYRUN="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
