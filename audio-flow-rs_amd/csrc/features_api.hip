@@ -415,8 +415,8 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
             twtab[n2 * kTwRow + 2 * k1 + 1] = (float)std::sin(a);
         }
     // hop-256 kernel tables: window [64][kWinRow2] (row = lane, its n2; n1 = 0..15: 0.5 hann[64 n1 + n2]),
-    // twiddles [64][kTw1Row] (row = lane: (cos, sin)(2 pi n2 k1 / 1024), k1 = 0..15) and
-    // [4][kTw2Row] (c: (cos, sin)(2 pi c b / 64), b = 0..15)
+    // twiddles [64][kTw1Row] (row = lane: (cos, sin)(2 pi n2 k1 / 1024), k1 = 1..15) and
+    // [4][kTw2Row] (c: (cos, sin)(2 pi c b / 64), b = 1..15)
     std::vector<float> tabs2(v2::kTabFloats, 0.0f);
     {
         float* win2 = tabs2.data();
@@ -429,16 +429,17 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
                 const int i = 64 * n1 + n2;
                 const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)kNfft);
                 win2[l * v2::kWinRow2 + n1] = 0.5f * (float)w;
-                const double a = 2.0 * kPi * (double)(n1 * n2) / (double)kNfft;   // n1 plays k1
-                tw1[l * v2::kTw1Row + 2 * n1] = (float)std::cos(a);
-                tw1[l * v2::kTw1Row + 2 * n1 + 1] = (float)std::sin(a);
+                if (n1 == 0) continue;                                           // n1 plays k1; rows start at k1 = 1
+                const double a = 2.0 * kPi * (double)(n1 * n2) / (double)kNfft;
+                tw1[l * v2::kTw1Row + 2 * (n1 - 1)] = (float)std::cos(a);
+                tw1[l * v2::kTw1Row + 2 * (n1 - 1) + 1] = (float)std::sin(a);
             }
         }
         for (int c = 0; c < 4; ++c)
-            for (int b = 0; b < 16; ++b) {
+            for (int b = 1; b < 16; ++b) {
                 const double a = 2.0 * kPi * (double)(c * b) / 64.0;
-                tw2[c * v2::kTw2Row + 2 * b] = (float)std::cos(a);
-                tw2[c * v2::kTw2Row + 2 * b + 1] = (float)std::sin(a);
+                tw2[c * v2::kTw2Row + 2 * (b - 1)] = (float)std::cos(a);
+                tw2[c * v2::kTw2Row + 2 * (b - 1) + 1] = (float)std::sin(a);
             }
     }
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };

@@ -26,9 +26,19 @@
 #include "features_dev.hpp"
 #include "fft_regs.hpp"
 
+// AF_ABL (diagnostic builds only, scripts/ablate/): bit mask of LDS access groups compiled OUT of the kernel, to
+// attribute SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT to them.  Every guard that bounds a global access stays in.
+//   1 tile reads (stage 1)   2 window rows   4 first twiddle rows   8 T1 stores   16 T1 reads   32 second twiddle rows
+//   64 exchange stores   128 exchange reads   256 power-row stores   512 mel operand reads   1024 tile update
+#ifndef AF_ABL
+#define AF_ABL 0
+#endif
+
 namespace af {
 namespace feat {
 namespace v2 {
+
+__device__ __forceinline__ float abl_val(int lane, int i) { return (float)(lane + i) * 0.001f; }
 
 __device__ __forceinline__ constexpr int brev4(int x)
 {
@@ -176,12 +186,12 @@ __device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float
         const float* src = tile + (2 * w) * kHop + tile_swz(n2);
         float s[20];
 #pragma unroll
-        for (int j = 0; j < 20; ++j) s[j] = src[64 * j];
+        for (int j = 0; j < 20; ++j) s[j] = (AF_ABL & 1) ? abl_val(lane, j) : src[64 * j];
         float win[16];
         const float4* wrow = reinterpret_cast<const float4*>(wtab + lane * kWinRow2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float4 v = wrow[j];
+            const float4 v = (AF_ABL & 2) ? float4{abl_val(lane, j), 0.5f, 0.25f, 0.125f} : wrow[j];
             win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
         }
 #pragma unroll
@@ -196,20 +206,26 @@ __device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float
     }
     fftr::dit_fft<16, 2>(re, im);                  // Y[k1] at element k1
 
-    // twiddle W1024^(n2 k1): this lane's row of the table holds (cos, sin) for k1 = 0..15
+    // twiddle W1024^(n2 k1): this lane's row of the table holds (cos, sin) for k1 = 1..15 (k1 = 0 needs none), so
+    // that every 16-byte piece is used whole: with k1 = 0 in the row hipcc dropped the unused first pair, re-cut the
+    // rest into 8-byte-aligned ds_read2_b64 (8 LDS cycles each, banked modulo 32: lanes l and l + 8 of a row stride
+    // of 36 dwords collide) and the eight reads cost 116 LDS cycles per frame pair instead of 32
+    // (scripts/ablate/lds_groups.sh: all of SQ_LDS_BANK_CONFLICT came from here).
     {
         const float4* trow = reinterpret_cast<const float4*>(tw1 + lane * kTw1Row);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-            const float4 t = trow[jj];
-            if (jj > 0) {
-                const float xr = re[2 * jj], xi = im[2 * jj];
-                re[2 * jj] = __builtin_fmaf(xr, t.x, xi * t.y);
-                im[2 * jj] = __builtin_fmaf(xi, t.x, -(xr * t.y));
+            const float4 t = (AF_ABL & 4) ? float4{abl_val(lane, jj), 0.5f, 0.25f, 0.125f} : trow[jj];
+            {
+                const float xr = re[2 * jj + 1], xi = im[2 * jj + 1];
+                re[2 * jj + 1] = __builtin_fmaf(xr, t.x, xi * t.y);
+                im[2 * jj + 1] = __builtin_fmaf(xi, t.x, -(xr * t.y));
             }
-            const float xr = re[2 * jj + 1], xi = im[2 * jj + 1];
-            re[2 * jj + 1] = __builtin_fmaf(xr, t.z, xi * t.w);
-            im[2 * jj + 1] = __builtin_fmaf(xi, t.z, -(xr * t.w));
+            if (jj < 7) {
+                const float xr = re[2 * jj + 2], xi = im[2 * jj + 2];
+                re[2 * jj + 2] = __builtin_fmaf(xr, t.z, xi * t.w);
+                im[2 * jj + 2] = __builtin_fmaf(xi, t.z, -(xr * t.w));
+            }
         }
     }
 
@@ -223,21 +239,25 @@ __device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float
         const int row = (int)((kRho >> (4 * k1)) & 15);
         const float4* rd = reinterpret_cast<const float4*>(wb + row * kT1Row + 16 * hi);
         // row r holds element inv(r): 4, 8, 0, 12, 5, 9, 1, 13, 6, 10, 2, 14, 7, 11, 3, 15
+        if constexpr (!(AF_ABL & 8)) {
         addtid_store8<4 * kT1Row, 0>(wv, re[4], re[8], re[0], re[12], re[5], re[9], re[1], re[13]);
         addtid_store8<4 * kT1Row, 8 * 4 * kT1Row>(wv, re[6], re[10], re[2], re[14], re[7], re[11], re[3], re[15]);
+        }
         lds_order();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = rd[q];
+            const float4 v = (AF_ABL & 16) ? float4{re[4 * q], re[4 * q + 1], re[4 * q + 2], re[4 * q + 3]} : rd[q];
             ur[brev4(4 * q)] = v.x; ur[brev4(4 * q + 1)] = v.y; ur[brev4(4 * q + 2)] = v.z; ur[brev4(4 * q + 3)] = v.w;
         }
         lds_order();
+        if constexpr (!(AF_ABL & 8)) {
         addtid_store8<4 * kT1Row, 0>(wv, im[4], im[8], im[0], im[12], im[5], im[9], im[1], im[13]);
         addtid_store8<4 * kT1Row, 8 * 4 * kT1Row>(wv, im[6], im[10], im[2], im[14], im[7], im[11], im[3], im[15]);
+        }
         lds_order();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = rd[q];
+            const float4 v = (AF_ABL & 16) ? float4{im[4 * q], im[4 * q + 1], im[4 * q + 2], im[4 * q + 3]} : rd[q];
             ui[brev4(4 * q)] = v.x; ui[brev4(4 * q + 1)] = v.y; ui[brev4(4 * q + 2)] = v.z; ui[brev4(4 * q + 3)] = v.w;
         }
         lds_order();
@@ -253,18 +273,20 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
     // ---- stage 2a: radix-16 over m -> b, twiddle W64^(c b)
     fftr::dit_fft<16>(ur, ui);
     {
-        const float4* trow = reinterpret_cast<const float4*>(tw2 + hi * kTw2Row);
+        const float4* trow = reinterpret_cast<const float4*>(tw2 + hi * kTw2Row);   // b = 1..15, as in part 1
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-            const float4 t = trow[jj];
-            if (jj > 0) {
-                const float xr = ur[2 * jj], xi = ui[2 * jj];
-                ur[2 * jj] = __builtin_fmaf(xr, t.x, xi * t.y);
-                ui[2 * jj] = __builtin_fmaf(xi, t.x, -(xr * t.y));
+            const float4 t = (AF_ABL & 32) ? float4{abl_val(lane, jj), 0.5f, 0.25f, 0.125f} : trow[jj];
+            {
+                const float xr = ur[2 * jj + 1], xi = ui[2 * jj + 1];
+                ur[2 * jj + 1] = __builtin_fmaf(xr, t.x, xi * t.y);
+                ui[2 * jj + 1] = __builtin_fmaf(xi, t.x, -(xr * t.y));
             }
-            const float xr = ur[2 * jj + 1], xi = ui[2 * jj + 1];
-            ur[2 * jj + 1] = __builtin_fmaf(xr, t.z, xi * t.w);
-            ui[2 * jj + 1] = __builtin_fmaf(xi, t.z, -(xr * t.w));
+            if (jj < 7) {
+                const float xr = ur[2 * jj + 2], xi = ui[2 * jj + 2];
+                ur[2 * jj + 2] = __builtin_fmaf(xr, t.z, xi * t.w);
+                ui[2 * jj + 2] = __builtin_fmaf(xi, t.z, -(xr * t.w));
+            }
         }
     }
 
@@ -305,10 +327,12 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
     // Published: registers 8..15 as planes 0..7, register 0 as plane 8 (lane 0's "register 16");
     // real parts at plane * 64, imaginary parts 576 dwords further.
     {
+        if constexpr (!(AF_ABL & 64)) {
         addtid_store8<256, 0>(wv, ZR(8), ZR(9), ZR(10), ZR(11), ZR(12), ZR(13), ZR(14), ZR(15));
         addtid_store1<8 * 256>(wv, ZR(0));
         addtid_store8<256, 576 * 4>(wv, ZI(8), ZI(9), ZI(10), ZI(11), ZI(12), ZI(13), ZI(14), ZI(15));
         addtid_store1<576 * 4 + 8 * 256>(wv, ZI(0));
+        }
         lds_order();
         const int pl = (64 - lane) & 63;
         const int d = lane == 0 ? 1 : 0;
@@ -317,8 +341,8 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // t = 8 only matters for lane 0 (bin 512, its own register 8 = plane 0)
-            const float pr = t < 8 ? ex[(7 - t) * 64] : wb[pl];
-            const float pi = t < 8 ? ex[576 + (7 - t) * 64] : wb[576 + pl];
+            const float pr = (AF_ABL & 128) ? ZR(15 - t) : t < 8 ? ex[(7 - t) * 64] : wb[pl];
+            const float pi = (AF_ABL & 128) ? ZI(15 - t) : t < 8 ? ex[576 + (7 - t) * 64] : wb[576 + pl];
             const float a1 = ZR(t) + pr, a2 = ZI(t) - pi;
             const float b1 = ZI(t) + pi, b2 = ZR(t) - pr;
             pa[t] = __builtin_fmaf(a1, a1, a2 * a2);
@@ -326,11 +350,18 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
         }
         lds_order();
         // power rows [frame][514] (they alias the exchange planes: every lane has read its partners)
+        if constexpr (!(AF_ABL & 256)) {
         addtid_store8<256, 0>(wv, pa[0], pa[1], pa[2], pa[3], pa[4], pa[5], pa[6], pa[7]);
         addtid_store8<256, 4 * kProw>(wv, pb[0], pb[1], pb[2], pb[3], pb[4], pb[5], pb[6], pb[7]);
         if (lane == 0) {
             wb[512] = pa[8];
             wb[kProw + 512] = pb[8];
+        }
+        } else {
+            float sink = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) sink += pa[t] + pb[t];
+            if (sink == 1.2345e-30f) wb[lane] = sink;      // keeps the arithmetic alive, never taken in practice
         }
     }
 #undef ZR
@@ -500,7 +531,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         __builtin_amdgcn_s_setprio(2);
         AF_STAMP2(4);
 
-        if (has_next) {
+        if (has_next && !(AF_ABL & 1024)) {
             // The next tile is this one shifted by 16 hops: the last kTail samples move to the front,
             // the new samples follow.  A staging unit that lands on part of the old tail is handled by
             // one thread: read the old samples, store the new ones there, store the old ones at the front.
@@ -538,7 +569,8 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                 for (int q = 0; q < NSLOT; ++q) {
                     const float* bq = pbase + lm[q];
 #pragma unroll
-                    for (int i = 0; i < kSlotSteps; ++i) bop[q * kSlotSteps + i] = bq[4 * i];
+                    for (int i = 0; i < kSlotSteps; ++i)
+                        bop[q * kSlotSteps + i] = (AF_ABL & 512) ? abl_val(lane, i + 4 * q) : bq[4 * i];
                 }
             }
             if constexpr (STAMPS) {                                  // diagnostics: operands and fragments landed

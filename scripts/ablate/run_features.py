@@ -1,0 +1,36 @@
+"""Ablation runner: python3 scripts/ablate/run_features.py [--reps R] [--warm W] [--clips N] LIB [LIB ...]
+Runs BASELINE config 2's fused feature launch through each given build of the library (build/ablate/libaf_*.so,
+scripts/ablate/build.sh), in the order given, in ONE process: W untimed + R timed launches each, HIP events.
+Under `rocprofv3 --pmc ...` use --warm 0 --reps 3: the dispatches of the feature kernel then appear in this order,
+R per library (scripts/ablate/pmc_table.py splits them).  Exits non-zero if the runtime reported a fault."""
+import argparse, ctypes as C, importlib.util, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+spec = importlib.util.spec_from_file_location("ffi", os.path.join(ROOT, "audio-flow-rs_amd", "_ffi.py"))
+ffi = importlib.util.module_from_spec(spec); spec.loader.exec_module(ffi)
+ap = argparse.ArgumentParser()
+ap.add_argument("--reps", type=int, default=20); ap.add_argument("--warm", type=int, default=30)
+ap.add_argument("--clips", type=int, default=256); ap.add_argument("libs", nargs="+")
+a = ap.parse_args()
+n = 1440000
+dev = torch.device("cuda:0")
+pcm = (torch.rand(a.clips, n, 2, device=dev) * 2 - 1) * 0.3
+s = torch.cuda.current_stream().cuda_stream
+for path in a.libs:
+    # RTLD_LOCAL: every build resolves its own symbols (RTLD_GLOBAL would bind later builds to the first one's)
+    lib = C.CDLL(os.path.abspath(path), mode=os.RTLD_LOCAL | os.RTLD_NOW)
+    for name in ("af_features_default_config", "af_features_create", "af_features_set_batch_uniform",
+                 "af_features_run_device", "af_features_destroy", "af_last_error"):
+        fn = getattr(lib, name); fn.restype, fn.argtypes = ffi.SIGNATURES[name]
+    cfg = ffi.FeaturesConfig(); lib.af_features_default_config(C.byref(cfg))
+    h = C.c_void_p(); assert lib.af_features_create(C.byref(cfg), C.byref(h)) == 0
+    tot = C.c_size_t(); assert lib.af_features_set_batch_uniform(h, a.clips, n, C.byref(tot)) == 0
+    mel = torch.empty(tot.value, 80, device=dev)
+    for _ in range(a.warm): assert lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), s) == 0
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps): assert lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), s) == 0
+    e1.record(); torch.cuda.synchronize()
+    print(f"{os.path.basename(path):28s} {e0.elapsed_time(e1) / a.reps:8.4f} ms", flush=True)
+    lib.af_features_destroy(h)
