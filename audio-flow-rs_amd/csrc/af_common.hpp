@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -43,14 +44,17 @@ int debug_knob(DebugKnob k);
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: `done` is the
 // caller's static per-kernel flag array, indexed by device ordinal.
 constexpr int kMaxDevices = 64;
+// (atomic flags: handles on different host threads launch the same kernel concurrently; setting the attribute
+// twice is harmless, a torn flag is not something to reason about)
+typedef std::atomic<bool> LdsAttrFlags[kMaxDevices];
 template <class K>
-inline hipError_t allow_big_lds(K kern, int bytes, bool (&done)[kMaxDevices])
+inline hipError_t allow_big_lds(K kern, int bytes, LdsAttrFlags& done)
 {
     const int dev = current_device();
-    if (dev < kMaxDevices && done[dev]) return hipSuccess;
+    if (dev < kMaxDevices && done[dev].load(std::memory_order_acquire)) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess && dev < kMaxDevices) done[dev] = true;
+    if (e == hipSuccess && dev < kMaxDevices) done[dev].store(true, std::memory_order_release);
     return e;
 }
 

@@ -680,7 +680,7 @@ namespace {
 template <int NKA, int NKB, int CH>
 af_status launch_resfir(const FusedGeom& g, unsigned grid, size_t smem, hipStream_t s)
 {
-    static bool attr_set[kMaxDevices] = {};
+    static LdsAttrFlags attr_set;
     AF_HIP(allow_big_lds(resfir_kernel<NKA, NKB, CH>, 160 * 1024, attr_set));
     hipLaunchKernelGGL((resfir_kernel<NKA, NKB, CH>), dim3(grid), dim3(512), smem, s, g);
     AF_HIP(hipGetLastError());

@@ -56,15 +56,28 @@ constexpr int kT = 64 * kW;               // threads per workgroup
 constexpr int kHop = 256;
 constexpr int kTile = 15 * kHop + kNfft;  // mono samples of one unit (4864)
 constexpr int kTail = kNfft - kHop;       // samples shared with the next unit (768)
-constexpr int kWb = 1284;                 // per-wave LDS buffer in dwords (== 4 mod 32: the 16 frames x 2
-                                          // k-groups of a mel operand read fall into 32 different banks)
+// Power rows of this kernel: frame f = 2w + r lives in wave w's buffer at r * kProw2.  The mel phase reads them with
+// ds_read_b128 (lane (frame n, k-group kq) takes bins bin0 + 4 kq .. + 3 of a slot): its 16-lane groups are
+// {n 0-3, 12-15 of kq} + {n 4-11 of kq + 1}, so with kWb = 16 and kProw2 = 8 (mod 64 dwords) the 16-byte slot of a
+// lane is 2 n + kq (mod 16) and every group covers all 16 slots = 64 banks.
+#ifndef AF_V2_MEL_B32
+constexpr bool kBinMajor = true;
+constexpr int kProw2 = 520;               // dwords per power row: 513 bins + 3 zeros (a slot may end at bin 515) + pad
+constexpr int kWb = 1168;                 // per-wave LDS buffer in dwords: exchange planes (2 x 576), T1 (16 x 68), 2 power rows
+#else                                     // ablation (scripts/ablate): round 2's four ds_read_b32 per slot
+constexpr bool kBinMajor = false;
+constexpr int kProw2 = 514;               // == 2 (mod 32)
+constexpr int kWb = 1284;                 // == 4 (mod 32): 16 frames x 2 k-groups of a ds_read_b32 on 32 different banks
+#endif
 constexpr int kT1Row = 68;                // first transposition: row k1 = 64 columns + 4: the 16 lanes (k1, c) of a
                                           // ds_read_b128 phase start 4 k1 banks apart and cover all 64
 constexpr int kWinRow2 = 20;              // window table row (one per lane): 16 values + 4 pad
 constexpr int kTw1Row = 36;               // twiddle table row (one per lane): 16 (cos, sin) + 4 pad
-constexpr int kTw2Row = 36;               // second twiddle table row (c = 0..3): 16 (cos, sin) + 4 pad
-constexpr int kTabFloats = 64 * kWinRow2 + 64 * kTw1Row + 4 * kTw2Row;
+constexpr int kTabFloats = 64 * kWinRow2 + 64 * kTw1Row;    // the tables every workgroup copies into LDS
+constexpr int kLaneTw = 10;               // per-lane stage-2 twiddles (registers), behind the tables in global memory
+constexpr int kLaneTwFloats = 64 * kLaneTw + 2;
 constexpr int kLdsFloats = kW * kWb + kTile + kTabFloats + kW * kMaxSlotsW;
+static_assert((!kBinMajor || (kWb % 64 == 16 && kProw2 % 64 == 8)) && kWb >= 2 * 576 && kWb >= 16 * kT1Row && kWb >= 2 * kProw2, "wave buffer layout");
 
 // One 16-frame unit, 32 bytes, read with one scalar load.
 struct UnitDesc {
@@ -79,7 +92,7 @@ struct UnitDesc {
 struct Params {
     const void* pcm;
     float* out;               // mel rows [total_frames][n_mels] or power rows [total_frames][513]
-    const float* tabs;        // wintab [64][kWinRow2] | tw1 [64][kTw1Row] | tw2 [4][kTw2Row]
+    const float* tabs;        // wintab [64][kWinRow2] | tw1 [64][kTw1Row] | lanetw [64][kLaneTw] (not copied to LDS)
     const float* wfrag;       // [8][kMaxSlotsW][64][4]
     const int* meta;          // [8][kMaxSlotsW]
     const UnitDesc* units;

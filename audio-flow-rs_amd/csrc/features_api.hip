@@ -111,8 +111,11 @@ void build_mel(const af_features_config& c, double f_max, std::vector<float>& W)
 // steps in total).
 int flush_cost() { return 8; }
 
+// bin_major (hop-256 kernel): a slot's 16 bins start on a multiple of 4 and lane (row, kq) of step i holds the
+// weight of bin bin0 + 4 kq + i, so that a lane's four B operands of a slot are ONE 16-byte LDS read; otherwise
+// (general kernel) step i covers bins bin0 + 4 i + kq.
 af_status build_plan(const std::vector<float>& W, int n_mels, int kWaves, int max_slots, int uf, Plan& plan,
-                     std::vector<float>& wfrag, std::vector<int>& meta)
+                     std::vector<float>& wfrag, std::vector<int>& meta, bool bin_major = false)
 {
     std::memset(&plan, 0, sizeof(plan));
     plan.n_mels = n_mels;
@@ -135,11 +138,14 @@ af_status build_plan(const std::vector<float>& W, int n_mels, int kWaves, int ma
         for (int m = uf * u0; m < uf * u1 && m < n_mels; ++m)
             if (hi[m] >= 0) { l = std::min(l, lo[m]); h = std::max(h, hi[m]); }
         if (h < l) { l = 0; h = 0; }                        // all-zero group: one harmless step
+        if (bin_major) l &= ~3;
         steps = (h - l + 1 + 3) / 4;
         b0 = l;
         // the group's steps, padding included, walk consecutive bins: never read past bin 512
+        // (bin_major: past bin 515 -- the kernel keeps three zero bins behind bin 512)
         const int padded = (steps + kSlotSteps - 1) / kSlotSteps * kSlotSteps;
-        if (b0 + 4 * padded > kBins) b0 = kBins - 4 * padded;
+        const int row_end = bin_major ? kBins + 3 : kBins;
+        if (b0 + 4 * padded > row_end) b0 = row_end - 4 * padded;
         if (b0 < 0) b0 = 0;
     };
     const int INF = 1 << 28;
@@ -157,8 +163,12 @@ af_status build_plan(const std::vector<float>& W, int n_mels, int kWaves, int ma
                 int b0, st;
                 band(k, j, b0, st);
                 st = (st + kSlotSteps - 1) / kSlotSteps * kSlotSteps;   // groups occupy whole slots
-                if (g[i][k] + st + kFlushCost < g[i][j]) {
-                    g[i][j] = g[i][k] + st + kFlushCost;
+                // a group that does not start and end on a multiple of 4 filters leaves as four predicated
+                // single-float stores per lane instead of one 16-byte store: twice the flush
+                const bool quads = (uf * k) % 4 == 0 && (std::min(uf * j, n_mels) - uf * k) % 4 == 0;
+                const int fl = quads ? kFlushCost : 2 * kFlushCost;
+                if (g[i][k] + st + fl < g[i][j]) {
+                    g[i][j] = g[i][k] + st + fl;
                     gs[i][j] = gs[i][k] + st;
                     gcut[i][j] = k;
                 }
@@ -213,7 +223,9 @@ af_status build_plan(const std::vector<float>& W, int n_mels, int kWaves, int ma
                 const int bin = b0 + 4 * i;
                 if (s % kSlotSteps == 0) meta[(size_t)w * kMaxSlotsW + s / kSlotSteps] = bin;
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int r = lane & 15, k = bin + (lane >> 4);
+                    const int r = lane & 15;
+                    const int k = bin_major ? (bin - 4 * (i % kSlotSteps)) + 4 * (lane >> 4) + i % kSlotSteps
+                                            : bin + (lane >> 4);
                     wfrag[(((size_t)w * kMaxSlotsW + s / kSlotSteps) * 64 + lane) * kSlotSteps +
                           s % kSlotSteps] =
                         (r < cnt && k < kBins) ? W[(size_t)(m0 + r) * kBins + k] : 0.0f;   // zero off the band
@@ -388,8 +400,8 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     std::vector<int> meta8;
     if (cfg->hop == (uint32_t)v2::kHop) {
         // 6 slots per wave where the filterbank allows it (the instance with the smaller register budget)
-        if (build_plan(p->W, (int)cfg->n_mels, v2::kW, 6, 2, p->plan8, wfrag8, meta8) != AF_OK &&
-            build_plan(p->W, (int)cfg->n_mels, v2::kW, 8, 2, p->plan8, wfrag8, meta8) != AF_OK) {
+        if (build_plan(p->W, (int)cfg->n_mels, v2::kW, 6, 2, p->plan8, wfrag8, meta8, v2::kBinMajor) != AF_OK &&
+            build_plan(p->W, (int)cfg->n_mels, v2::kW, 8, 2, p->plan8, wfrag8, meta8, v2::kBinMajor) != AF_OK) {
             std::memset(&p->plan8, 0, sizeof(p->plan8));
             wfrag8.clear();
             meta8.clear();
@@ -415,13 +427,13 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
             twtab[n2 * kTwRow + 2 * k1 + 1] = (float)std::sin(a);
         }
     // hop-256 kernel tables: window [64][kWinRow2] (row = lane, its n2; n1 = 0..15: 0.5 hann[64 n1 + n2]),
-    // twiddles [64][kTw1Row] (row = lane: (cos, sin)(2 pi n2 k1 / 1024), k1 = 1..15) and
-    // [4][kTw2Row] (c: (cos, sin)(2 pi c b / 64), b = 1..15)
-    std::vector<float> tabs2(v2::kTabFloats, 0.0f);
+    // twiddles [64][kTw1Row] (row = lane: (cos, sin)(2 pi n2 k1 / 1024), k1 = 1..15), then the per-lane
+    // stage-2 twiddles [64][kLaneTw] that the kernel keeps in registers
+    std::vector<float> tabs2(v2::kTabFloats + v2::kLaneTwFloats, 0.0f);
     {
         float* win2 = tabs2.data();
         float* tw1 = win2 + 64 * v2::kWinRow2;
-        float* tw2 = tw1 + 64 * v2::kTw1Row;
+        float* ltw = tw1 + 64 * v2::kTw1Row;
         // rows are indexed by LANE: lane l = 16 c + m runs stage 1 for n2 = c + 4 m (features_v2.hip, T1)
         for (int l = 0; l < 64; ++l) {
             const int n2 = (l >> 4) + 4 * (l & 15);
@@ -435,12 +447,18 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
                 tw1[l * v2::kTw1Row + 2 * (n1 - 1) + 1] = (float)std::sin(a);
             }
         }
-        for (int c = 0; c < 4; ++c)
-            for (int b = 1; b < 16; ++b) {
-                const double a = 2.0 * kPi * (double)(c * b) / 64.0;
-                tw2[c * v2::kTw2Row + 2 * (b - 1)] = (float)std::cos(a);
-                tw2[c * v2::kTw2Row + 2 * (b - 1) + 1] = (float)std::sin(a);
+        // stage-2 twiddles per lane (kept in registers): lane (k1, j = l / 16): cos, sin of W32^j, then for
+        // b' = 0..3 tan, cos of w = e^{-2 pi i (j + 4 b') / 64} (angle <= 84.4 degrees)
+        for (int l = 0; l < 64; ++l) {
+            const int j = l >> 4;
+            ltw[l * v2::kLaneTw] = (float)std::cos(2.0 * kPi * (double)j / 32.0);
+            ltw[l * v2::kLaneTw + 1] = (float)std::sin(2.0 * kPi * (double)j / 32.0);
+            for (int bp = 0; bp < 4; ++bp) {
+                const double a1 = 2.0 * kPi * (double)(j + 4 * bp) / 64.0;
+                ltw[l * v2::kLaneTw + 2 + 2 * bp] = (float)std::tan(a1);
+                ltw[l * v2::kLaneTw + 3 + 2 * bp] = (float)std::cos(a1);
             }
+        }
     }
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t off_tw = wintab.size() * sizeof(float);

@@ -529,7 +529,7 @@ template <int HOP_T, int CH, bool I16, bool STAMPS, bool SEP, int NSLOT>
 static af_status launch_k(const Params& p, int grid, size_t smem, hipStream_t stream)
 {
     auto kern = af_features_kernel<HOP_T, CH, I16, STAMPS, SEP, NSLOT>;
-    static bool attr_set[kMaxDevices] = {};
+    static LdsAttrFlags attr_set;
     AF_HIP(allow_big_lds(kern, 160 * 1024, attr_set));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), smem, stream, p);
     AF_HIP(hipGetLastError());

@@ -10,14 +10,15 @@
 //       stage 1   lane 16 c + m takes n2 = c + 4 m:  radix-16 over n1  (n = 64 n1 + n2), twiddle W1024^(n2 k1)
 //       T1        through LDS: row k1, position = writing lane;  lane (k1, c) reads its columns c + 4m as
 //                 positions 16 c .. 16 c + 15 (four ds_read_b128)
-//       stage 2a  radix-16 over m -> b, twiddle W64^(c b)
+//       stage 2a  radix-16 over m -> b
 //       T2        in registers (v_permlane32_swap / v_permlane16_swap): lane (k1, j) gets b = j + 4b' of its four c lanes
-//       stage 2b  four radix-4 over c -> a;  lane L = k1 + 16 j then holds Z[L + 64 t], t = b' + 4a
+//       stage 2b  twiddle W64^(c b) from four per-lane register constants, folded into four radix-4 over c -> a;
+//                 lane L = k1 + 16 j then holds Z[L + 64 t], t = b' + 4a
 //     All butterflies are FMA-shaped (fft_regs.hpp).  The transposition stores are
 //     ds_write_addtid_b32 (row / plane offset in the instruction, no address register, half the
 //     LDS cycles of ds_write_b32).
 //   * split of the packed spectrum: Z[1024 - k] sits in lane (64 - L) % 64, register 15 - t
-//     (lane 0: 16 - t), exchanged through the same buffer; power rows [frame][514] in LDS.
+//     (lane 0: 16 - t), exchanged through the same buffer; power rows [frame][kProw2] in LDS.
 //   * mel: the banded filterbank groups are dealt to the 8 waves (features_api.hip build_plan),
 //     v_mfma_f32_16x16x4_f32; a wave's A fragments (L2-resident) are fetched once per unit, after
 //     stage 1, where the register pressure has dropped.
@@ -32,6 +33,9 @@
 //   64 exchange stores   128 exchange reads   256 power-row stores   512 mel operand reads   1024 tile update
 #ifndef AF_ABL
 #define AF_ABL 0
+#endif
+#ifndef AF_V2_ALL_SLOTS
+#define AF_V2_ALL_SLOTS 0
 #endif
 
 namespace af {
@@ -67,8 +71,8 @@ __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 // Lane-consecutive LDS stores without an address register: ds_write_addtid_b32 writes lane l's
 // value to  M0 + offset + 4 l  (half the LDS cycles of ds_write_b32: no address VGPR to move).
 // m0 = LDS byte address of the wave's buffer (wave-uniform); value i goes to row i, rows STRIDE
-// bytes apart from BASE.  M0 is set inside every statement (the compiler treats it as a scratch
-// register), followed by the wait state the ISA asks for between an M0 write and an add-TID access.
+// bytes apart from BASE.  M0 is set inside every statement and listed as clobbered (the compiler may keep
+// a value of its own there), followed by the wait state the ISA asks for between an M0 write and an add-TID access.
 // AF_V2_NO_ADDTID (diagnostics): the same stores as plain ds_write_b32.
 struct WaveBuf {
     float* wb;
@@ -101,7 +105,7 @@ __device__ __forceinline__ void addtid_store8(const WaveBuf& b, float v0, float 
                    "n"(BASE), "n"(BASE + STRIDE), "n"(BASE + 2 * STRIDE), "n"(BASE + 3 * STRIDE),
                    "n"(BASE + 4 * STRIDE), "n"(BASE + 5 * STRIDE), "n"(BASE + 6 * STRIDE),
                    "n"(BASE + 7 * STRIDE)
-                 : "memory");
+                 : "memory", "m0");
 #endif
 }
 template <int BASE>
@@ -112,7 +116,7 @@ __device__ __forceinline__ void addtid_store1(const WaveBuf& b, float v0)
     asm volatile("" ::: "memory");
 #else
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(v0), "s"(b.m0), "n"(BASE)
-                 : "memory");
+                 : "memory", "m0");
 #endif
 }
 template <int STRIDE, int BASE>
@@ -167,33 +171,37 @@ __device__ __forceinline__ int tile_phys(int idx)
 // One frame pair: signal tile -> two power rows in this wave's buffer wb.
 //   tile   mono samples of the unit, frame f starts at tile[f * kHop]
 //   wb     this wave's buffer (kWb dwords), m0 its byte offset in LDS
-// Part 1: stage 1 and the first transposition; ur / ui hold stage 2a's inputs (element brev4(m)).
-__device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float* wb, const WaveBuf& wv, int w,
-                                           int lane, const float* __restrict__ wtab,
-                                           const float* __restrict__ tw1, float (&ur)[16], float (&ui)[16])
+// Part 1a: this lane's 20 tile samples and its 16 window values (LDS reads only; the tile may be rewritten as soon
+// as every wave of the workgroup has these in registers).
+__device__ __forceinline__ void stage1_load(const float* __restrict__ tile, int w, int lane,
+                                            const float* __restrict__ wtab, float (&s)[20], float (&win)[16])
 {
-    const int k1 = lane & 15, hi = lane >> 4;
     // lane l = 16 c + m runs stage 1 for column n2 = c + 4 m, so that the 16 columns c + 4 m' a lane (k1, c)
     // reads after the transposition sit next to each other (positions 16 c .. 16 c + 15 of a row: four
     // ds_read_b128 instead of sixteen ds_read_b32).  The window / twiddle table rows are stored per lane.
-    const int n2 = hi + 4 * k1;
+    const int n2 = (lane >> 4) + 4 * (lane & 15);
+    const float* src = tile + (2 * w) * kHop + tile_swz(n2);
+#pragma unroll
+    for (int j = 0; j < 20; ++j) s[j] = (AF_ABL & 1) ? abl_val(lane, j) : src[64 * j];
+    const float4* wrow = reinterpret_cast<const float4*>(wtab + lane * kWinRow2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 v = (AF_ABL & 2) ? float4{abl_val(lane, j), 0.5f, 0.25f, 0.125f} : wrow[j];
+        win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
+    }
+}
+
+// Part 1b: stage 1 and the first transposition; ur / ui hold stage 2a's inputs (element brev4(m)).
+__device__ __forceinline__ void fft_pair_1(const float (&s)[20], const float (&win)[16], float* wb, const WaveBuf& wv,
+                                           int lane, const float* __restrict__ tw1, float (&ur)[16], float (&ui)[16])
+{
+    const int k1 = lane & 15, hi = lane >> 4;
     float re[16], im[16];
 
     // ---- stage 1: z[64 n1 + n2] = w * (a + i b); frame b = frame a shifted by
     // kHop samples = 4 registers.  The window multiply is fused into the twiddle-free first DIT
     // stage (element e holds input brev4(e): elements (e, e + 1) are inputs (na, na + 8)).
     {
-        const float* src = tile + (2 * w) * kHop + tile_swz(n2);
-        float s[20];
-#pragma unroll
-        for (int j = 0; j < 20; ++j) s[j] = (AF_ABL & 1) ? abl_val(lane, j) : src[64 * j];
-        float win[16];
-        const float4* wrow = reinterpret_cast<const float4*>(wtab + lane * kWinRow2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 v = (AF_ABL & 2) ? float4{abl_val(lane, j), 0.5f, 0.25f, 0.125f} : wrow[j];
-            win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
-        }
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
             const int na = brev4(e), nb = na + 8;
@@ -266,34 +274,20 @@ __device__ __forceinline__ void fft_pair_1(const float* __restrict__ tile, float
 }
 
 // Part 2: stage 2, spectrum split, power rows.
-__device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lane, const float* __restrict__ tw2,
+//   ltw    this lane's stage-2 twiddles (registers for the whole launch, behind Params::tabs), j = lane / 16:
+//          cos, sin of W32^j, then for b' = 0..3 tan, cos of w = W64^(j + 4 b')
+__device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lane, const float (&ltw)[kLaneTw],
                                            float (&ur)[16], float (&ui)[16])
 {
-    const int hi = lane >> 4;
-    // ---- stage 2a: radix-16 over m -> b, twiddle W64^(c b)
+    // ---- stage 2a: radix-16 over m -> b.  Its twiddle W64^(c b) is applied AFTER the transposition below, where
+    // c has become the register index and b = j + 4 b' has one lane-dependent part only: every lane keeps its
+    // four w = W64^b (and w^2) in registers and no table row is read (was 8 ds_read_b128 per frame pair).
     fftr::dit_fft<16>(ur, ui);
-    {
-        const float4* trow = reinterpret_cast<const float4*>(tw2 + hi * kTw2Row);   // b = 1..15, as in part 1
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const float4 t = (AF_ABL & 32) ? float4{abl_val(lane, jj), 0.5f, 0.25f, 0.125f} : trow[jj];
-            {
-                const float xr = ur[2 * jj + 1], xi = ui[2 * jj + 1];
-                ur[2 * jj + 1] = __builtin_fmaf(xr, t.x, xi * t.y);
-                ui[2 * jj + 1] = __builtin_fmaf(xi, t.x, -(xr * t.y));
-            }
-            if (jj < 7) {
-                const float xr = ur[2 * jj + 2], xi = ui[2 * jj + 2];
-                ur[2 * jj + 2] = __builtin_fmaf(xr, t.z, xi * t.w);
-                ui[2 * jj + 2] = __builtin_fmaf(xi, t.z, -(xr * t.w));
-            }
-        }
-    }
 
-    // ---- T2: lane (k1, j) needs U'[k1][c][j + 4b'] for c = 0..3 from the four lanes (k1, c): per b' a
+    // ---- T2: lane (k1, j) needs U[k1][c][j + 4b'] for c = 0..3 from the four lanes (k1, c): per b' a
     // 4 x 4 transpose (lane row c, register j) -> (lane row j, register c) of registers 4b'..4b'+3,
     // done in registers: v_permlane32_swap exchanges rows {2, 3} of one register with rows {0, 1} of
-    // another, v_permlane16_swap rows {1, 3} with rows {0, 2}.  Afterwards element 4b' + c holds x_c.
+    // another, v_permlane16_swap rows {1, 3} with rows {0, 2}.  Afterwards element 4b' + c holds U_c.
 #pragma unroll
     for (int bp = 0; bp < 4; ++bp) {
         swap_rows32(ur[4 * bp], ur[4 * bp + 2]);
@@ -306,17 +300,29 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
         swap_rows16(ui[4 * bp + 2], ui[4 * bp + 3]);
     }
 
-    // ---- stage 2b: radix-4 over c -> a, in place: Z[lane + 64 t], t = b' + 4a, is element 4b' + a
+    // ---- stage 2b: Z_a = sum_c W4^(c a) w^c U_c, in place (Z[lane + 64 t], t = b' + 4a, is element 4b' + a):
+    //   E+- = U0 +- w^2 U2,  O+- = U1 +- w^2 U3,  Z0 / Z2 = E+ +- w O+,  Z1 / Z3 = E- +- (-i w) O-
+    // w^2 = W32^j W8^b': the lane's W32^j as a plain complex product (registers ltw[0..1]), W8^b' folded into the
+    // E / O butterflies at compile time (fft_regs.hpp); w itself in the FMA form w = cos (1 - i tan) from
+    // ltw[2 + 2b'], ltw[3 + 2b'] (angle <= 84.4 degrees).
+    const float c2 = ltw[0], s2 = ltw[1];
 #pragma unroll
     for (int bp = 0; bp < 4; ++bp) {
-        const float x0r = ur[4 * bp], x1r = ur[4 * bp + 1], x2r = ur[4 * bp + 2], x3r = ur[4 * bp + 3];
-        const float x0i = ui[4 * bp], x1i = ui[4 * bp + 1], x2i = ui[4 * bp + 2], x3i = ui[4 * bp + 3];
-        const float t0r = x0r + x2r, t0i = x0i + x2i, t1r = x0r - x2r, t1i = x0i - x2i;
-        const float t2r = x1r + x3r, t2i = x1i + x3i, t3r = x1r - x3r, t3i = x1i - x3i;
-        ur[4 * bp] = t0r + t2r;     ui[4 * bp] = t0i + t2i;         // a = 0
-        ur[4 * bp + 2] = t0r - t2r; ui[4 * bp + 2] = t0i - t2i;     // a = 2
-        ur[4 * bp + 1] = t1r + t3i; ui[4 * bp + 1] = t1i - t3r;     // a = 1: t1 - i t3
-        ur[4 * bp + 3] = t1r - t3i; ui[4 * bp + 3] = t1i + t3r;     // a = 3: t1 + i t3
+        const float t1 = ltw[2 + 2 * bp], c1 = ltw[3 + 2 * bp];
+        float epr = ur[4 * bp], epi = ui[4 * bp], opr = ur[4 * bp + 1], opi = ui[4 * bp + 1];
+        const float u2r = ur[4 * bp + 2], u3r = ur[4 * bp + 3], u2i = ui[4 * bp + 2], u3i = ui[4 * bp + 3];
+        float emr = __builtin_fmaf(c2, u2r, s2 * u2i), emi = __builtin_fmaf(c2, u2i, -(s2 * u2r));    // W32^j U2
+        float omr = __builtin_fmaf(c2, u3r, s2 * u3i), omi = __builtin_fmaf(c2, u3i, -(s2 * u3r));    // W32^j U3
+        fftr::butterfly(4 * bp, epr, epi, emr, emi);          // (E+, E-) = U0 +- W8^b' (W32^j U2)
+        fftr::butterfly(4 * bp, opr, opi, omr, omi);          // (O+, O-) = U1 +- W8^b' (W32^j U3)
+        // w O / cos:  (or + oi t) + i (oi - or t)
+        const float vpr = __builtin_fmaf(opi, t1, opr), vpi = __builtin_fmaf(-opr, t1, opi);
+        const float vmr = __builtin_fmaf(omi, t1, omr), vmi = __builtin_fmaf(-omr, t1, omi);
+        ur[4 * bp] = __builtin_fmaf(vpr, c1, epr);      ui[4 * bp] = __builtin_fmaf(vpi, c1, epi);        // a = 0
+        ur[4 * bp + 2] = __builtin_fmaf(-vpr, c1, epr); ui[4 * bp + 2] = __builtin_fmaf(-vpi, c1, epi);   // a = 2
+        // -i w O- = cos (vmi - i vmr)
+        ur[4 * bp + 1] = __builtin_fmaf(vmi, c1, emr);  ui[4 * bp + 1] = __builtin_fmaf(-vmr, c1, emi);   // a = 1
+        ur[4 * bp + 3] = __builtin_fmaf(-vmi, c1, emr); ui[4 * bp + 3] = __builtin_fmaf(vmr, c1, emi);    // a = 3
     }
 #define ZR(t) ur[4 * ((t) & 3) + ((t) >> 2)]
 #define ZI(t) ui[4 * ((t) & 3) + ((t) >> 2)]
@@ -352,10 +358,16 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
         // power rows [frame][514] (they alias the exchange planes: every lane has read its partners)
         if constexpr (!(AF_ABL & 256)) {
         addtid_store8<256, 0>(wv, pa[0], pa[1], pa[2], pa[3], pa[4], pa[5], pa[6], pa[7]);
-        addtid_store8<256, 4 * kProw>(wv, pb[0], pb[1], pb[2], pb[3], pb[4], pb[5], pb[6], pb[7]);
+        addtid_store8<256, 4 * kProw2>(wv, pb[0], pb[1], pb[2], pb[3], pb[4], pb[5], pb[6], pb[7]);
         if (lane == 0) {
-            wb[512] = pa[8];
-            wb[kProw + 512] = pb[8];
+            if constexpr (kBinMajor) {
+                // bin 512 and the three zero bins behind it (the last mel slot may reach bin 515; the words alias T1)
+                *reinterpret_cast<float4*>(wb + 512) = float4{pa[8], 0.f, 0.f, 0.f};
+                *reinterpret_cast<float4*>(wb + kProw2 + 512) = float4{pb[8], 0.f, 0.f, 0.f};
+            } else {
+                wb[512] = pa[8];
+                wb[kProw2 + 512] = pb[8];
+            }
         }
         } else {
             float sink = 0.f;
@@ -419,8 +431,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     float* tile = wbufs + kW * kWb;
     float* wtab = tile + kTile;
     float* tw1 = wtab + 64 * kWinRow2;
-    float* tw2 = tw1 + 64 * kTw1Row;
-    int* lmeta = reinterpret_cast<int*>(tw2 + 4 * kTw2Row);
+    int* lmeta = reinterpret_cast<int*>(tw1 + 64 * kTw1Row);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -443,10 +454,25 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     int slot_end_w[NSLOT];
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) slot_end_w[q] = p.plan.slot_end[w][q];
+    const int n_slots_w = p.plan.wave_nslots[w];
     const int n_mels = p.plan.n_mels;
     const bool vec_ok = (n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(p.out) % 16 == 0);
-    const float* pbase = wbufs + ((lane & 15) >> 1) * kWb + (lane & 1) * kProw + (lane >> 4);
+    const float* pbase = wbufs + ((lane & 15) >> 1) * kWb + (lane & 1) * kProw2 + (kBinMajor ? 4 : 1) * (lane >> 4);
     const unsigned row_off = (unsigned)(lane & 15) * (unsigned)n_mels + 4u * (unsigned)(lane >> 4);
+
+    // this lane's stage-2 twiddles, in registers for the whole launch
+    float ltw[kLaneTw];
+    {
+        const float* lt = p.tabs + kTabFloats + kLaneTw * lane;
+#pragma unroll
+        for (int q = 0; q < kLaneTw; ++q) ltw[q] = lt[q];
+        // Wait for them HERE, with a wait the compiler sees: otherwise its wait-count pass carries these loads as
+        // possibly pending around the unit loop and puts an s_waitcnt vmcnt(1) in front of their first use in every
+        // iteration -- which waits for the PCM prefetch requested at the top of the iteration, in the middle of the FFT.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+#pragma unroll
+        for (int q = 0; q < kLaneTw; ++q) asm volatile("" : "+v"(ltw[q]));
+    }
 
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memtime() : 0;
@@ -502,7 +528,9 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             // 0..3 and would run the two FFT parts ~25 % slower (10.5 k against 8.5 k cycles), everyone then
             // waiting for them at B2.  One priority step for the younger half evens that out (-2.3 %).
             if (w >= 4) __builtin_amdgcn_s_setprio(1);
-            fft_pair_1(tile, wb, wv, w, lane, wtab, tw1, ur, ui);
+            float s1[20], win[16];
+            stage1_load(tile, w, lane, wtab, s1, win);
+            fft_pair_1(s1, win, wb, wv, lane, tw1, ur, ui);
 
             AF_STAMP2(2);
             // This wave's filterbank fragments (L2-resident, one float4 per slot), issued where the
@@ -520,7 +548,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
 #pragma unroll
                 for (int q = 0; q < NSLOT * kSlotSteps; ++q) wf[q] = 0.0f;
             }
-            fft_pair_2(wb, wv, lane, tw2, ur, ui);
+            fft_pair_2(wb, wv, lane, ltw, ur, ui);
             __builtin_amdgcn_s_setprio(0);
         }
         AF_STAMP2(3);
@@ -530,6 +558,11 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         // let them go ahead of the other workgroup's FFT stream
         __builtin_amdgcn_s_setprio(2);
         AF_STAMP2(4);
+        // Everything this wave has in flight is old by now (prefetch: a whole FFT ago; fragments: half of one; the
+        // previous unit's mel stores: a unit ago) and all of it is needed right below.  One wait the compiler sees,
+        // instead of its own: it counts the fragment loads against the mel stores issued between the slots (vector
+        // memory operations retire in order), so a slot behind a flush waited for that flush's HBM stores.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
 
         if (has_next && !(AF_ABL & 1024)) {
             // The next tile is this one shifted by 16 hops: the last kTail samples move to the front,
@@ -567,10 +600,13 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                 const int* lm = lmeta + w * kMaxSlotsW;
 #pragma unroll
                 for (int q = 0; q < NSLOT; ++q) {
+                    // one ds_read_b128: step i of the slot takes bins bin0 + 4 kq + i (the fragments are cut to match)
                     const float* bq = pbase + lm[q];
-#pragma unroll
-                    for (int i = 0; i < kSlotSteps; ++i)
-                        bop[q * kSlotSteps + i] = (AF_ABL & 512) ? abl_val(lane, i + 4 * q) : bq[4 * i];
+                    const float4 bv = (AF_ABL & 512) ? float4{abl_val(lane, q), 0.5f, 0.25f, 0.125f}
+                                      : kBinMajor    ? *reinterpret_cast<const float4*>(bq)
+                                                     : float4{bq[0], bq[4], bq[8], bq[12]};
+                    bop[q * kSlotSteps] = bv.x; bop[q * kSlotSteps + 1] = bv.y;
+                    bop[q * kSlotSteps + 2] = bv.z; bop[q * kSlotSteps + 3] = bv.w;
                 }
             }
             if constexpr (STAMPS) {                                  // diagnostics: operands and fragments landed
@@ -583,13 +619,14 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             const bool fvalid = (lane & 15) < ud.n_rows;
             const int i0 = 4 * (lane >> 4);
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            // Every compiled-in slot runs, also the ones this wave does not use (zero weights, no flush behind
-            // them): skipped slots left their fragment loads unconsumed, hipcc then made the next unit's first
-            // LDS reads -- which overwrite those registers -- wait for vmcnt(5..0), i.e. for the PCM prefetch
-            // that had just been requested, and the prefetch never overlapped the FFT.
+            // Slots this wave does not use are skipped (wave-uniform branch).  Round 2 had to run every compiled-in
+            // slot: skipped slots left their fragment loads unconsumed and hipcc made the next unit's first LDS
+            // reads -- which overwrite those registers -- wait for vmcnt(5..0), i.e. for the PCM prefetch just
+            // requested.  The explicit vmcnt(0) above retires all of them for the compiler, so the branch is free
+            // of that; AF_V2_ALL_SLOTS = 1 (ablation) restores the branch-free form.
 #pragma unroll
             for (int q = 0; q < NSLOT; ++q) {
-                {
+                if (AF_V2_ALL_SLOTS || q < n_slots_w) {
 #pragma unroll
                     for (int st = q * kSlotSteps; st < (q + 1) * kSlotSteps; st += 2) {
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], bop[st], acc0, 0, 0, 0);
@@ -624,7 +661,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                 const int f = 2 * w + r;
                 if (f < ud.n_rows) {
                     float* o = p.out + (ud.out0 + f) * kBins;
-                    for (int k = lane; k < kBins; k += 64) o[k] = wb[r * kProw + k];
+                    for (int k = lane; k < kBins; k += 64) o[k] = wb[r * kProw2 + k];
                 }
             }
         }
@@ -645,7 +682,7 @@ static af_status launch_kp(const Params& p, int grid, hipStream_t stream)
     auto kern = af_features_v2_kernel<CH, I16, SEP, NSLOT, STAMPS, POWER>;
     constexpr size_t smem = sizeof(float) * kLdsFloats;
     static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
-    static bool attr_set[kMaxDevices] = {};
+    static LdsAttrFlags attr_set;
     AF_HIP(allow_big_lds(kern, (int)smem, attr_set));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kT), smem, stream, p);
     AF_HIP(hipGetLastError());

@@ -227,7 +227,7 @@ af_status launch(const Design& d, const float* x_dev, int64_t x_abs0, int64_t x_
     g.M = d.M;
     g.taps_in_lds = d.taps_in_lds;
     g.x_tile_cap = d.x_tile_cap;
-    static bool attr_set[kMaxDevices] = {};
+    static LdsAttrFlags attr_set;
     AF_HIP(allow_big_lds(resample_kernel, 160 * 1024, attr_set));
     int64_t grid = g.n_tiles;
     const int64_t cap = device_cu_count(current_device()) * (int64_t)(d.smem > 80 * 1024 ? 1 : d.smem > 53 * 1024 ? 2 : 3) * 4;
