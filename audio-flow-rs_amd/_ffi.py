@@ -102,6 +102,9 @@ SIGNATURES = {
     "af_vad_detect": (_st, [_vp, _vp, _sz, C.POINTER(C.c_int)]),
     "af_vad_detect_frames": (_st, [_vp, _vp, _sz, _sz, _vp]),
     "af_vad_reset": (None, [_vp]),
+    "af_resample_release_staging": (None, []),
+    "af_vad_detect_batch_device": (_st, [C.POINTER(VadConfig), _vp, _sz, _sz, _sz, _vp, _vp, _sz, _vp]),
+    "af_vad_detect_batch": (_st, [C.POINTER(VadConfig), _vp, _sz, _sz, _sz, _vp]),
     "af_vad_state": (C.c_int, [_vp]),
     "af_vad_energy_db": (C.c_float, [_vp]),
     "af_vad_speech_frame_count": (_sz, [_vp]),

@@ -355,6 +355,34 @@ class VoiceActivityDetector:
     def reset(self) -> None:
         self._lib.af_vad_reset(self._h)                               # vad.rs:179
 
+    @staticmethod
+    def detect_batch(clips, frame_len: int, config: Optional[VadConfig] = None) -> np.ndarray:
+        """A batch of independent detectors (one per clip, vad.rs:60-70), scanned on the device:
+        clips [n_clips][n_frames * frame_len] f32 -> states [n_clips][n_frames] (VadState values, uint8).
+        Every row equals VoiceActivityDetector(config).detect_frames(row, frame_len)."""
+        x = np.ascontiguousarray(clips, dtype=np.float32)
+        assert x.ndim == 2 and frame_len > 0 and x.shape[1] % frame_len == 0
+        n_clips, n_frames = x.shape[0], x.shape[1] // frame_len
+        cfg = config or VadConfig()
+        c = _ffi.VadConfig(cfg.threshold_db, cfg.smoothing_factor, cfg.silence_timeout_frames,
+                           cfg.min_speech_frames)
+        out = np.zeros((n_clips, max(n_frames, 1)), np.uint8)
+        _check(library().af_vad_detect_batch(C.byref(c), _ptr(x), n_clips, n_frames, frame_len, _ptr(out)))
+        return out[:, :n_frames]
+
+    @staticmethod
+    def detect_batch_device(energy_ptr: int, n_clips: int, n_frames: int, states_ptr: int,
+                            config: Optional[VadConfig] = None, lanes_ptr: int = 0, row_stride: int = 0,
+                            state_stride: int = 0, stream: int = 0) -> None:
+        """Device pointers: energies [n_clips][row_stride] f32 -> states [n_clips][state_stride] uint8;
+        lanes_ptr: optional [n_clips] af_vad_lane records carried between calls (streaming)."""
+        cfg = config or VadConfig()
+        c = _ffi.VadConfig(cfg.threshold_db, cfg.smoothing_factor, cfg.silence_timeout_frames,
+                           cfg.min_speech_frames)
+        _check(library().af_vad_detect_batch_device(C.byref(c), energy_ptr, n_clips, n_frames,
+                                                    row_stride or n_frames, lanes_ptr or None, states_ptr,
+                                                    state_stride or n_frames, stream or None))
+
     def state(self) -> VadState:
         return VadState(self._lib.af_vad_state(self._h))              # vad.rs:187
 

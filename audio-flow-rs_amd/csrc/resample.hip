@@ -37,6 +37,18 @@ constexpr int kOutPerThread = 4;
 constexpr int kTileOut = kBlock * kOutPerThread;   // outputs per workgroup tile
 constexpr double kPi = 3.14159265358979323846;
 
+// Device staging of the host-buffer convenience entry point af_resample_batch, one slot per device ordinal.
+constexpr size_t kKeepBytes = (size_t)256 << 20;        // what a slot may keep between calls
+struct Staging {
+    std::mutex mu;                                       // one caller at a time per device
+    DevBuf in, out;
+};
+inline Staging& staging_slot(int dev)
+{
+    static Staging* const slots = new Staging[kMaxDevices];   // never freed: no hipFree during static destruction
+    return slots[dev >= 0 && dev < kMaxDevices ? dev : 0];
+}
+
 struct Geometry {
     const float* x;          // clip 0, element at absolute stream index x_abs0
     float* y;
@@ -502,15 +514,22 @@ af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate, const flo
     if (n_clips == 0 || n_in == 0) return AF_OK;
     AF_REQUIRE(in && out, "af_resample_batch: null buffer");
     AF_TRY(ensure_device(-1));
-    // Device staging of this convenience entry point: kept per device (grow-only) between calls -- allocating and
-    // freeing a few hundred MB per call costs more than the kernel.  One caller at a time per process.
-    struct Staging { DevBuf in, out; };
-    static std::mutex mu;
-    static Staging* const staging = new Staging[kMaxDevices];   // never freed: no hipFree during static destruction
-    std::lock_guard<std::mutex> lock(mu);
+    // Device staging of this convenience entry point: kept per device between calls -- allocating and freeing a
+    // few hundred MB per call costs more than the kernel -- but no more than kKeepBytes of it: what a bigger call
+    // needed goes back when the call returns (a config-3-sized call would otherwise pin 10 GB of HBM for the life
+    // of the process).  One caller at a time PER DEVICE; af_resample_release_staging() returns the rest.
     const int dev_ix = current_device() < kMaxDevices ? current_device() : 0;
-    DevBuf& din = staging[dev_ix].in;
-    DevBuf& dout = staging[dev_ix].out;
+    rs::Staging& stg = rs::staging_slot(dev_ix);
+    std::lock_guard<std::mutex> lock(stg.mu);
+    DevBuf& din = stg.in;
+    DevBuf& dout = stg.out;
+    struct Trim {
+        rs::Staging& s;
+        ~Trim()
+        {
+            if (s.in.bytes + s.out.bytes > rs::kKeepBytes) { s.in.release(); s.out.release(); }
+        }
+    } trim{stg};
     AF_TRY(din.reserve(n_clips * n_in * sizeof(float)));
     AF_TRY(dout.reserve(n_clips * n_out * sizeof(float)));
     // Page-locked input of some size: chunks of whole clips (about 32 MB each) with the H2D copy of chunk
@@ -574,6 +593,21 @@ af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate, const flo
                                     dout.as<float>(), nullptr));
     AF_HIP(hipMemcpy(out, dout.p, n_clips * n_out * sizeof(float), hipMemcpyDeviceToHost));
     return AF_OK;
+}
+
+void af_resample_release_staging(void)
+{
+    for (int d = 0; d < kMaxDevices; ++d) {
+        rs::Staging& s = rs::staging_slot(d);
+        std::lock_guard<std::mutex> lock(s.mu);
+        if (!s.in.p && !s.out.p) continue;
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        if (have && cur != d) (void)hipSetDevice(d);
+        s.in.release();
+        s.out.release();
+        if (have && cur != d) (void)hipSetDevice(cur);
+    }
 }
 
 af_status af_resample_taps(uint32_t input_rate, uint32_t output_rate, float* taps, size_t cap,

@@ -211,6 +211,17 @@ public:
         return static_cast<VadState>(st);
     }
     void reset() { af_vad_reset(h_); }                                            // :179
+    // A batch of independent detectors, one per clip (vad.rs:60-70), scanned on the device:
+    // clips [n_clips][n_frames * frame_len] -> states [n_clips][n_frames] (VadState values as bytes)
+    static std::vector<uint8_t> detect_batch(const VadConfig& c, const std::vector<float>& clips, size_t n_clips,
+                                             size_t frame_len)
+    {
+        af_vad_config cfg{c.threshold_db, c.smoothing_factor, c.silence_timeout_frames, c.min_speech_frames};
+        const size_t n_frames = (n_clips && frame_len) ? clips.size() / n_clips / frame_len : 0;
+        std::vector<uint8_t> out(n_clips * n_frames);
+        detail::check(af_vad_detect_batch(&cfg, clips.data(), n_clips, n_frames, frame_len, out.data()));
+        return out;
+    }
     VadState state() const { return static_cast<VadState>(af_vad_state(h_)); }    // :187
     float energy_db() const { return af_vad_energy_db(h_); }                      // :192
     bool is_speaking() const { return state() == VadState::Speech; }              // :197

@@ -120,6 +120,26 @@ af_status af_vad_detect(af_vad* v, const float* frame, size_t n, int* state_out)
 af_status af_vad_detect_frames(af_vad* v, const float* in, size_t n_frames,
                                size_t frame_len, int* states_out);
 void      af_vad_reset(af_vad* v);                       /* vad.rs:179 */
+/* A batch of detectors, one per clip (every VoiceActivityDetector owns its state, vad.rs:60-70), scanned on the
+ * device: one lane per clip walks its frames in order (vad.rs:97-154).  The EMA keeps the reference's three
+ * separately rounded f32 operations (vad.rs:102-104); the speech decision `20 log10(e) > threshold_db`
+ * (vad.rs:115-118) is taken as `e >= e*`, e* being the smallest f32 the host's log10f accepts (found by bisection),
+ * so states equal af_vad_detect_frames' exactly.  states: AF_VAD_* as one byte per frame.
+ *   energy_dev [n_clips][row_stride]  mean-square energies (af_vad_energy_device), row_stride >= n_frames
+ *   lanes_dev  [n_clips] detector state carried in and out (streaming), or NULL = fresh detectors, state dropped
+ *   states_dev [n_clips][state_stride] */
+typedef struct {
+    float    smoothed_energy;   /* vad.rs:63 */
+    uint32_t silence_frames;    /* vad.rs:65 */
+    uint32_t speech_frames;     /* vad.rs:67 */
+    uint32_t state;             /* vad.rs:69, AF_VAD_* */
+} af_vad_lane;
+af_status af_vad_detect_batch_device(const af_vad_config* cfg, const float* energy_dev, size_t n_clips,
+                                     size_t n_frames, size_t row_stride, af_vad_lane* lanes_dev,
+                                     uint8_t* states_dev, size_t state_stride, void* stream);
+/* host buffers: in [n_clips][n_frames][frame_len] f32 -> states_out [n_clips][n_frames] (energy + scan on the device) */
+af_status af_vad_detect_batch(const af_vad_config* cfg, const float* in, size_t n_clips, size_t n_frames,
+                              size_t frame_len, uint8_t* states_out);
 int       af_vad_state(const af_vad* v);                 /* vad.rs:187 */
 float     af_vad_energy_db(const af_vad* v);             /* vad.rs:192 */
 size_t    af_vad_speech_frame_count(const af_vad* v);    /* vad.rs:202 */
@@ -151,13 +171,16 @@ void      af_resampler_reset(af_resampler* r);
 
 /* One-shot batch resample [B] (BASELINE config 3): n_clips mono clips of
  * n_in samples each, contiguous; out gets n_clips * af_resample_out_len().
- * af_resample_batch (host buffers) keeps its device staging per device between calls (grow-only)
- * and serialises concurrent callers; from page-locked memory it overlaps H2D, kernel and D2H in
- * chunks of whole clips. */
+ * af_resample_batch (host buffers) keeps its device staging per device between calls and
+ * serialises concurrent callers of the SAME device; from page-locked memory it overlaps H2D, kernel
+ * and D2H in chunks of whole clips. */
 size_t    af_resample_out_len(uint32_t input_rate, uint32_t output_rate, size_t n_in);
 af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate,
                             const float* in, size_t n_clips, size_t n_in,
                             float* out, size_t out_cap);
+/* af_resample_batch keeps up to 256 MB of device staging per device between calls (what a larger call needed is
+ * freed when it returns); this frees the rest.  No reference counterpart (resampler.rs:78 allocates per call). */
+void      af_resample_release_staging(void);
 af_status af_resample_batch_device(uint32_t input_rate, uint32_t output_rate,
                                    const float* in_dev, size_t n_clips, size_t n_in,
                                    float* out_dev, void* stream);

@@ -188,6 +188,18 @@ int afo_vad_detect(afo_vad* v, const float* frame, size_t n)
     return afo_vad_step_energy(v, afo_vad_energy(frame, n));
 }
 
+/* n_clips independent detectors (vad.rs:60-70: each owns its state), each fed its row of energies in order */
+void afo_vad_scan_batch(const afo_vad_config* c, const float* energy, size_t n_clips, size_t n_frames,
+                        unsigned char* states)
+{
+    for (size_t i = 0; i < n_clips; ++i) {
+        afo_vad v;
+        afo_vad_init(&v, c);
+        for (size_t f = 0; f < n_frames; ++f)
+            states[i * n_frames + f] = (unsigned char)afo_vad_step_energy(&v, energy[i * n_frames + f]);
+    }
+}
+
 /* ---- ring buffer, capture.rs:84-161 ---------------------------------- */
 int afo_ring_init(afo_ring* r, size_t capacity)
 {

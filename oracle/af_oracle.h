@@ -74,6 +74,9 @@ int  afo_vad_detect(afo_vad* v, const float* frame, size_t n); /* vad.rs:97-154 
 /* Same state machine driven by a precomputed energy (for checking the GPU
  * energy kernel + host state machine split). */
 int  afo_vad_step_energy(afo_vad* v, float energy);
+/* n_clips independent detectors over energy[n_clips][n_frames] -> states[n_clips][n_frames] */
+void afo_vad_scan_batch(const afo_vad_config* c, const float* energy, size_t n_clips, size_t n_frames,
+                        unsigned char* states);
 void afo_vad_reset(afo_vad* v);                              /* vad.rs:179-184 */
 
 /* modules/audio/capture.rs:84-161  RingBuffer (capacity-1 usable slots). */

@@ -73,6 +73,7 @@ _vad_init = _sig("afo_vad_init", None, C.POINTER(_Vad), C.POINTER(VadConfig))
 _vad_detect = _sig("afo_vad_detect", C.c_int, C.POINTER(_Vad), _f32p, C.c_size_t)
 _vad_step = _sig("afo_vad_step_energy", C.c_int, C.POINTER(_Vad), C.c_float)
 _vad_reset = _sig("afo_vad_reset", None, C.POINTER(_Vad))
+_vad_scan = _sig("afo_vad_scan_batch", None, C.POINTER(VadConfig), _f32p, C.c_size_t, C.c_size_t, _u8p)
 _ring_init = _sig("afo_ring_init", C.c_int, C.POINTER(_Ring), C.c_size_t)
 _ring_free = _sig("afo_ring_free", None, C.POINTER(_Ring))
 _ring_write = _sig("afo_ring_write", C.c_size_t, C.POINTER(_Ring), _f32p, C.c_size_t)
@@ -151,6 +152,17 @@ def energy_to_dbfs(e: float) -> float:
 
 
 SILENCE, SPEECH, ENDING = 0, 1, 2
+
+
+def vad_scan_batch(energy, threshold_db=-50.0, smoothing_factor=0.3, silence_timeout_frames=15,
+                   min_speech_frames=3) -> np.ndarray:
+    """n_clips independent detectors (vad.rs:60-70) over energy[n_clips][n_frames] -> states uint8."""
+    e = np.ascontiguousarray(energy, dtype=np.float32)
+    assert e.ndim == 2
+    cfg = VadConfig(threshold_db, smoothing_factor, silence_timeout_frames, min_speech_frames)
+    out = np.zeros(e.shape, np.uint8)
+    _vad_scan(C.byref(cfg), e.reshape(-1), e.shape[0], e.shape[1], out.reshape(-1))
+    return out
 
 
 class Vad:

@@ -28,6 +28,9 @@ pub struct af_vad_config {
     pub threshold_db: f32, pub smoothing_factor: f32,
     pub silence_timeout_frames: usize, pub min_speech_frames: usize,
 }
+/// one detector's carried state for `af_vad_detect_batch_device` (vad.rs:63-69)
+#[repr(C)] #[derive(Clone, Copy, Debug, Default)]
+pub struct af_vad_lane { pub smoothed_energy: f32, pub silence_frames: u32, pub speech_frames: u32, pub state: u32 }
 #[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct af_features_config {
     pub sample_rate: u32, pub channels: u32, pub n_fft: u32, pub hop: u32, pub n_mels: u32,
@@ -72,6 +75,12 @@ extern "C" {
     pub fn af_vad_detect(v: *mut af_vad, frame: *const f32, n: usize, state_out: *mut c_int) -> af_status;
     pub fn af_vad_detect_frames(v: *mut af_vad, input: *const f32, n_frames: usize, frame_len: usize, states_out: *mut c_int) -> af_status;
     pub fn af_vad_reset(v: *mut af_vad);
+    // batched detectors, one lane per clip (vad.rs:60-70, :97-154)
+    pub fn af_vad_detect_batch_device(cfg: *const af_vad_config, energy_dev: *const f32, n_clips: usize, n_frames: usize,
+                                      row_stride: usize, lanes_dev: *mut af_vad_lane, states_dev: *mut u8,
+                                      state_stride: usize, stream: *mut c_void) -> af_status;
+    pub fn af_vad_detect_batch(cfg: *const af_vad_config, input: *const f32, n_clips: usize, n_frames: usize,
+                               frame_len: usize, states_out: *mut u8) -> af_status;
     pub fn af_vad_state(v: *const af_vad) -> c_int;
     pub fn af_vad_energy_db(v: *const af_vad) -> f32;
     pub fn af_vad_speech_frame_count(v: *const af_vad) -> usize;

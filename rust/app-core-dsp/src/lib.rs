@@ -56,22 +56,29 @@ impl AudioFrame {
     pub fn new(samples: Vec<f32>, sample_rate: u32, channels: u16, timestamp_ns: u128) -> Self {
         Self { samples, sample_rate, channels, timestamp_ns }
     }
-    /// capture.rs:30-42 (the reference cannot fail; a device failure degrades to the input clone)
-    pub fn to_mono(&self) -> Self {
+    /// capture.rs:30-42 with the device failure reported: `Err(AudioError::ResamplingFailed(msg))` carries the
+    /// library's message (no device, HIP error, out of memory).
+    pub fn try_to_mono(&self) -> Result<Self, AudioError> {
         if self.channels == 1 {
-            return self.clone();
+            return Ok(self.clone());
         }
         let cap = unsafe { ffi::af_to_mono_out_len(self.samples.len(), self.channels) };
         let mut mono = vec![0.0f32; cap];
         let mut n = 0usize;
-        let st = unsafe {
+        check(unsafe {
             ffi::af_to_mono(self.samples.as_ptr(), self.samples.len(), self.channels, mono.as_mut_ptr(), cap, &mut n)
-        };
-        if st != ffi::AF_OK {
-            return self.clone();
-        }
+        })?;
         mono.truncate(n);
-        Self { samples: mono, sample_rate: self.sample_rate, channels: 1, timestamp_ns: self.timestamp_ns }
+        Ok(Self { samples: mono, sample_rate: self.sample_rate, channels: 1, timestamp_ns: self.timestamp_ns })
+    }
+    /// capture.rs:30-42.  The reference's signature is infallible, the device is not: a failure PANICS with the
+    /// library's message rather than hand back a frame that still has `channels` channels (a caller that must
+    /// not unwind uses `try_to_mono`; the C++ and Python mirrors raise in the same place).
+    pub fn to_mono(&self) -> Self {
+        match self.try_to_mono() {
+            Ok(m) => m,
+            Err(e) => panic!("AudioFrame::to_mono: {e:?}"),
+        }
     }
 }
 
@@ -247,6 +254,22 @@ impl VoiceActivityDetector {
         let mut s = vec![0 as c_int; n];
         check(unsafe { ffi::af_vad_detect_frames(self.h, input.as_ptr(), n, frame_len, s.as_mut_ptr()) })?;
         Ok(s.into_iter().map(vad_state).collect())
+    }
+    /// A batch of independent detectors, one per clip (vad.rs:60-70: each owns its state), scanned on the device:
+    /// `clips` = n_clips rows of n_frames * frame_len samples; returns n_clips rows of n_frames states, each row
+    /// equal to `VoiceActivityDetector::new(config)` fed that row frame by frame (vad.rs:97-154).
+    pub fn detect_batch(config: VadConfig, clips: &[f32], n_clips: usize, frame_len: usize)
+        -> Result<Vec<Vec<VadState>>, AudioError> {
+        let c = ffi::af_vad_config {
+            threshold_db: config.threshold_db,
+            smoothing_factor: config.smoothing_factor,
+            silence_timeout_frames: config.silence_timeout_frames,
+            min_speech_frames: config.min_speech_frames,
+        };
+        let n_frames = if n_clips > 0 && frame_len > 0 { clips.len() / n_clips / frame_len } else { 0 };
+        let mut s = vec![0u8; n_clips * n_frames];
+        check(unsafe { ffi::af_vad_detect_batch(&c, clips.as_ptr(), n_clips, n_frames, frame_len, s.as_mut_ptr()) })?;
+        Ok(s.chunks(n_frames.max(1)).take(n_clips).map(|r| r.iter().map(|&v| vad_state(v as c_int)).collect()).collect())
     }
     /// vad.rs:179-184
     pub fn reset(&mut self) { unsafe { ffi::af_vad_reset(self.h) } }

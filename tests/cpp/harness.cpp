@@ -90,6 +90,12 @@ int main()
         CHECK(d.is_speaking());
         d.reset();
         CHECK(d.state() == VadState::Silence && !d.is_speaking());
+        // the same vectors through the batched device scan: clip 0 = vad.rs:239-265, clip 1 = four silent frames
+        std::vector<float> clips;
+        for (const auto* f : {&speech, &silence, &silence, &silence}) clips.insert(clips.end(), f->begin(), f->end());
+        for (int i = 0; i < 4; ++i) clips.insert(clips.end(), silence.begin(), silence.end());
+        auto st = VoiceActivityDetector::detect_batch(VadConfig{-50.0f, 0.0f, 2, 1}, clips, 2, 480);
+        CHECK(st == std::vector<uint8_t>({1, 1, 2, 0, 0, 0, 0, 0}));
     }
     // websocket.rs:376-382 test_message_builder_audio (values per :342)
     {

@@ -141,6 +141,70 @@ def test_vad_state_sequence_vs_oracle(af, po):
     assert v.speech_frame_count() == o.speech_frames
 
 
+def test_vad_batch_reference_state_tests(af):
+    """The reference's state tests (vad.rs:211-281) through the batched device scan: one clip per test."""
+    C = af.VadConfig
+    speech, silence = np.full(480, 0.5, np.float32), np.full(480, 0.0001, np.float32)
+    got = af.VoiceActivityDetector.detect_batch(np.stack([silence, speech]), 480, C(threshold_db=-50.0))
+    assert got.tolist() == [[0], [1]]                                                    # vad.rs:211, :225
+    seq = np.concatenate([speech, silence, silence, silence])[None, :]
+    got = af.VoiceActivityDetector.detect_batch(seq, 480, C(threshold_db=-50.0, silence_timeout_frames=2,
+                                                            min_speech_frames=1, smoothing_factor=0.0))
+    assert got.tolist() == [[1, 1, 2, 0]]                                                # vad.rs:239-265
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(smoothing_factor=0.0, silence_timeout_frames=2, min_speech_frames=1),
+                                 dict(threshold_db=-30.0, smoothing_factor=0.9, silence_timeout_frames=4),
+                                 dict(threshold_db=float("-inf")), dict(threshold_db=float("inf")),
+                                 dict(threshold_db=-50.0, min_speech_frames=50)])
+def test_vad_batch_device_scan_equals_oracle(af, po, cfg):
+    """1024 clips x 1500 frames of energies around the threshold (incl. 0, denormals, inf, NaN): the states of
+    the device scan equal n_clips oracle detectors exactly, and a scan cut in two pieces with the lane records
+    carried over equals the one-piece scan."""
+    import torch
+    rng = np.random.default_rng(11)
+    n_clips, n_frames = 1024, 1500
+    thr = cfg.get("threshold_db", -50.0)
+    centre = 10.0 ** (thr / 20.0) if np.isfinite(thr) else 1e-3
+    e = (centre * np.exp(rng.normal(0, 0.02, (n_clips, n_frames)))).astype(np.float32)      # hugging the threshold
+    burst = (np.arange(n_frames)[None, :] // rng.integers(5, 60, (n_clips, 1))) % 2 == 0
+    e = np.where(burst, e * np.float32(3.0), e * np.float32(0.3)).astype(np.float32)
+    e[0, :8] = [0.0, 1e-45, 1e-39, np.inf, np.nan, -1.0, 3.4e38, centre]
+    want = po.vad_scan_batch(e, **cfg)
+    dev = torch.device("cuda:0")
+    ed = torch.from_numpy(e).to(dev)
+    st = torch.zeros(n_clips, n_frames, dtype=torch.uint8, device=dev)
+    c = af.VadConfig(**cfg)
+    af.VoiceActivityDetector.detect_batch_device(ed.data_ptr(), n_clips, n_frames, st.data_ptr(), c)
+    torch.cuda.synchronize()
+    assert np.array_equal(st.cpu().numpy(), want)
+    if np.isfinite(thr):
+        assert {0, 1} <= set(np.unique(want).tolist())
+    # streaming: two pieces (the second one not a multiple of 4 frames in), lanes carried on the device
+    lanes = torch.zeros(n_clips, 4, dtype=torch.int32, device=dev)
+    st2 = torch.zeros_like(st)
+    cut = 701
+    a, b = ed[:, :cut].contiguous(), ed[:, cut:].contiguous()
+    sa = torch.zeros(n_clips, cut, dtype=torch.uint8, device=dev)
+    sb = torch.zeros(n_clips, n_frames - cut, dtype=torch.uint8, device=dev)
+    af.VoiceActivityDetector.detect_batch_device(a.data_ptr(), n_clips, cut, sa.data_ptr(), c, lanes.data_ptr())
+    af.VoiceActivityDetector.detect_batch_device(b.data_ptr(), n_clips, n_frames - cut, sb.data_ptr(), c,
+                                                 lanes.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(torch.cat([sa, sb], 1).cpu().numpy(), want)
+
+
+def test_vad_batch_host_entry_equals_single_handles(af, po):
+    rng = np.random.default_rng(3)
+    n_clips, n_frames, frame_len = 37, 61, 160
+    x = (rng.standard_normal((n_clips, n_frames * frame_len)) * 0.01).astype(np.float32)
+    x *= (rng.random((n_clips, n_frames)) < 0.5).repeat(frame_len, axis=1).astype(np.float32) * 30 + 0.05
+    got = af.VoiceActivityDetector.detect_batch(x, frame_len)
+    for c in range(0, n_clips, 6):
+        v = af.VoiceActivityDetector(af.VadConfig())
+        assert [int(s) for s in v.detect_frames(x[c], frame_len)] == got[c].tolist()
+
+
 # ---- level meter (specs/0002-design.md:727-732) ------------------------------------------------
 @pytest.mark.parametrize("window", [1, 64, 800, 2400])
 def test_level_meter_vs_oracle(af, po, window):
