@@ -61,7 +61,7 @@ class ChainConfig(C.Structure):
     _fields_ = [("input_rate", C.c_uint32), ("channels", C.c_uint32), ("output_rate", C.c_uint32),
                 ("fir_taps", C.c_void_p), ("n_fir_taps", C.c_size_t), ("hop", C.c_uint32),
                 ("n_mels", C.c_uint32), ("f_min", C.c_float), ("f_max", C.c_float),
-                ("device", C.c_int32)]
+                ("device", C.c_int32), ("sample_format", C.c_uint32)]
 
 
 class VadConfig(C.Structure):
@@ -184,6 +184,20 @@ SIGNATURES = {
     "af_chain_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp]),
     "af_chain_run_device": (_st, [_vp, _vp, _vp, _vp]),
     "af_chain_run": (_st, [_vp, _vp, _sz, _vp, _sz]),
+    "af_chain_set_batch": (_st, [_vp, _vp, _sz, _szp]),
+    "af_chain_set_option": (_st, [_vp, C.c_char_p, C.c_int]),
+    "af_features_set_option": (_st, [_vp, C.c_char_p, C.c_int]),
+    "af_chain_stream_create": (_st, [C.POINTER(ChainConfig), _sz, C.POINTER(_vp)]),
+    "af_chain_stream_destroy": (None, [_vp]),
+    "af_chain_stream_step_frames": (_sz, [_vp]),
+    "af_chain_stream_rows_per_step": (_sz, [_vp]),
+    "af_chain_stream_row_len": (_sz, [_vp]),
+    "af_chain_stream_total_rows": (_sz, [_vp, C.c_uint64]),
+    "af_chain_stream_max_rows": (_sz, [_vp, _sz]),
+    "af_chain_stream_push": (_st, [_vp, _vp, _sz, _vp, _sz, _szp]),
+    "af_chain_stream_flush": (_st, [_vp, _vp, _sz, _szp]),
+    "af_chain_stream_reset": (_st, [_vp]),
+    "af_chain_stream_stats": (_st, [_vp, _vp]),
     # RingBuffer (capture.rs:84-161)
     "af_ring_create": (_st, [_sz, C.POINTER(_vp)]),
     "af_ring_destroy": (None, [_vp]),

@@ -721,17 +721,16 @@ class MelFilterbank:
 
 
 class ChainPipeline:
-    """BASELINE config 4 chain [B]: to_mono -> resample -> FIR -> STFT -> mel on the device."""
+    """BASELINE config 4 chain [B]: to_mono -> resample -> FIR -> STFT -> mel on the device.
+    ``sample_format``: AF_PCM_F32 or the wire format's AF_PCM_I16 (websocket.rs:246-251)."""
 
     def __init__(self, input_rate: int = 48000, channels: int = 2, output_rate: int = 16000,
                  fir_taps=None, hop: int = 256, n_mels: int = 80, f_min: float = 0.0,
-                 f_max: float = 0.0, device: int = -1):
+                 f_max: float = 0.0, device: int = -1, sample_format: int = _ffi.AF_PCM_F32):
         self._lib = library()
         self._taps = _f32(fir_taps) if fir_taps is not None and len(fir_taps) else None
-        self.cfg = _ffi.ChainConfig(input_rate, channels, output_rate,
-                                    _ptr(self._taps) if self._taps is not None else None,
-                                    self._taps.size if self._taps is not None else 0,
-                                    hop, n_mels, f_min, f_max, device)
+        self.cfg = _chain_config(self._taps, input_rate, channels, output_rate, hop, n_mels, f_min, f_max, device,
+                                 sample_format)
         h = C.c_void_p()
         _check(self._lib.af_chain_create(C.byref(self.cfg), C.byref(h)))
         self._h = h
@@ -742,6 +741,9 @@ class ChainPipeline:
         if h:
             self._lib.af_chain_destroy(h)
 
+    def _dtype(self):
+        return np.int16 if self.cfg.sample_format == _ffi.AF_PCM_I16 else np.float32
+
     def n_frames(self, n_pcm_frames: int) -> int:
         return int(self._lib.af_chain_n_frames(self._h, n_pcm_frames))
 
@@ -750,6 +752,19 @@ class ChainPipeline:
         _check(self._lib.af_chain_set_batch_uniform(self._h, n_clips, frames_per_clip, C.byref(tot)))
         self.total_frames = tot.value
         return self.total_frames
+
+    def set_batch(self, clip_offsets) -> int:
+        """Ragged batch (AudioFrame is variable-length, capture.rs:13-28): clip i = PCM frames
+        [clip_offsets[i], clip_offsets[i + 1]) of the buffer."""
+        off = np.ascontiguousarray(clip_offsets, np.int64)
+        tot = C.c_size_t()
+        _check(self._lib.af_chain_set_batch(self._h, _ptr(off), off.size - 1, C.byref(tot)))
+        self.total_frames = tot.value
+        return self.total_frames
+
+    def set_option(self, key: str, value: int) -> None:
+        """Per-handle diagnostics: ``"unfused"`` 1 / 0 / -1 (follow af_debug_set)."""
+        _check(self._lib.af_chain_set_option(self._h, key.encode(), int(value)))
 
     def run_device(self, pcm_ptr: int, mel_ptr: int, stream: int = 0) -> None:
         _check(self._lib.af_chain_run_device(self._h, C.c_void_p(pcm_ptr), C.c_void_p(mel_ptr),
@@ -760,7 +775,66 @@ class ChainPipeline:
         return int(self._lib.af_chain_n_launches(self._h))
 
     def run(self, pcm) -> np.ndarray:
-        x = np.ascontiguousarray(pcm, np.float32).reshape(-1)
+        x = np.ascontiguousarray(pcm, self._dtype()).reshape(-1)
         mel = np.empty((self.total_frames, self.cfg.n_mels), np.float32)
         _check(self._lib.af_chain_run(self._h, _ptr(x), x.size, _ptr(mel), mel.size))
         return mel
+
+
+def _chain_config(taps, input_rate, channels, output_rate, hop, n_mels, f_min, f_max, device, sample_format):
+    return _ffi.ChainConfig(input_rate, channels, output_rate, _ptr(taps) if taps is not None else None,
+                            taps.size if taps is not None else 0, hop, n_mels, f_min, f_max, device, sample_format)
+
+
+class ChainStream:
+    """The whole chain over an unbounded stream (BASELINE config 5 on the full chain, ``af_chain_stream_*``):
+    ``push`` returns the rows of every step it completed (one hipGraph replay each: H2D, fused resampler + FIR,
+    STFT / mel, history move, D2H), ``flush`` the rows of the rest; all rows in order == ``ChainPipeline.run`` on
+    the whole stream, bit for bit.  Carry / flush analogue in the reference: resampler.rs:132-166."""
+
+    def __init__(self, step_frames: int = 1 << 20, input_rate: int = 48000, channels: int = 2,
+                 output_rate: int = 16000, fir_taps=None, hop: int = 256, n_mels: int = 80, f_min: float = 0.0,
+                 f_max: float = 0.0, device: int = -1, sample_format: int = _ffi.AF_PCM_F32):
+        self._lib = library()
+        self._taps = _f32(fir_taps) if fir_taps is not None and len(fir_taps) else None
+        self.cfg = _chain_config(self._taps, input_rate, channels, output_rate, hop, n_mels, f_min, f_max, device,
+                                 sample_format)
+        h = C.c_void_p()
+        _check(self._lib.af_chain_stream_create(C.byref(self.cfg), int(step_frames), C.byref(h)))
+        self._h = h
+        self.row_len = int(self._lib.af_chain_stream_row_len(h))
+        self.rows_per_step = int(self._lib.af_chain_stream_rows_per_step(h))
+        self.step_frames = int(self._lib.af_chain_stream_step_frames(h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_chain_stream_destroy(h)
+
+    def _dtype(self):
+        return np.int16 if self.cfg.sample_format == _ffi.AF_PCM_I16 else np.float32
+
+    def push(self, pcm) -> np.ndarray:
+        x = np.ascontiguousarray(pcm, self._dtype()).reshape(-1)
+        n_frames = x.size // self.cfg.channels
+        rows = np.empty((int(self._lib.af_chain_stream_max_rows(self._h, n_frames)), self.row_len), np.float32)
+        n = C.c_size_t()
+        _check(self._lib.af_chain_stream_push(self._h, _ptr(x), n_frames, _ptr(rows), rows.size, C.byref(n)))
+        return rows[:n.value]
+
+    def flush(self) -> np.ndarray:
+        rows = np.empty((self.rows_per_step, self.row_len), np.float32)
+        n = C.c_size_t()
+        _check(self._lib.af_chain_stream_flush(self._h, _ptr(rows), rows.size, C.byref(n)))
+        return rows[:n.value].copy()
+
+    def reset(self) -> None:
+        _check(self._lib.af_chain_stream_reset(self._h))
+
+    def total_rows(self, n_frames: int) -> int:
+        return int(self._lib.af_chain_stream_total_rows(self._h, int(n_frames)))
+
+    def stats(self) -> dict:
+        v = (C.c_double * 4)()
+        _check(self._lib.af_chain_stream_stats(self._h, v))
+        return {"device_ms": v[0], "wall_ms": v[1], "steps": int(v[2]), "rows": int(v[3])}

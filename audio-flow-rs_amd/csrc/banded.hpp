@@ -81,26 +81,55 @@ af_status launch_fir(const FirParts& p, const float* afrag_dev, const float* x_d
 
 // The resampler followed by a FIR (BASELINE config 4's middle stages) as ONE launch: the resampled
 // signal only exists in LDS.  Covered: ratios with a single block matrix (L divides 16: 48 k / 32 k ->
-// 16 k, 48 k -> 24 k ...), FIRs of at most 129 taps; everything else runs the two kernels above.
+// 16 k, 48 k -> 24 k ...), FIRs of at most 129 taps, mono / stereo, f32 / i16, uniform or ragged batches,
+// whole clips or a window of a stream; everything else runs the two kernels above.
+// Input formats of the fused launch (interleaved PCM; stereo is downmixed while it is staged, capture.rs:30-42).
+enum FusedFmt { kFmtMonoF32 = 0, kFmtStereoF32 = 1, kFmtStereoI16 = 2, kFmtMonoI16 = 3 };
+inline int fused_fmt(int channels, bool i16) { return channels == 2 ? (i16 ? kFmtStereoI16 : kFmtStereoF32) : (i16 ? kFmtMonoI16 : kFmtMonoF32); }
+inline int fused_bytes_per_frame(int fmt) { return fmt == kFmtMonoF32 ? 4 : fmt == kFmtStereoF32 ? 8 : fmt == kFmtStereoI16 ? 4 : 2; }
+
 struct FusedPlan {
     bool ok = false;
-    Plan a;                    // the resampler's plan (a.ch = 2: stereo input, downmixed while staged)
+    Plan a;                    // the resampler's plan
+    int fmt = kFmtMonoF32;     // how x is staged
     int K = 0;                 // FIR taps
     int NKB = 0;               // MFMA steps of the FIR chain (20 or 36)
     int H2 = 0, pad = 0;       // resampled samples recomputed per tile (multiple of 16), H2 - (K - 1)
     int P2 = 0;                // FIR block periods per column and tile
     int seg_len_b = 0, seg_stride_b = 0;
-    int shift = 0, seg_stride_a = 0;   // x segments in LDS (stereo: one frame early when the origin is odd)
+    int shift = 0, seg_stride_a = 0;   // x segments in LDS (pair formats: one frame early when the origin is odd)
     int64_t z_per_tile = 0;    // 256 * P2
     size_t smem = 0;
     size_t afrag_b_floats() const { return (size_t)NKB * 64; }
 };
-FusedPlan make_fused_plan(const Plan& resampler, int K);
+FusedPlan make_fused_plan(const Plan& resampler, int K, int fmt);
 af_status build_fused_fir_afrag(const FusedPlan& f, const float* taps_dev, float* afrag_dev, hipStream_t stream);
-// z[clip][n] = FIR(resample(x[clip]))[n], n < n_res = the resampler's output length for x_len frames
-af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* afrag_b, const float* x_dev,
-                       int64_t x_len, int64_t x_stride, float* z_dev, int64_t z_stride, int64_t n_res,
-                       int64_t n_clips, hipStream_t stream);
+
+// One tile of a ragged batch (32 bytes, one scalar load): which clip, which tile of it.
+struct FusedTile {
+    int64_t x_off;             // first frame of the clip, in frames from the batch's first frame
+    int64_t z_off;             // first FIR output of the clip, in floats from z
+    int32_t x_len;             // frames of the clip
+    int32_t n_res;             // resampled samples (= FIR outputs) of the clip
+    int32_t t;                 // tile of the clip (tiles are anchored at output 0)
+    int32_t pad;
+};
+struct FusedArgs {
+    const void* x = nullptr;   // device; uniform: clip i starts x_stride frames behind clip i - 1
+    float* z = nullptr;        // device; uniform: row i = outputs [m0, m0 + n_out) of clip i, z_stride floats apart
+    int64_t x_abs0 = 0;        // absolute stream index of x[0] (streaming; even in the pair formats); 0 for whole clips
+    int64_t x_len = 0, x_stride = 0, z_stride = 0;
+    int64_t n_res = 0;         // resampled samples that exist, [0, n_res): zeros before, nothing behind
+    int64_t m0 = 0, n_out = 0; // FIR outputs wanted per clip (absolute)
+    int64_t n_clips = 0;
+    const FusedTile* tiles = nullptr;   // device; ragged batch (then x_len .. n_clips above are ignored)
+    int64_t n_tiles = 0;
+};
+// z[clip][m - m0] = FIR(resample(to_mono(x[clip])))[m]
+af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* afrag_b, const FusedArgs& args,
+                       hipStream_t stream);
+// longest clip (frames) the fused kernel's 32-bit byte offsets reach
+bool fits(const FusedPlan& f, int64_t x_len);
 
 }  // namespace banded
 

@@ -257,17 +257,29 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 // mapping and chain order are those of the stand-alone kernels, so with the same NK the output is
 // theirs bit for bit.
 struct FusedGeom {
-    const float* x;                  // [clip][frame][CH]
-    float* z;                        // [clip][n_res]
+    const void* x;                   // [clip][frame][channels], f32 or i16 (FMT)
+    float* z;                        // [clip][n_out]: FIR outputs m0 .. m0 + n_out of every clip
     const float* afrag_a;            // resampler fragments [NKA][64]
     const float* afrag_b;            // FIR fragments [NKB][64]
-    int64_t x_len, x_stride, z_stride, n_res;
-    int64_t tiles_per_clip, n_tiles;
+    const FusedTile* tiles;          // ragged batch: one record per tile; null: uniform clips (arithmetic below)
+    int64_t x_abs0;                  // absolute stream index of x[0] of every clip (even in the pair formats)
+    int64_t x_len, x_stride, z_stride;
+    int64_t n_res;                   // resampled samples that exist: [0, n_res); the FIR sees zeros before 0
+    int64_t m0, n_out;               // FIR outputs wanted (absolute indices), tiles are anchored at output 0
+    int64_t tile0, tiles_per_clip, n_tiles;
     int lo_off;                      // resampler: c - (T - 1)
     int S, G, gpw, seg_len, seg_stride;
-    int shift;                       // CH = 2: frames in front of a segment so that (L, R) pairs load 16-byte aligned
+    int shift;                       // pair formats: frames in front of a segment so that frame pairs load aligned
     int H2, pad, P2, seg_len_b, seg_stride_b, ys_off;
     float inv_colz;                  // 1 / (16 P2)
+};
+
+// What a tile needs to know about its clip (wave-uniform: SGPRs).
+struct TileCtx {
+    const char* xp;                  // the clip's first byte
+    float* zp;                       // where FIR output 0 of the clip would be stored (z row - m0)
+    int64_t n_res, t_abs, m_lo, m_hi;
+    uint32_t x_bytes;
 };
 
 // One pair of MFMA chains over two block periods; `issue(t)` may put global loads between the steps.
@@ -295,9 +307,25 @@ __device__ __forceinline__ void chain2(const float (&a)[NK], const float* b0p, c
     }
 }
 
-template <int NKA, int NKB, int CH>
+// FMT: 0 = mono f32 (a thread stages samples tid and tid + 512 of every column segment, one dword load each);
+// pair formats (a thread stages the frame pair (2 tid, 2 tid + 1) of every segment with ONE load; the segment starts
+// `shift` frames early so that a pair never straddles the clip start and the buffer's range check only ever zeroes
+// whole pairs' dwords): 1 = stereo f32 (16 bytes: L0 R0 L1 R1), 2 = stereo i16 (8 bytes), 3 = mono i16 (4 bytes).
+// Stereo is downmixed on its way into LDS ((L + R) * 0.5, the to_mono of capture.rs:30-42), i16 samples are scaled
+// by 1 / 32768 first (docs/OPS.md "PCM formats": the arithmetic of the feature kernels' Stage<>).
+template <int FMT>
+struct FusedFmt {
+    static constexpr bool kPair = FMT != 0;
+    static constexpr int kBytesPerFrame = FMT == 0 ? 4 : FMT == 1 ? 8 : FMT == 2 ? 4 : 2;
+    static constexpr int kRegsPerCol = FMT == 0 ? kPfSlots : FMT == 1 ? 4 : FMT == 2 ? 2 : 1;
+};
+
+template <int NKA, int NKB, int FMT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void resfir_kernel(const FusedGeom g)
 {
+    using F = FusedFmt<FMT>;
+    constexpr bool PAIR = F::kPair;
+    constexpr int BPF = F::kBytesPerFrame;
     extern __shared__ __attribute__((aligned(16))) float xs[];
     float* ys = xs + g.ys_off;
     constexpr int FULLA = NKA / 16, TAILA = NKA % 16, FULLB = NKB / 16, TAILB = NKB % 16;
@@ -317,17 +345,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int z_lane = 16 * (col * g.P2 + wave * kGpw) + 4 * g4;    // tile-relative FIR output of acc0[0]
     const int colz = 16 * g.P2, z_per_tile = 16 * colz, y_per_tile = 256 * g.G;
     const int col_span = g.G * g.S;
-    // CH = 1: a thread stages samples tid and tid + 512 of every column segment, one dword load each.
-    // CH = 2: a thread stages the frame pair (2 tid, 2 tid + 1) of every segment with ONE 16-byte load
-    // (L0 R0 L1 R1); the segment starts `shift` frames early so that a pair never straddles the clip
-    // start (the buffer's range check then zeroes whole dwords only).
-    const bool first = CH == 2 ? 2 * tid < g.seg_len + g.shift : tid < g.seg_len;
-    const bool second = CH == 1 && tid + nthreads < g.seg_len;
+    const bool first = PAIR ? 2 * tid < g.seg_len + g.shift : tid < g.seg_len;
+    const bool second = !PAIR && tid + nthreads < g.seg_len;
     const uint32_t tpc = (uint32_t)g.tiles_per_clip, n_tiles = (uint32_t)g.n_tiles;
+
+    // The clip of a tile: arithmetic for uniform batches, one 32-byte record (scalar load) for ragged ones.
+    auto tile_ctx = [&](uint32_t tile) {
+        TileCtx c;
+        if (g.tiles) {
+            typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+            typedef const __attribute__((address_space(4))) u32x8* cptr;
+            const u32x8 r = reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(g.tiles))[__builtin_amdgcn_readfirstlane(tile)];
+            const int64_t x_off = (int64_t)(((unsigned long long)r[1] << 32) | r[0]);
+            const int64_t z_off = (int64_t)(((unsigned long long)r[3] << 32) | r[2]);
+            c.xp = static_cast<const char*>(g.x) + x_off * BPF;
+            c.zp = g.z + z_off;
+            c.x_bytes = r[4] * (uint32_t)BPF;
+            c.n_res = (int64_t)r[5];
+            c.t_abs = (int64_t)r[6];
+            c.m_lo = 0;
+            c.m_hi = c.n_res;
+        } else {
+            const uint32_t clip = tile / tpc;
+            c.xp = static_cast<const char*>(g.x) + (int64_t)clip * g.x_stride * BPF;
+            c.zp = g.z + (int64_t)clip * g.z_stride - g.m0;
+            c.x_bytes = (uint32_t)(g.x_len * BPF);
+            c.n_res = g.n_res;
+            c.t_abs = g.tile0 + (tile - clip * tpc);
+            c.m_lo = g.m0;
+            c.m_hi = g.m0 + g.n_out < g.n_res ? g.m0 + g.n_out : g.n_res;
+        }
+        return c;
+    };
 
     // Register plan (128 per lane, 4 waves per SIMD): a phase only holds its own fragments -- they are
     // fetched again (L2) per tile, the resampler's before the first barrier, the FIR's while the
-    // resampled samples go to LDS.  The next tile's x is requested in two halves: slot 0 (CH = 1: all
+    // resampled samples go to LDS.  The next tile's x is requested in two halves: slot 0 (mono f32: all
     // of it) in the first half of phase A, slot 1 step by step through phase B while the FIR fragments
     // are dying, so at most 32 staging registers are live next to a full set of fragments.
     float a1[NKA], a2[NKB];
@@ -341,21 +394,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
 
     constexpr uint32_t kOob = 0xFFF00000u;
-    constexpr int kLoads = CH == 2 ? kCols : kCols * kPfSlots;       // load instructions per thread and tile
-    constexpr int kLoadsA = CH == 2 ? kCols / 2 : kLoads;            // requested during phase A
-    constexpr int kRegs = CH == 2 ? kCols * 4 : kCols * kPfSlots;
+    constexpr int kLoads = PAIR ? kCols : kCols * kPfSlots;          // load instructions per thread and tile
+    constexpr int kLoadsA = FMT == 1 ? kCols / 2 : kLoads;           // requested during phase A
+    constexpr int kRegs = kCols * F::kRegsPerCol;
     float pf[kRegs];
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[kPfSlots];
     auto prep_tile = [&](uint32_t tile, bool live) {
-        const uint32_t clip = tile / tpc;
-        const int64_t t = tile - clip * tpc;
-        // x index of the first staged sample of the tile: q(y0) + lo_off - shift, y0 = t z_per_tile - H2
-        const int64_t base = (t * (int64_t)(16 * g.P2) - g.H2 / 16) * g.S + g.lo_off - g.shift;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride * CH), 0,
-                                                 (int)(uint32_t)(g.x_len * 4 * CH), 0x00020000);
-        if constexpr (CH == 2) {
-            const uint32_t v0 = ((uint32_t)base + 2u * (uint32_t)(tid + opaque_zero())) * 8u;
+        const TileCtx c = tile_ctx(tile);
+        // x index of the first staged sample of the tile: q(y0) + lo_off - shift, y0 = t z_per_tile - H2,
+        // relative to the buffer's first frame
+        const int64_t base = (c.t_abs * (int64_t)(16 * g.P2) - g.H2 / 16) * g.S + g.lo_off - g.shift - g.x_abs0;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.xp), 0, (int)c.x_bytes, 0x00020000);
+        if constexpr (PAIR) {
+            const uint32_t v0 = ((uint32_t)base + 2u * (uint32_t)(tid + opaque_zero())) * (uint32_t)BPF;
             voff[0] = live && first ? v0 : kOob;
         } else {
             const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * 4u;
@@ -364,16 +416,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     };
     auto issue_load = [&](int s) {
-        if constexpr (CH == 1) {                                    // s = h * 16 + cc
+        if constexpr (FMT == 0) {                                   // s = h * 16 + cc
             const int cc = s % kCols, h = s / kCols;
             pf[cc * kPfSlots + h] = __builtin_bit_cast(
                 float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
-        } else {                                                    // s = cc
+        } else if constexpr (FMT == 1) {                            // s = cc
             // (cast the whole vector: hipcc 7.2 reads element 0 for __builtin_bit_cast(float, v[i]))
             const f32x4 v = __builtin_bit_cast(
                 f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 8u), 0, 0));
 #pragma unroll
             for (int i = 0; i < 4; ++i) pf[s * 4 + i] = v[i];
+        } else if constexpr (FMT == 2) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 v = __builtin_bit_cast(
+                f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 4u), 0, 0));
+            pf[s * 2] = v[0];
+            pf[s * 2 + 1] = v[1];
+        } else {
+            pf[s] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 2u), 0, 0));
+        }
+    };
+    // the frame pair of column cc as two mono samples
+    auto staged_pair = [&](int cc, float& m0, float& m1) {
+        auto lo16 = [](float w) { return (float)(int16_t)(__float_as_uint(w) & 0xffffu) * (1.0f / 32768.0f); };
+        auto hi16 = [](float w) { return (float)(int16_t)(__float_as_uint(w) >> 16) * (1.0f / 32768.0f); };
+        if constexpr (FMT == 1) {
+            m0 = (pf[cc * 4] + pf[cc * 4 + 1]) * 0.5f;
+            m1 = (pf[cc * 4 + 2] + pf[cc * 4 + 3]) * 0.5f;
+        } else if constexpr (FMT == 2) {
+            m0 = (lo16(pf[cc * 2]) + hi16(pf[cc * 2])) * 0.5f;
+            m1 = (lo16(pf[cc * 2 + 1]) + hi16(pf[cc * 2 + 1])) * 0.5f;
+        } else {
+            m0 = lo16(pf[cc]);
+            m1 = hi16(pf[cc]);
         }
     };
 
@@ -387,13 +463,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // No barrier here: xs was last read in phase A and ys in phase B of the previous tile; a wave
         // writes xs before, and ys after, the next barrier, which every wave reaches after its phase B.
         {
-            if constexpr (CH == 2) {
+            if constexpr (PAIR) {
                 float* dst = xs + 2 * (tid + opaque_zero());
                 if (first) {
 #pragma unroll
-                    for (int cc = 0; cc < kCols; ++cc) {            // downmix: (L + R) * 0.5, exact
-                        dst[cc * g.seg_stride] = (pf[cc * 4] + pf[cc * 4 + 1]) * 0.5f;
-                        dst[cc * g.seg_stride + 1] = (pf[cc * 4 + 2] + pf[cc * 4 + 3]) * 0.5f;
+                    for (int cc = 0; cc < kCols; ++cc) {
+                        float m0, m1;
+                        staged_pair(cc, m0, m1);
+                        dst[cc * g.seg_stride] = m0;
+                        dst[cc * g.seg_stride + 1] = m1;
                     }
                 }
             } else {
@@ -410,20 +488,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         load_a1(opaque_zero());
         __syncthreads();
-        const uint32_t clip = tile / tpc;
-        const int64_t t_in_clip = tile - clip * tpc;
+        const TileCtx tc = tile_ctx(tile);
         {
             const bool live = tile + gridDim.x < n_tiles;
             prep_tile(live ? tile + gridDim.x : tile, live);
         }
 
         // ---- phase A: resampled samples [y0, y0 + 256 G) into the FIR's column segments ----
-        const int64_t z0 = t_in_clip * z_per_tile;                   // first FIR output of the tile
+        const int64_t z0 = tc.t_abs * z_per_tile;                    // first FIR output of the tile
         {
             const int64_t y0 = z0 - g.H2;
             // resampled samples outside [0, n_res) are the FIR's zero initial state / never used
             const int y_lo = y0 >= 0 ? 0 : (int)-y0;
-            const int64_t y_left = g.n_res - y0;
+            const int64_t y_left = tc.n_res - y0;
             const int y_hi = y_left > y_per_tile ? y_per_tile : (int)y_left;
             const float* b0p = xs + base_full_a;
             const float* t0p = xs + base_tail_a;
@@ -458,10 +535,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
         // ---- phase B: the FIR over the segments, P2 valid block periods per column ----
         {
-            float* zc = g.z + (int64_t)clip * g.z_stride + z0;
-            const int64_t z_left = g.n_res - z0;
-            const int z_hi = z_left > z_per_tile ? z_per_tile : (int)z_left;
-            const bool whole = z_hi == z_per_tile && ((reinterpret_cast<uintptr_t>(zc) >> 2) & 3) == 0;
+            float* zc = tc.zp + z0;
+            // outputs [z_lo, z_hi) of the tile are wanted (absolute m_lo <= z0 + o < m_hi)
+            const int64_t lo_left = tc.m_lo - z0, hi_left = tc.m_hi - z0;
+            const int z_lo = lo_left <= 0 ? 0 : lo_left > z_per_tile ? z_per_tile : (int)lo_left;
+            const int z_hi = hi_left <= 0 ? 0 : hi_left > z_per_tile ? z_per_tile : (int)hi_left;
+            const bool whole = z_lo == 0 && z_hi == z_per_tile && ((reinterpret_cast<uintptr_t>(zc) >> 2) & 3) == 0;
             const float* b0p = ys + base_full_b;
             const float* t0p = ys + base_tail_b;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -484,8 +563,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (pr0 < g.P2 && o0 + j < z_hi) zc[o0 + j] = acc0[j];
-                    if (pr0 + 1 < g.P2 && o1 + j < z_hi) zc[o1 + j] = acc1[j];
+                    if (pr0 < g.P2 && o0 + j >= z_lo && o0 + j < z_hi) zc[o0 + j] = acc0[j];
+                    if (pr0 + 1 < g.P2 && o1 + j >= z_lo && o1 + j < z_hi) zc[o1 + j] = acc1[j];
                 }
             }
         }
@@ -677,34 +756,47 @@ af_status launch_fir(const FirParts& p, const float* afrag_dev, const float* x_d
 // ---- fused resampler + FIR ------------------------------------------------------------------------
 namespace {
 
-template <int NKA, int NKB, int CH>
+template <int NKA, int NKB, int FMT>
 af_status launch_resfir(const FusedGeom& g, unsigned grid, size_t smem, hipStream_t s)
 {
     static LdsAttrFlags attr_set;
-    AF_HIP(allow_big_lds(resfir_kernel<NKA, NKB, CH>, 160 * 1024, attr_set));
-    hipLaunchKernelGGL((resfir_kernel<NKA, NKB, CH>), dim3(grid), dim3(512), smem, s, g);
+    AF_HIP(allow_big_lds(resfir_kernel<NKA, NKB, FMT>, 160 * 1024, attr_set));
+    hipLaunchKernelGGL((resfir_kernel<NKA, NKB, FMT>), dim3(grid), dim3(512), smem, s, g);
     AF_HIP(hipGetLastError());
     return AF_OK;
 }
 
-template <int NKA, int CH>
+template <int NKA, int FMT>
 af_status launch_resfir_b(int nkb, const FusedGeom& g, unsigned grid, size_t smem, hipStream_t s)
 {
     switch (nkb) {
-    case 20: return launch_resfir<NKA, 20, CH>(g, grid, smem, s);
-    case 36: return launch_resfir<NKA, 36, CH>(g, grid, smem, s);
+    case 20: return launch_resfir<NKA, 20, FMT>(g, grid, smem, s);
+    case 36: return launch_resfir<NKA, 36, FMT>(g, grid, smem, s);
     default: return fail(AF_ERR_UNSUPPORTED, "no fused kernel for a FIR of %d steps", nkb);
+    }
+}
+
+template <int NKA>
+af_status launch_resfir_f(int fmt, int nkb, const FusedGeom& g, unsigned grid, size_t smem, hipStream_t s)
+{
+    switch (fmt) {
+    case kFmtMonoF32: return launch_resfir_b<NKA, 0>(nkb, g, grid, smem, s);
+    case kFmtStereoF32: return launch_resfir_b<NKA, 1>(nkb, g, grid, smem, s);
+    case kFmtStereoI16: return launch_resfir_b<NKA, 2>(nkb, g, grid, smem, s);
+    case kFmtMonoI16: return launch_resfir_b<NKA, 3>(nkb, g, grid, smem, s);
+    default: return fail(AF_ERR_UNSUPPORTED, "fused kernel: unknown input format %d", fmt);
     }
 }
 
 }  // namespace
 
-FusedPlan make_fused_plan(const Plan& a, int K)
+FusedPlan make_fused_plan(const Plan& a, int K, int fmt)
 {
     FusedPlan f;
     f.a = a;
     f.K = K;
-    if (!a.ok || a.nb != 1 || a.nwaves != 8 || K < 1) return f;
+    f.fmt = fmt;
+    if (!a.ok || a.nb != 1 || a.nwaves != 8 || K < 1 || fmt < 0 || fmt > 3) return f;
     if (a.NK != 24 && a.NK != 28) return f;                    // the instances built below
     const int need = 16 * ((K + 15) / 64) + (((K + 15) % 64) + 3) / 4;
     f.NKB = need <= 20 ? 20 : need <= 36 ? 36 : 0;
@@ -719,9 +811,10 @@ FusedPlan make_fused_plan(const Plan& a, int K)
     // every window sample phase B reads is a resampled sample of this tile
     if (15 * 16 * f.P2 + f.pad + f.seg_len_b > 256 * a.G) return f;
     f.z_per_tile = (int64_t)256 * f.P2;
-    if (a.ch == 2) {
+    if (fmt != kFmtMonoF32) {
         if (a.S % 2) return f;                                 // frame pairs need an even tile origin
         f.shift = (a.c - (a.T - 1)) & 1;
+        if (a.seg_len + f.shift > 2 * 512) return f;           // a thread stages one pair per column
         f.seg_stride_a = ((a.seg_len + f.shift + 1) / 2 * 2) | 1;
     } else {
         f.seg_stride_a = a.seg_stride;
@@ -730,6 +823,11 @@ FusedPlan make_fused_plan(const Plan& a, int K)
     if (2 * f.smem > 160 * 1024) return f;                     // two workgroups per CU or not at all
     f.ok = true;
     return f;
+}
+
+bool fits(const FusedPlan& f, int64_t x_len)
+{
+    return f.ok && x_len * fused_bytes_per_frame(f.fmt) < (int64_t)kMaxClip * 4 && x_len < (1ll << 31);
 }
 
 af_status build_fused_fir_afrag(const FusedPlan& f, const float* taps_dev, float* afrag_dev, hipStream_t stream)
@@ -741,26 +839,38 @@ af_status build_fused_fir_afrag(const FusedPlan& f, const float* taps_dev, float
     return AF_OK;
 }
 
-af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* afrag_b, const float* x_dev,
-                       int64_t x_len, int64_t x_stride, float* z_dev, int64_t z_stride, int64_t n_res,
-                       int64_t n_clips, hipStream_t stream)
+af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* afrag_b, const FusedArgs& q,
+                       hipStream_t stream)
 {
-    if (n_res <= 0 || n_clips <= 0) return AF_OK;
     if (!f.ok) return fail(AF_ERR_UNSUPPORTED, "banded::launch_fused without a plan");
-    if (!fits(f.a, x_len))
-        return fail(AF_ERR_UNSUPPORTED, "clips of %lld frames are beyond the banded kernel's 32-bit offsets",
-                    (long long)x_len);
     FusedGeom g{};
-    g.x = x_dev;
-    g.z = z_dev;
+    g.x = q.x;
+    g.z = q.z;
     g.afrag_a = afrag_a;
     g.afrag_b = afrag_b;
-    g.x_len = x_len;
-    g.x_stride = x_stride;
-    g.z_stride = z_stride;
-    g.n_res = n_res;
-    g.tiles_per_clip = (n_res + f.z_per_tile - 1) / f.z_per_tile;
-    g.n_tiles = g.tiles_per_clip * n_clips;
+    if (q.tiles) {
+        if (q.n_tiles <= 0) return AF_OK;
+        g.tiles = q.tiles;
+        g.n_tiles = q.n_tiles;
+        g.tiles_per_clip = 1;
+    } else {
+        if (q.n_out <= 0 || q.n_clips <= 0) return AF_OK;
+        if (!fits(f, q.x_len))
+            return fail(AF_ERR_UNSUPPORTED, "clips of %lld frames are beyond the fused kernel's 32-bit offsets",
+                        (long long)q.x_len);
+        if (f.fmt != kFmtMonoF32 && (q.x_abs0 & 1))
+            return fail(AF_ERR_INVALID_ARG, "banded::launch_fused: x must start on an even frame in the pair formats");
+        g.x_abs0 = q.x_abs0;
+        g.x_len = q.x_len;
+        g.x_stride = q.x_stride;
+        g.z_stride = q.z_stride;
+        g.n_res = q.n_res;
+        g.m0 = q.m0;
+        g.n_out = q.n_out;
+        g.tile0 = q.m0 / f.z_per_tile;
+        g.tiles_per_clip = (q.m0 + q.n_out - 1) / f.z_per_tile - g.tile0 + 1;
+        g.n_tiles = g.tiles_per_clip * q.n_clips;
+    }
     if (g.n_tiles >= (1ll << 31)) return fail(AF_ERR_UNSUPPORTED, "banded::launch_fused: too many tiles");
     g.lo_off = f.a.c - (f.a.T - 1);
     g.S = f.a.S;
@@ -779,11 +889,8 @@ af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* af
     int64_t grid = g.n_tiles;
     const int64_t cap = 2 * (int64_t)device_cu_count(current_device());
     if (grid > cap) grid = cap;
-    if (f.a.NK == 24)
-        return f.a.ch == 2 ? launch_resfir_b<24, 2>(f.NKB, g, (unsigned)grid, f.smem, stream)
-                           : launch_resfir_b<24, 1>(f.NKB, g, (unsigned)grid, f.smem, stream);
-    return f.a.ch == 2 ? launch_resfir_b<28, 2>(f.NKB, g, (unsigned)grid, f.smem, stream)
-                       : launch_resfir_b<28, 1>(f.NKB, g, (unsigned)grid, f.smem, stream);
+    if (f.a.NK == 24) return launch_resfir_f<24>(f.fmt, f.NKB, g, (unsigned)grid, f.smem, stream);
+    return launch_resfir_f<28>(f.fmt, f.NKB, g, (unsigned)grid, f.smem, stream);
 }
 
 }  // namespace banded

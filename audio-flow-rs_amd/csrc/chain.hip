@@ -1,12 +1,23 @@
 // chain.hip -- the full feature chain of BASELINE config 4 as one handle:
-//   interleaved PCM -> to_mono [R capture.rs:30-42] -> polyphase resample [B]
+//   interleaved PCM (f32 | i16) -> to_mono [R capture.rs:30-42] -> polyphase resample [B]
 //   -> FIR [B] -> Hann STFT -> |X|^2 -> mel [B]
 // Two launches where the shapes allow it (banded::FusedPlan: downmix + resampler + FIR in one kernel,
 // the 16 kHz signal before the FIR only exists in LDS; then the fused STFT / mel kernel), otherwise
 // every stage is the corresponding device entry point of this library, enqueued back to back on the
 // caller's stream.  All intermediate buffers are allocated when the batch is described, so
 // af_chain_run_device() only launches kernels (it can be captured into a hipGraph and replayed per
-// streaming step).
+// streaming step).  Batches are equal-length clips (af_chain_set_batch_uniform) or ragged ones
+// (af_chain_set_batch: AudioFrame is variable-length, capture.rs:13-28); PCM is f32 or the wire
+// format's i16 (websocket.rs:246-251).
+//
+// af_chain_stream_* (BASELINE config 5 on the whole chain): one handle owns the input history the
+// resampler, the FIR (K - 1 samples) and the STFT (n_fft - hop samples) need, and replays ONE captured
+// hipGraph per step: H2D of the new frames, the fused resampler + FIR launch, the STFT / mel launch, the
+// history move, D2H of the rows.  Steps are whole tiles of both kernels, tiles are anchored at absolute
+// sample 0, so the rows equal one-shot af_chain_run on the whole stream bit for bit.  Reference analogue
+// of the carry / flush: BatchResampler, resampler.rs:132-166; intended pipeline: specs/0002-design.md:1102-1125.
+#include <chrono>
+#include <cstring>
 #include <new>
 #include <numeric>
 #include <vector>
@@ -18,13 +29,23 @@ using namespace af;
 
 struct af_chain {
     af_chain_config cfg{};
+    int fmt = banded::kFmtMonoF32;   // banded::FusedFmt of (channels, sample_format)
+    size_t bpf = 4;                  // bytes per PCM frame
     af_features* feat = nullptr;
     af_fir* fir = nullptr;           // taps + MFMA fragments, built once
     banded::FusedPlan fused;         // ok: resampler + FIR are one launch
     const float* afrag_res = nullptr;
     DevBuf d_afrag_fir;
-    DevBuf d_mono, d_res, d_fir, d_pcm, d_mel;
-    size_t n_clips = 0, n_in = 0, n_res = 0, total_frames = 0;
+    int opt_unfused = -1;            // af_chain_set_option("unfused"); -1: the process-wide af_debug_set switch
+    // the batch
+    bool ragged = false;
+    size_t n_clips = 0, n_in = 0, n_res = 0;         // uniform: frames per clip in / resampled
+    std::vector<int64_t> off, len, res_len, z_off;   // ragged: per clip (frames in, frames in, resampled, floats)
+    int64_t total_in = 0, total_z = 0;               // frames of PCM / floats of the 16 kHz buffers described
+    size_t total_frames = 0;
+    DevBuf d_tiles;                                  // ragged + fused: banded::FusedTile per tile
+    int64_t n_tiles = 0;
+    DevBuf d_f32, d_mono, d_res, d_fir, d_pcm, d_mel;
 };
 
 namespace {
@@ -33,8 +54,8 @@ namespace {
 af_status plan_fused(af_chain* c, const float* taps)
 {
     banded::Plan rp;
-    AF_TRY(resampler_fragments(c->cfg.input_rate, c->cfg.output_rate, (int)c->cfg.channels, &rp, &c->afrag_res));
-    c->fused = banded::make_fused_plan(rp, (int)c->cfg.n_fir_taps);
+    AF_TRY(resampler_fragments(c->cfg.input_rate, c->cfg.output_rate, 1, &rp, &c->afrag_res));
+    c->fused = banded::make_fused_plan(rp, (int)c->cfg.n_fir_taps, c->fmt);
     if (!c->fused.ok) return AF_OK;
     DevBuf d_taps;
     AF_TRY(d_taps.reserve(c->cfg.n_fir_taps * sizeof(float)));
@@ -43,6 +64,26 @@ af_status plan_fused(af_chain* c, const float* taps)
     AF_TRY(banded::build_fused_fir_afrag(c->fused, d_taps.as<float>(), c->d_afrag_fir.as<float>(), nullptr));
     AF_HIP(hipStreamSynchronize(nullptr));
     return AF_OK;
+}
+
+bool want_unfused(const af_chain* c)
+{
+    return c->opt_unfused >= 0 ? c->opt_unfused != 0 : debug_knob(kKnobChainUnfused) != 0;
+}
+
+// the wire format's i16 (websocket.rs:246-251) back to f32 for the stage-by-stage path: x / 32768, the scale of
+// the fused kernels' staging (docs/OPS.md "PCM formats")
+__global__ void pcm16_to_f32_kernel(const int16_t* __restrict__ in, float* __restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i] * (1.0f / 32768.0f);
+}
+
+bool fused_applies(const af_chain* c)
+{
+    if (!c->fused.ok || want_unfused(c)) return false;
+    if (!c->ragged) return banded::fits(c->fused, (int64_t)c->n_in);
+    return c->n_tiles > 0 || c->n_clips == 0;        // the tile table exists: every clip fits and is aligned
 }
 
 }  // namespace
@@ -62,6 +103,7 @@ void af_chain_default_config(af_chain_config* c)
     c->f_min = 0.0f;
     c->f_max = 0.0f;
     c->device = -1;
+    c->sample_format = AF_PCM_F32;
 }
 
 af_status af_chain_create(const af_chain_config* cfg, af_chain** out)
@@ -70,6 +112,8 @@ af_status af_chain_create(const af_chain_config* cfg, af_chain** out)
     *out = nullptr;
     AF_REQUIRE(cfg->input_rate > 0 && cfg->output_rate > 0, "sample rates must be positive");
     AF_REQUIRE(cfg->channels == 1 || cfg->channels == 2, "channels must be 1 or 2 (got %u)", cfg->channels);
+    AF_REQUIRE(cfg->sample_format == AF_PCM_F32 || cfg->sample_format == AF_PCM_I16,
+               "sample_format must be AF_PCM_F32 or AF_PCM_I16 (got %u)", cfg->sample_format);
     AF_REQUIRE(cfg->n_fir_taps == 0 || cfg->fir_taps, "fir_taps is null");
     AF_REQUIRE(cfg->n_fir_taps <= 1024, "FIR needs at most 1024 taps (got %zu)", cfg->n_fir_taps);
     AF_TRY(ensure_device(cfg->device));
@@ -77,6 +121,8 @@ af_status af_chain_create(const af_chain_config* cfg, af_chain** out)
     if (!c) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
     c->cfg = *cfg;
     c->cfg.fir_taps = nullptr;            // the taps are copied to the device below
+    c->fmt = banded::fused_fmt((int)cfg->channels, cfg->sample_format == AF_PCM_I16);
+    c->bpf = (size_t)banded::fused_bytes_per_frame(c->fmt);
     af_features_config fc;
     af_features_default_config(&fc);
     fc.sample_rate = cfg->output_rate;
@@ -104,6 +150,16 @@ void af_chain_destroy(af_chain* c)
     delete c;
 }
 
+af_status af_chain_set_option(af_chain* c, const char* key, int value)
+{
+    AF_REQUIRE(c && key, "af_chain_set_option: null argument");
+    if (std::strcmp(key, "unfused") == 0) {
+        c->opt_unfused = value < 0 ? -1 : value != 0;
+        return AF_OK;
+    }
+    return fail(AF_ERR_INVALID_ARG, "af_chain_set_option: unknown option '%s'", key);
+}
+
 size_t af_chain_n_frames(const af_chain* c, size_t n_pcm_frames)
 {
     if (!c) return 0;
@@ -115,12 +171,18 @@ af_status af_chain_set_batch_uniform(af_chain* c, size_t n_clips, size_t frames_
                                      size_t* total_frames_out)
 {
     AF_REQUIRE(c, "af_chain_set_batch_uniform: null handle");
+    c->ragged = false;
     c->n_clips = n_clips;
     c->n_in = frames_per_clip;
     c->n_res = af_resample_out_len(c->cfg.input_rate, c->cfg.output_rate, frames_per_clip);
-    if (c->cfg.channels == 2) AF_TRY(c->d_mono.reserve(n_clips * frames_per_clip * sizeof(float)));
-    if (c->cfg.input_rate != c->cfg.output_rate) AF_TRY(c->d_res.reserve(n_clips * c->n_res * sizeof(float)));
-    if (c->cfg.n_fir_taps) AF_TRY(c->d_fir.reserve(n_clips * c->n_res * sizeof(float)));
+    c->total_in = (int64_t)(n_clips * frames_per_clip);
+    c->total_z = (int64_t)(n_clips * c->n_res);
+    c->n_tiles = 0;
+    const bool resample = c->cfg.input_rate != c->cfg.output_rate;
+    if (c->cfg.sample_format == AF_PCM_I16) AF_TRY(c->d_f32.reserve((size_t)c->total_in * c->cfg.channels * sizeof(float)));
+    if (c->cfg.channels == 2) AF_TRY(c->d_mono.reserve((size_t)c->total_in * sizeof(float)));
+    if (resample) AF_TRY(c->d_res.reserve((size_t)c->total_z * sizeof(float)));
+    if (c->cfg.n_fir_taps) AF_TRY(c->d_fir.reserve((size_t)c->total_z * sizeof(float)));
     size_t total = 0;
     AF_TRY(af_features_set_batch_uniform(c->feat, n_clips, c->n_res, &total));
     c->total_frames = total;
@@ -128,38 +190,138 @@ af_status af_chain_set_batch_uniform(af_chain* c, size_t n_clips, size_t frames_
     return AF_OK;
 }
 
-af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev, void* stream)
+af_status af_chain_set_batch(af_chain* c, const int64_t* clip_offsets, size_t n_clips, size_t* total_frames_out)
+{
+    AF_REQUIRE(c, "af_chain_set_batch: null handle");
+    AF_REQUIRE(clip_offsets || n_clips == 0, "af_chain_set_batch: null offsets");
+    c->ragged = true;
+    c->n_clips = n_clips;
+    c->n_in = c->n_res = 0;
+    c->off.assign(n_clips, 0);
+    c->len.assign(n_clips, 0);
+    c->res_len.assign(n_clips, 0);
+    c->z_off.assign(n_clips, 0);
+    int64_t z = 0;
+    bool fused_ok = c->fused.ok;
+    for (size_t i = 0; i < n_clips; ++i) {
+        const int64_t b = clip_offsets[i], e = clip_offsets[i + 1];
+        AF_REQUIRE(b >= 0 && e >= b, "af_chain_set_batch: offsets must be monotone (clip %zu: %lld .. %lld)", i,
+                   (long long)b, (long long)e);
+        c->off[i] = b;
+        c->len[i] = e - b;
+        c->res_len[i] = (int64_t)af_resample_out_len(c->cfg.input_rate, c->cfg.output_rate, (size_t)(e - b));
+        c->z_off[i] = z;
+        z += (c->res_len[i] + 3) / 4 * 4;            // every clip's 16 kHz signal starts on a 16-byte boundary
+        // the fused launch: 32-bit offsets inside a clip; mono i16 frames are 2 bytes, its loads are dwords
+        if (!banded::fits(c->fused, e - b) || c->res_len[i] >= (1ll << 31)) fused_ok = false;
+        if (c->fmt == banded::kFmtMonoI16 && (b & 1)) fused_ok = false;
+    }
+    c->total_in = n_clips ? clip_offsets[n_clips] : 0;
+    c->total_z = z;
+    const bool resample = c->cfg.input_rate != c->cfg.output_rate;
+    if (c->cfg.sample_format == AF_PCM_I16) AF_TRY(c->d_f32.reserve((size_t)c->total_in * c->cfg.channels * sizeof(float)));
+    if (c->cfg.channels == 2) AF_TRY(c->d_mono.reserve((size_t)c->total_in * sizeof(float)));
+    if (resample) AF_TRY(c->d_res.reserve((size_t)(z ? z : 1) * sizeof(float)));
+    if (c->cfg.n_fir_taps) AF_TRY(c->d_fir.reserve((size_t)(z ? z : 1) * sizeof(float)));
+    // one record per tile of the fused launch
+    c->n_tiles = 0;
+    if (fused_ok && n_clips) {
+        std::vector<banded::FusedTile> tiles;
+        for (size_t i = 0; i < n_clips; ++i) {
+            const int64_t nt = (c->res_len[i] + c->fused.z_per_tile - 1) / c->fused.z_per_tile;
+            for (int64_t t = 0; t < nt; ++t)
+                tiles.push_back(banded::FusedTile{c->off[i], c->z_off[i], (int32_t)c->len[i], (int32_t)c->res_len[i],
+                                                  (int32_t)t, 0});
+        }
+        if (tiles.size() >= ((size_t)1 << 31)) return fail(AF_ERR_UNSUPPORTED, "af_chain_set_batch: too many tiles");
+        if (!tiles.empty()) {
+            AF_TRY(c->d_tiles.reserve(tiles.size() * sizeof(banded::FusedTile)));
+            AF_HIP(hipMemcpy(c->d_tiles.p, tiles.data(), tiles.size() * sizeof(banded::FusedTile), hipMemcpyHostToDevice));
+        }
+        c->n_tiles = (int64_t)tiles.size();
+        if (tiles.empty()) c->n_tiles = 0;
+    }
+    size_t total = 0;
+    AF_TRY(af_features_set_batch_spans(c->feat, c->z_off.data(), c->res_len.data(), n_clips, &total));
+    c->total_frames = total;
+    if (total_frames_out) *total_frames_out = total;
+    return AF_OK;
+}
+
+af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, void* stream)
 {
     AF_REQUIRE(c, "af_chain_run_device: null handle");
-    if (c->n_clips == 0 || c->n_in == 0) return AF_OK;
+    if (c->n_clips == 0 || c->total_in == 0) return AF_OK;
     AF_REQUIRE(pcm_dev && (mel_dev || c->total_frames == 0), "af_chain_run_device: null buffer");
-    const float* cur = pcm_dev;
     const bool resample = c->cfg.input_rate != c->cfg.output_rate;
-    if (c->fused.ok && !debug_knob(kKnobChainUnfused) && banded::fits(c->fused.a, (int64_t)c->n_in)) {
-        AF_TRY(banded::launch_fused(c->fused, c->afrag_res, c->d_afrag_fir.as<float>(), cur, (int64_t)c->n_in,
-                                    (int64_t)c->n_in, c->d_fir.as<float>(), (int64_t)c->n_res, (int64_t)c->n_res,
-                                    (int64_t)c->n_clips, as_stream(stream)));
+    const bool i16 = c->cfg.sample_format == AF_PCM_I16;
+    if (fused_applies(c)) {
+        banded::FusedArgs q;
+        q.x = pcm_dev;
+        q.z = c->d_fir.as<float>();
+        if (c->ragged) {
+            q.tiles = c->d_tiles.as<banded::FusedTile>();
+            q.n_tiles = c->n_tiles;
+        } else {
+            q.x_len = q.x_stride = (int64_t)c->n_in;
+            q.z_stride = q.n_res = q.n_out = (int64_t)c->n_res;
+            q.n_clips = (int64_t)c->n_clips;
+        }
+        AF_TRY(banded::launch_fused(c->fused, c->afrag_res, c->d_afrag_fir.as<float>(), q, as_stream(stream)));
         return af_features_run_device(c->feat, c->d_fir.as<float>(), mel_dev, stream);
     }
-    if (c->cfg.channels == 2 && resample &&
-        af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate)) {
+    // ---- stage by stage ----
+    const float* cur = static_cast<const float*>(pcm_dev);
+    if (i16) {
+        const size_t n = (size_t)c->total_in * c->cfg.channels;
+        const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(pcm16_to_f32_kernel, dim3(grid), dim3(256), 0, as_stream(stream),
+                           static_cast<const int16_t*>(pcm_dev), c->d_f32.as<float>(), n);
+        AF_HIP(hipGetLastError());
+        cur = c->d_f32.as<float>();
+    }
+    if (!c->ragged && c->cfg.channels == 2 && resample &&
+        af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate) &&
+        2 * (int64_t)c->n_in < ((1ll << 30) - (1ll << 20))) {
         // downmix fused into the resampler's loads: the mono signal never reaches HBM
         AF_TRY(af_resample_batch_stereo_device(c->cfg.input_rate, c->cfg.output_rate, cur, c->n_clips,
                                                c->n_in, c->d_res.as<float>(), stream));
         cur = c->d_res.as<float>();
     } else {
-    if (c->cfg.channels == 2) {
-        AF_TRY(af_to_mono_device(cur, c->n_clips * c->n_in * 2, 2, c->d_mono.as<float>(), stream));
-        cur = c->d_mono.as<float>();
-    }
-    if (resample) {
-        AF_TRY(af_resample_batch_device(c->cfg.input_rate, c->cfg.output_rate, cur, c->n_clips, c->n_in,
-                                        c->d_res.as<float>(), stream));
-        cur = c->d_res.as<float>();
-    }
+        if (c->cfg.channels == 2) {
+            // (frames are consecutive across clip boundaries: one launch for the whole buffer)
+            AF_TRY(af_to_mono_device(cur, (size_t)c->total_in * 2, 2, c->d_mono.as<float>(), stream));
+            cur = c->d_mono.as<float>();
+        }
+        if (resample) {
+            if (!c->ragged) {
+                AF_TRY(af_resample_batch_device(c->cfg.input_rate, c->cfg.output_rate, cur, c->n_clips, c->n_in,
+                                                c->d_res.as<float>(), stream));
+            } else {
+                for (size_t i = 0; i < c->n_clips; ++i)   // clip by clip: the stand-alone kernels take uniform batches
+                    AF_TRY(af_resample_batch_device(c->cfg.input_rate, c->cfg.output_rate, cur + c->off[i], 1,
+                                                    (size_t)c->len[i], c->d_res.as<float>() + c->z_off[i], stream));
+            }
+            cur = c->d_res.as<float>();
+        }
     }
     if (c->cfg.n_fir_taps) {
-        AF_TRY(af_fir_apply_batch_device(c->fir, cur, c->n_clips, c->n_res, c->d_fir.as<float>(), stream));
+        if (!c->ragged) {
+            AF_TRY(af_fir_apply_batch_device(c->fir, cur, c->n_clips, c->n_res, c->d_fir.as<float>(), stream));
+        } else {
+            // without a resampler the clips sit at their PCM offsets, with one at their 16 kHz offsets
+            for (size_t i = 0; i < c->n_clips; ++i)
+                AF_TRY(af_fir_apply_batch_device(c->fir, cur + (resample ? c->z_off[i] : c->off[i]), 1,
+                                                 (size_t)c->res_len[i], c->d_fir.as<float>() + c->z_off[i], stream));
+        }
+        cur = c->d_fir.as<float>();
+    } else if (c->ragged && !resample) {
+        // neither resampler nor FIR: the feature spans were laid out at the padded offsets -- copy clip by clip
+        // (rare configuration; the feature handle alone serves it better)
+        AF_TRY(c->d_fir.reserve((size_t)(c->total_z ? c->total_z : 1) * sizeof(float)));
+        for (size_t i = 0; i < c->n_clips; ++i)
+            AF_HIP(hipMemcpyAsync(c->d_fir.as<float>() + c->z_off[i], cur + c->off[i], (size_t)c->len[i] * sizeof(float),
+                                  hipMemcpyDeviceToDevice, as_stream(stream)));
         cur = c->d_fir.as<float>();
     }
     return af_features_run_device(c->feat, cur, mel_dev, stream);
@@ -169,15 +331,17 @@ int af_chain_n_launches(const af_chain* c)
 {
     if (!c) return 0;
     const bool resample = c->cfg.input_rate != c->cfg.output_rate;
-    if (c->fused.ok && !debug_knob(kKnobChainUnfused) && banded::fits(c->fused.a, (int64_t)c->n_in)) return 2;
+    if (fused_applies(c)) return 2;
+    const int per_clip = c->ragged ? (int)c->n_clips : 1;
     int n = 1;                                                  // the STFT / mel kernel
+    if (c->cfg.sample_format == AF_PCM_I16) n += 1;             // i16 -> f32
     if (c->cfg.n_fir_taps) {
         const banded::FirParts fp = banded::make_fir_parts((int)c->cfg.n_fir_taps);
-        n += fp.ok() ? fp.n : 1;
+        n += (fp.ok() ? fp.n : 1) * per_clip;
     }
-    if (resample) n += 1;
+    if (resample) n += per_clip;
     if (c->cfg.channels == 2 &&
-        !(resample && af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate)))
+        !(!c->ragged && resample && af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate)))
         n += 1;                                                 // stand-alone to_mono
     return n;
 }
@@ -190,8 +354,8 @@ int af_chain_fused_plan_describe(uint32_t input_rate, uint32_t output_rate, uint
     if (input_rate == output_rate || n_fir_taps == 0 || n_fir_taps > 1024) return 0;
     const uint32_t g = std::gcd(input_rate, output_rate);
     const banded::Plan rp = banded::make_plan(output_rate / g, input_rate / g, banded::kResamplerTaps,
-                                              banded::kResamplerTaps / 2, (int)channels);
-    const banded::FusedPlan f = banded::make_fused_plan(rp, (int)n_fir_taps);
+                                              banded::kResamplerTaps / 2, 1);
+    const banded::FusedPlan f = banded::make_fused_plan(rp, (int)n_fir_taps, banded::fused_fmt((int)channels, false));
     const int32_t v[10] = {f.ok ? 1 : 0, f.a.NK, f.NKB, f.H2, f.pad, f.P2, f.seg_len_b, f.seg_stride_b,
                            (int32_t)f.z_per_tile, (int32_t)f.smem};
     if (f.ok)
@@ -199,23 +363,380 @@ int af_chain_fused_plan_describe(uint32_t input_rate, uint32_t output_rate, uint
     return f.ok ? 1 : 0;
 }
 
-af_status af_chain_run(af_chain* c, const float* pcm, size_t pcm_len, float* mel, size_t mel_cap)
+af_status af_chain_run(af_chain* c, const void* pcm, size_t pcm_len, float* mel, size_t mel_cap)
 {
     AF_REQUIRE(c, "af_chain_run: null handle");
-    if (pcm_len < c->n_clips * c->n_in * c->cfg.channels)
-        return fail(AF_ERR_BUFFER_TOO_SMALL, "pcm buffer holds %zu samples, the batch describes %zu", pcm_len,
-                    c->n_clips * c->n_in * c->cfg.channels);
+    const size_t need = (size_t)c->total_in * c->cfg.channels;
+    if (pcm_len < need)
+        return fail(AF_ERR_BUFFER_TOO_SMALL, "pcm buffer holds %zu samples, the batch describes %zu", pcm_len, need);
     const size_t n_out = c->total_frames * c->cfg.n_mels;
     if (mel_cap < n_out) return fail(AF_ERR_BUFFER_TOO_SMALL, "mel buffer holds %zu floats, need %zu", mel_cap, n_out);
-    if (c->n_clips == 0 || c->n_in == 0) return AF_OK;
+    if (c->n_clips == 0 || c->total_in == 0) return AF_OK;
     AF_REQUIRE(pcm && (mel || n_out == 0), "af_chain_run: null buffer");
-    const size_t in_bytes = c->n_clips * c->n_in * c->cfg.channels * sizeof(float);
+    const size_t in_bytes = (size_t)c->total_in * c->bpf;
     AF_TRY(c->d_pcm.reserve(in_bytes));
     AF_TRY(c->d_mel.reserve((n_out ? n_out : 1) * sizeof(float)));
     AF_HIP(hipMemcpy(c->d_pcm.p, pcm, in_bytes, hipMemcpyHostToDevice));
-    AF_TRY(af_chain_run_device(c, c->d_pcm.as<float>(), c->d_mel.as<float>(), nullptr));
+    AF_TRY(af_chain_run_device(c, c->d_pcm.p, c->d_mel.as<float>(), nullptr));
     if (n_out) AF_HIP(hipMemcpy(mel, c->d_mel.p, n_out * sizeof(float), hipMemcpyDeviceToHost));
     else AF_HIP(hipDeviceSynchronize());
+    return AF_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// af_chain_stream_*
+//
+// Notation (nb = 1 resamplers only: q(16 b) = b S): resampled sample m reads x[q(m) + lo_off .. q(m) + c], FIR
+// output n reads resampled samples (n - K, n], STFT frame f reads FIR outputs [f hop, f hop + n_fft).  A step is
+// Cz FIR outputs, a multiple of the fused launch's tile (z_per_tile) and of the feature kernel's unit (16 hop): step
+// k emits the Cz / hop frames that start in [k Cz, (k + 1) Cz) and needs FIR outputs [k Cz, (k + 1) Cz + n_fft - hop).
+// The tiles that cover them stage x from base(t0) = (t0 16 P2 - H2 / 16) S + lo_off - shift on, t0 = k Cz / z_per_tile:
+// the device buffer holds x[base(t0_k), Xneed_k), Xneed_k = q((k + 1) Cz + n_fft - hop - 1) + c + 1, and every step
+// moves both ends by Cx = Cz M / L frames: the last Lx - Cx frames are carried to the front, Cx new ones follow.
+// Step 0 is run eagerly with the stream's true origin (zeros in front of sample 0: the clip edge of one-shot
+// processing); every later step looks the same relative to its first tile, so it is launched with FIXED arguments
+// ("the stream starts one tile before this step") and captured once.
+struct af_chain_stream {
+    af_chain* chain = nullptr;        // plans, fragments (its feature handle serves the replayed step)
+    af_features* tail = nullptr;      // the final, shorter span (flush)
+    int64_t Cz = 0, Cx = 0, H = 0;    // FIR outputs / input frames per step; n_fft - hop
+    int64_t need0 = 0;                // input frames step 0 needs: Xneed_0
+    int64_t base1 = 0;                // base(1): x index of the first staged sample of tile 1 (even)
+    int64_t carry = 0;                // frames carried between steps: need0 - base(t0_1)
+    int64_t Lx = 0;                   // frames of a steady step's buffer: carry + Cx
+    int64_t z_cap = 0;                // floats of d_z
+    size_t bpf = 0, rows_per_step = 0, row_len = 0;
+    void* h_in = nullptr;             // page-locked: max(need0, Cx) frames
+    float* h_out = nullptr;           // page-locked: rows of one step
+    DevBuf d_x, d_z, d_rows;
+    int64_t fill = 0;                 // frames waiting in h_in
+    uint64_t steps = 0, frames_in = 0, rows_out = 0;
+    hipStream_t stream = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_device_ms = 0.0f, last_wall_ms = 0.0f;
+    bool flushed = false;
+};
+
+namespace {
+
+constexpr int64_t kEndless = (int64_t)1 << 60;
+
+int64_t q_of(const af_chain* c, int64_t m) { return m * (int64_t)c->fused.a.M / (int64_t)c->fused.a.L; }
+
+int64_t tile_base(const af_chain* c, int64_t t)
+{
+    const banded::FusedPlan& f = c->fused;
+    return (t * 16 * f.P2 - f.H2 / 16) * f.a.S + (f.a.c - (f.a.T - 1)) - f.shift;
+}
+
+void cs_free(af_chain_stream* s)
+{
+    if (!s) return;
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->h_in) (void)hipHostFree(s->h_in);
+    if (s->h_out) (void)hipHostFree(s->h_out);
+    af_features_destroy(s->tail);
+    af_chain_destroy(s->chain);
+    delete s;
+}
+
+// kernels of one step on s->stream: FIR outputs [m0, m0 + n_out) of the stream whose frame x_abs0 is d_x[0], then
+// the spectrogram rows of `feat`'s span over them
+af_status cs_kernels(af_chain_stream* s, af_features* feat, int64_t x_abs0, int64_t x_len, int64_t n_res, int64_t m0,
+                     int64_t n_out)
+{
+    af_chain* c = s->chain;
+    banded::FusedArgs q;
+    q.x = s->d_x.p;
+    q.z = s->d_z.as<float>();
+    q.x_abs0 = x_abs0;
+    q.x_len = q.x_stride = x_len;
+    q.z_stride = n_out;
+    q.n_res = n_res;
+    q.m0 = m0;
+    q.n_out = n_out;
+    q.n_clips = 1;
+    AF_TRY(banded::launch_fused(c->fused, c->afrag_res, c->d_afrag_fir.as<float>(), q, s->stream));
+    return af_features_run_device(feat, s->d_z.as<float>(), s->d_rows.as<float>(), s->stream);
+}
+
+// the replayed step: new frames in, both kernels with the fixed "one tile in" arguments, history move, rows out
+af_status cs_enqueue_step(af_chain_stream* s)
+{
+    char* x = s->d_x.as<char>();
+    AF_HIP(hipMemcpyAsync(x + s->carry * s->bpf, s->h_in, (size_t)s->Cx * s->bpf, hipMemcpyHostToDevice, s->stream));
+    AF_TRY(cs_kernels(s, s->chain->feat, s->base1, s->Lx, kEndless, s->chain->fused.z_per_tile, s->Cz + s->H));
+    // the last `carry` frames are the next step's history (carry <= Cx: the regions do not overlap)
+    AF_HIP(hipMemcpyAsync(x, x + (size_t)s->Cx * s->bpf, (size_t)s->carry * s->bpf, hipMemcpyDeviceToDevice, s->stream));
+    AF_HIP(hipMemcpyAsync(s->h_out, s->d_rows.p, s->rows_per_step * s->row_len * sizeof(float), hipMemcpyDeviceToHost,
+                          s->stream));
+    return AF_OK;
+}
+
+af_status cs_timed(af_chain_stream* s, bool replay)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    AF_HIP(hipEventRecord(s->ev0, s->stream));
+    if (replay) AF_HIP(hipGraphLaunch(s->exec, s->stream));
+    else AF_TRY(cs_enqueue_step(s));
+    AF_HIP(hipEventRecord(s->ev1, s->stream));
+    AF_HIP(hipStreamSynchronize(s->stream));
+    AF_HIP(hipEventElapsedTime(&s->last_device_ms, s->ev0, s->ev1));
+    s->last_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return AF_OK;
+}
+
+// step 0: the stream's first need0 frames, true origin
+af_status cs_first_step(af_chain_stream* s)
+{
+    char* x = s->d_x.as<char>();
+    AF_HIP(hipMemcpyAsync(x, s->h_in, (size_t)s->need0 * s->bpf, hipMemcpyHostToDevice, s->stream));
+    AF_TRY(cs_kernels(s, s->chain->feat, 0, s->need0, kEndless, 0, s->Cz + s->H));
+    // history of step 1: frames [base(t0_1), need0) to the front
+    const int64_t from = s->need0 - s->carry;
+    AF_HIP(hipMemcpyAsync(s->d_z.p, x + (size_t)from * s->bpf, (size_t)s->carry * s->bpf, hipMemcpyDeviceToDevice,
+                          s->stream));       // (through d_z's head: source and destination may overlap in d_x)
+    AF_HIP(hipMemcpyAsync(s->h_out, s->d_rows.p, s->rows_per_step * s->row_len * sizeof(float), hipMemcpyDeviceToHost,
+                          s->stream));
+    AF_HIP(hipMemcpyAsync(x, s->d_z.p, (size_t)s->carry * s->bpf, hipMemcpyDeviceToDevice, s->stream));
+    AF_HIP(hipStreamSynchronize(s->stream));
+    return AF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+af_status af_chain_stream_create(const af_chain_config* cfg, size_t step_frames, af_chain_stream** out)
+{
+    AF_REQUIRE(cfg && out, "af_chain_stream_create: null argument");
+    *out = nullptr;
+    af_chain_stream* s = new (std::nothrow) af_chain_stream();
+    if (!s) return fail(AF_ERR_OUT_OF_MEMORY, "out of host memory");
+    af_status st = af_chain_create(cfg, &s->chain);
+    if (st != AF_OK) { cs_free(s); return st; }
+    af_chain* c = s->chain;
+    const banded::FusedPlan& f = c->fused;
+    if (!f.ok) {
+        cs_free(s);
+        return fail(AF_ERR_UNSUPPORTED,
+                    "af_chain_stream: %u -> %u Hz with %zu FIR taps has no fused resampler + FIR launch (needs a ratio "
+                    "with one block matrix, e.g. 48 / 32 k -> 16 k, and 1..129 taps); stream the stages with "
+                    "af_resampler_*, af_fir_* and af_stream_* instead", cfg->input_rate, cfg->output_rate, cfg->n_fir_taps);
+    }
+    const int64_t hop = cfg->hop, n_fft = 1024;
+    s->H = n_fft - hop;
+    // a step = whole tiles of both kernels and a whole number of input frames
+    int64_t quantum = std::lcm<int64_t>(f.z_per_tile, 16 * hop);
+    quantum = std::lcm<int64_t>(quantum, (int64_t)f.a.L);
+    const int64_t qx = quantum * f.a.M / f.a.L;                     // input frames per quantum
+    int64_t nq = ((int64_t)step_frames + qx / 2) / qx;
+    if (nq < 1) nq = 1;
+    s->Cz = nq * quantum;
+    s->Cx = nq * qx;
+    s->bpf = c->bpf;
+    s->need0 = q_of(c, s->Cz + s->H - 1) + f.a.c + 1;
+    s->base1 = tile_base(c, 1);
+    const int64_t t01 = s->Cz / f.z_per_tile;
+    s->carry = s->need0 - tile_base(c, t01);
+    s->Lx = s->carry + s->Cx;
+    if (s->base1 < 0 || (c->fmt != banded::kFmtMonoF32 && (s->base1 & 1)) || s->carry <= 0 || s->carry > s->Cx || tile_base(c, t01) < 0) {
+        cs_free(s);
+        return fail(AF_ERR_UNSUPPORTED, "af_chain_stream: step geometry not covered (base %lld, carry %lld, step %lld)",
+                    (long long)s->base1, (long long)s->carry, (long long)s->Cx);
+    }
+    af_features_config fc;
+    af_features_default_config(&fc);
+    fc.sample_rate = cfg->output_rate;
+    fc.channels = 1;
+    fc.hop = cfg->hop;
+    fc.n_mels = cfg->n_mels;
+    fc.f_min = cfg->f_min;
+    fc.f_max = cfg->f_max;
+    fc.device = -1;
+    st = af_features_create(&fc, &s->tail);
+    size_t rows = 0;
+    const int64_t start = 0, len = s->Cz + s->H;
+    if (st == AF_OK) st = af_features_set_batch_spans(c->feat, &start, &len, 1, &rows);
+    if (st != AF_OK) { cs_free(s); return st; }
+    s->rows_per_step = rows;                                        // Cz / hop
+    s->row_len = af_features_row_len(c->feat);
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        st = fail(e == hipErrorOutOfMemory ? AF_ERR_OUT_OF_MEMORY : AF_ERR_HIP, "%s failed: %s", what,
+                  hipGetErrorString(e));
+        return false;
+    };
+    const int64_t in_cap = std::max(s->need0, s->Cx);
+    if (!hip_ok(hipHostMalloc(&s->h_in, (size_t)in_cap * s->bpf, hipHostMallocDefault), "hipHostMalloc") ||
+        !hip_ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_out), rows * s->row_len * sizeof(float),
+                              hipHostMallocDefault), "hipHostMalloc") ||
+        !hip_ok(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hip_ok(hipEventCreate(&s->ev0), "hipEventCreate") || !hip_ok(hipEventCreate(&s->ev1), "hipEventCreate")) {
+        cs_free(s);
+        return st;
+    }
+    const int64_t x_cap = std::max(s->need0, s->Lx);
+    st = s->d_x.reserve((size_t)x_cap * s->bpf);
+    // FIR outputs of a step, or of the flush (a little longer: what the resampler makes of the frames short of a
+    // step); never grown later -- the captured graph holds this pointer
+    s->z_cap = s->Cz + s->H + 64 + 64 * (int64_t)f.a.L / (int64_t)f.a.M;
+    if (st == AF_OK) st = s->d_z.reserve((size_t)std::max<int64_t>(s->z_cap * 4, s->carry * (int64_t)s->bpf));
+    if (st == AF_OK) st = s->d_rows.reserve(rows * s->row_len * sizeof(float));
+    // one eager steady step on zeros (sets the kernels' LDS attributes, which a capture cannot do), then the
+    // capture of the very same enqueue
+    if (st == AF_OK && hip_ok(hipMemsetAsync(s->d_x.p, 0, (size_t)x_cap * s->bpf, s->stream), "hipMemsetAsync")) {
+        std::memset(s->h_in, 0, (size_t)in_cap * s->bpf);
+        st = cs_enqueue_step(s);
+        if (st == AF_OK) hip_ok(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+    }
+    if (st == AF_OK && hip_ok(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture")) {
+        const af_status se = cs_enqueue_step(s);
+        hipGraph_t g = nullptr;
+        const hipError_t ee = hipStreamEndCapture(s->stream, &g);
+        s->graph = g;
+        if (se != AF_OK) st = se;
+        else if (hip_ok(ee, "hipStreamEndCapture"))
+            hip_ok(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+    }
+    if (st != AF_OK) { cs_free(s); return st; }
+    *out = s;
+    return AF_OK;
+}
+
+void af_chain_stream_destroy(af_chain_stream* s) { cs_free(s); }
+
+size_t af_chain_stream_step_frames(const af_chain_stream* s) { return s ? (size_t)s->Cx : 0; }
+size_t af_chain_stream_rows_per_step(const af_chain_stream* s) { return s ? s->rows_per_step : 0; }
+size_t af_chain_stream_row_len(const af_chain_stream* s) { return s ? s->row_len : 0; }
+
+/* rows the stream will have produced in total once n_frames have been pushed and flushed (= af_chain_n_frames) */
+size_t af_chain_stream_total_rows(const af_chain_stream* s, uint64_t n_frames)
+{
+    return s ? af_chain_n_frames(s->chain, (size_t)n_frames) : 0;
+}
+
+/* upper bound of the rows one af_chain_stream_push of n_frames can return */
+size_t af_chain_stream_max_rows(const af_chain_stream* s, size_t n_frames)
+{
+    if (!s) return 0;
+    int64_t pending = s->fill + (int64_t)n_frames;
+    size_t steps = 0;
+    if (s->steps == 0) {
+        if (pending < s->need0) return 0;
+        pending -= s->need0;
+        steps = 1;
+    }
+    steps += (size_t)(pending / s->Cx);
+    return steps * s->rows_per_step;
+}
+
+af_status af_chain_stream_push(af_chain_stream* s, const void* pcm, size_t n_frames, float* rows_out, size_t rows_cap,
+                               size_t* n_rows)
+{
+    AF_REQUIRE(s && n_rows, "af_chain_stream_push: null argument");
+    *n_rows = 0;
+    AF_REQUIRE(!s->flushed, "af_chain_stream_push after af_chain_stream_flush (af_chain_stream_reset starts a new stream)");
+    AF_REQUIRE(pcm || n_frames == 0, "af_chain_stream_push: null buffer");
+    const size_t will = af_chain_stream_max_rows(s, n_frames);
+    if (rows_cap < will * s->row_len)
+        return fail(AF_ERR_BUFFER_TOO_SMALL, "row buffer holds %zu floats, this push can produce %zu", rows_cap,
+                    will * s->row_len);
+    AF_REQUIRE(rows_out || will == 0, "af_chain_stream_push: null row buffer");
+    const char* src = static_cast<const char*>(pcm);
+    int64_t left = (int64_t)n_frames;
+    size_t wrote = 0;
+    while (left > 0) {
+        const int64_t target = s->steps == 0 ? s->need0 : s->Cx;
+        const int64_t take = std::min(left, target - s->fill);
+        std::memcpy(static_cast<char*>(s->h_in) + (size_t)s->fill * s->bpf, src, (size_t)take * s->bpf);
+        s->fill += take;
+        src += (size_t)take * s->bpf;
+        left -= take;
+        s->frames_in += (uint64_t)take;
+        if (s->fill < target) break;
+        if (s->steps == 0) AF_TRY(cs_first_step(s));
+        else AF_TRY(cs_timed(s, true));
+        std::memcpy(rows_out + wrote * s->row_len, s->h_out, s->rows_per_step * s->row_len * sizeof(float));
+        wrote += s->rows_per_step;
+        s->steps += 1;
+        s->fill = 0;
+    }
+    s->rows_out += wrote;
+    *n_rows = wrote;
+    return AF_OK;
+}
+
+af_status af_chain_stream_flush(af_chain_stream* s, float* rows_out, size_t rows_cap, size_t* n_rows)
+{
+    AF_REQUIRE(s && n_rows, "af_chain_stream_flush: null argument");
+    *n_rows = 0;
+    if (s->flushed) return AF_OK;
+    af_chain* c = s->chain;
+    const size_t total = af_chain_stream_total_rows(s, s->frames_in);
+    const size_t rows = total - (size_t)s->rows_out;               // what the partial step still owes
+    if (rows_cap < rows * s->row_len)
+        return fail(AF_ERR_BUFFER_TOO_SMALL, "row buffer holds %zu floats, the flush produces %zu", rows_cap,
+                    rows * s->row_len);
+    if (rows > 0) {
+        AF_REQUIRE(rows_out, "af_chain_stream_flush: null row buffer");
+        // the rest of the stream with its true coordinates, eagerly (its shape differs per stream): the buffer
+        // holds [history | the fill frames], the stream ends behind them (zeros beyond: the clip edge of one-shot)
+        const int64_t k = (int64_t)s->steps;
+        const int64_t hist = k == 0 ? 0 : s->carry;
+        const int64_t x_abs0 = k == 0 ? 0 : tile_base(c, k * s->Cz / c->fused.z_per_tile);
+        const int64_t n_res = (int64_t)af_resample_out_len(c->cfg.input_rate, c->cfg.output_rate, (size_t)s->frames_in);
+        const int64_t m0 = k * s->Cz, n_out = n_res - m0;
+        AF_REQUIRE(n_out > 0 && x_abs0 + hist + s->fill == (int64_t)s->frames_in,
+                   "stream bookkeeping: history %lld + %lld + %lld frames, %llu pushed", (long long)x_abs0,
+                   (long long)hist, (long long)s->fill, (unsigned long long)s->frames_in);
+        char* x = s->d_x.as<char>();
+        AF_HIP(hipMemcpyAsync(x + (size_t)hist * s->bpf, s->h_in, (size_t)s->fill * s->bpf, hipMemcpyHostToDevice, s->stream));
+        const int64_t start = 0;
+        size_t got = 0;
+        AF_TRY(af_features_set_batch_spans(s->tail, &start, &n_out, 1, &got));
+        AF_REQUIRE(got == rows, "stream bookkeeping: %zu rows in the tail span, expected %zu", got, rows);
+        AF_REQUIRE(n_out <= s->z_cap, "stream bookkeeping: %lld FIR outputs in the flush, room for %lld",
+                   (long long)n_out, (long long)s->z_cap);
+        AF_TRY(cs_kernels(s, s->tail, x_abs0, hist + s->fill, n_res, m0, n_out));
+        AF_HIP(hipMemcpyAsync(s->h_out, s->d_rows.p, rows * s->row_len * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        AF_HIP(hipStreamSynchronize(s->stream));
+        std::memcpy(rows_out, s->h_out, rows * s->row_len * sizeof(float));
+    }
+    s->rows_out += rows;
+    s->flushed = true;
+    *n_rows = rows;
+    return AF_OK;
+}
+
+af_status af_chain_stream_reset(af_chain_stream* s)
+{
+    AF_REQUIRE(s, "af_chain_stream_reset: null handle");
+    AF_HIP(hipStreamSynchronize(s->stream));
+    s->fill = 0;
+    s->steps = 0;
+    s->frames_in = s->rows_out = 0;
+    s->flushed = false;
+    return AF_OK;
+}
+
+/* timing of the last replayed step: device time between the events around the graph launch and host wall time of
+ * launch + wait; stats[4] = {device_ms, wall_ms, steps so far, rows so far} */
+af_status af_chain_stream_stats(const af_chain_stream* s, double* stats)
+{
+    AF_REQUIRE(s && stats, "af_chain_stream_stats: null argument");
+    stats[0] = s->last_device_ms;
+    stats[1] = s->last_wall_ms;
+    stats[2] = (double)s->steps;
+    stats[3] = (double)s->rows_out;
     return AF_OK;
 }
 

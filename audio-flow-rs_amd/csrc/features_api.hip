@@ -58,6 +58,7 @@ struct af_features {
     // staging for the host-buffer entry point
     DevBuf d_pcm, d_mel;
     DevBuf d_stamps;                 // diagnostics: per-phase cycle sums (af_features_debug_stamps)
+    int opt_kernel = -1, opt_wg_per_cu = -1;   // af_features_set_option; -1: the process-wide af_debug_set switch
 };
 
 namespace {
@@ -604,8 +605,9 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     prm.log_mel = (int)p->cfg.log_mel;
     prm.separate = p->cfg.channel_mode == AF_CH_SEPARATE;
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
-    const int wg_knob = debug_knob(kKnobFeaturesWgPerCu);
-    if (p->units_ok && prm.aligned16 && !debug_knob(kKnobFeaturesKernel)) {
+    const int wg_knob = p->opt_wg_per_cu >= 0 ? p->opt_wg_per_cu : debug_knob(kKnobFeaturesWgPerCu);
+    const int general = p->opt_kernel >= 0 ? p->opt_kernel : debug_knob(kKnobFeaturesKernel);
+    if (p->units_ok && prm.aligned16 && !general) {
         // hop 256, 16-byte aligned clips: the 8-wave kernel, two workgroups per CU
         v2::Params q{};
         q.pcm = pcm_dev;
@@ -744,6 +746,15 @@ const char* af_features_kernel_name(void) { return "af_features_v2_kernel"; }   
 // diagnostics, host only: the mel plans -- info[81] = {groups, K-steps, slots of wave 0..3} of the
 // general kernel, then {waves (0: not in use), groups, K-steps, slots of wave 0..7} of the hop-256 kernel,
 // then its slot_end words [8 waves][8 slots] (0: the group continues; else 0x10000 | filters << 8 | first filter)
+af_status af_features_set_option(af_features* p, const char* key, int value)
+{
+    AF_REQUIRE(p && key, "af_features_set_option: null argument");
+    if (std::strcmp(key, "kernel") == 0) p->opt_kernel = value < 0 ? -1 : value;
+    else if (std::strcmp(key, "wg_per_cu") == 0) p->opt_wg_per_cu = value < 0 ? -1 : value;
+    else return fail(AF_ERR_INVALID_ARG, "af_features_set_option: unknown option '%s'", key);
+    return AF_OK;
+}
+
 int af_features_plan_describe(const af_features* p, int32_t* info)
 {
     if (!p || !info) return 0;

@@ -447,20 +447,31 @@ private:
 };
 
 // BASELINE config 4: interleaved PCM -> to_mono -> polyphase resample -> FIR -> STFT -> mel on a batch of
-// equal-length clips (af_chain_*).  Two kernel launches where the fused resampler + FIR stage applies.
+// clips (af_chain_*): equal lengths or ragged (AudioFrame is variable-length, capture.rs:13-28), f32 or the wire
+// format's i16 (websocket.rs:246-251).  Two kernel launches where the fused resampler + FIR stage applies.
+namespace detail {
+inline af_chain_config chain_config(uint32_t input_rate, uint32_t channels, uint32_t output_rate,
+                                    const std::vector<float>& fir_taps, uint32_t n_mels, uint32_t sample_format)
+{
+    af_chain_config cfg;
+    af_chain_default_config(&cfg);
+    cfg.input_rate = input_rate;
+    cfg.channels = channels;
+    cfg.output_rate = output_rate;
+    cfg.fir_taps = fir_taps.empty() ? nullptr : fir_taps.data();
+    cfg.n_fir_taps = fir_taps.size();
+    cfg.n_mels = n_mels;
+    cfg.sample_format = sample_format;
+    return cfg;
+}
+}  // namespace detail
+
 class ChainPipeline {
 public:
     ChainPipeline(uint32_t input_rate, uint32_t channels, uint32_t output_rate, const std::vector<float>& fir_taps,
-                  uint32_t n_mels = 80)
+                  uint32_t n_mels = 80, uint32_t sample_format = AF_PCM_F32)
     {
-        af_chain_config cfg;
-        af_chain_default_config(&cfg);
-        cfg.input_rate = input_rate;
-        cfg.channels = channels;
-        cfg.output_rate = output_rate;
-        cfg.fir_taps = fir_taps.empty() ? nullptr : fir_taps.data();
-        cfg.n_fir_taps = fir_taps.size();
-        cfg.n_mels = n_mels;
+        const af_chain_config cfg = detail::chain_config(input_rate, channels, output_rate, fir_taps, n_mels, sample_format);
         n_mels_ = n_mels;
         detail::check(af_chain_create(&cfg, &h_));
     }
@@ -478,11 +489,66 @@ public:
         detail::check(af_chain_run(h_, pcm.data(), pcm.size(), mel.data(), mel.size()));
         return mel;
     }
+    // ragged batch: clip i = PCM frames [clip_offsets[i], clip_offsets[i + 1]); pcm = f32 or i16 samples (T)
+    template <class T>
+    std::vector<float> run_ragged(const std::vector<T>& pcm, const std::vector<int64_t>& clip_offsets)
+    {
+        size_t total = 0;
+        detail::check(af_chain_set_batch(h_, clip_offsets.data(), clip_offsets.empty() ? 0 : clip_offsets.size() - 1, &total));
+        std::vector<float> mel(total * n_mels_);
+        detail::check(af_chain_run(h_, pcm.data(), pcm.size(), mel.data(), mel.size()));
+        return mel;
+    }
+    void set_option(const char* key, int value) { detail::check(af_chain_set_option(h_, key, value)); }
     int n_launches() const { return af_chain_n_launches(h_); }
 
 private:
     af_chain* h_ = nullptr;
     uint32_t n_mels_ = 80;
+};
+
+// BASELINE config 5 on the whole chain (af_chain_stream_*): push() returns the rows of every step it completed (one
+// hipGraph replay each), flush() the rest; all rows in order == ChainPipeline::run on the whole stream, bit for bit.
+// Carry / flush analogue in the reference: BatchResampler, resampler.rs:132-166.
+class ChainStream {
+public:
+    ChainStream(size_t step_frames, uint32_t input_rate, uint32_t channels, uint32_t output_rate,
+                const std::vector<float>& fir_taps, uint32_t n_mels = 80, uint32_t sample_format = AF_PCM_F32)
+        : channels_(channels)
+    {
+        const af_chain_config cfg = detail::chain_config(input_rate, channels, output_rate, fir_taps, n_mels, sample_format);
+        detail::check(af_chain_stream_create(&cfg, step_frames, &h_));
+    }
+    ChainStream(const ChainStream&) = delete;
+    ChainStream& operator=(const ChainStream&) = delete;
+    ~ChainStream() { af_chain_stream_destroy(h_); }
+
+    size_t step_frames() const { return af_chain_stream_step_frames(h_); }
+    size_t row_len() const { return af_chain_stream_row_len(h_); }
+    size_t total_rows(uint64_t n_frames) const { return af_chain_stream_total_rows(h_, n_frames); }
+    template <class T>
+    std::vector<float> push(const std::vector<T>& pcm)
+    {
+        const size_t n_frames = pcm.size() / channels_;
+        std::vector<float> rows(af_chain_stream_max_rows(h_, n_frames) * row_len());
+        size_t n = 0;
+        detail::check(af_chain_stream_push(h_, pcm.data(), n_frames, rows.data(), rows.size(), &n));
+        rows.resize(n * row_len());
+        return rows;
+    }
+    std::vector<float> flush()
+    {
+        std::vector<float> rows(af_chain_stream_rows_per_step(h_) * row_len());
+        size_t n = 0;
+        detail::check(af_chain_stream_flush(h_, rows.data(), rows.size(), &n));
+        rows.resize(n * row_len());
+        return rows;
+    }
+    void reset() { detail::check(af_chain_stream_reset(h_)); }
+
+private:
+    af_chain_stream* h_ = nullptr;
+    uint32_t channels_ = 2;
 };
 
 }  // namespace audioflow

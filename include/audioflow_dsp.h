@@ -55,7 +55,10 @@ int         af_device_count(void);
  *   "features.kernel"     1: the general fused STFT+mel kernel also where the hop-256 kernel applies
  *   "features.wg_per_cu"  workgroups per CU of the fused kernels
  *   "banded.off"          1: resampler / FIR on the thread-per-output kernels instead of MFMA
- *   "chain.unfused"       1: af_chain_* runs resampler and FIR as two launches instead of one */
+ *   "chain.unfused"       1: af_chain_* runs resampler and FIR as two launches instead of one
+ * The switches are atomics: reading and writing them is race-free, and an entry point reads a switch once per
+ * call.  They are process-wide, though: with handles on several threads use the per-handle forms
+ * (af_chain_set_option, af_features_set_option) instead, which override them. */
 af_status   af_debug_set(const char* key, int value);
 
 /* ------------------------------------------------------------------ [R] */
@@ -294,6 +297,10 @@ af_status af_features_set_batch_uniform(af_features* p, size_t n_clips,
 af_status af_features_set_batch_spans(af_features* p, const int64_t* starts,
                                       const int64_t* lengths, size_t n_spans,
                                       size_t* total_frames_out);
+/* per-handle diagnostics (unlike af_debug_set they touch no other handle); value -1: follow af_debug_set
+ *   "kernel"     1: the general fused kernel also where the hop-256 kernel applies
+ *   "wg_per_cu"  workgroups per CU of the fused kernels */
+af_status af_features_set_option(af_features* p, const char* key, int value);
 /* enqueue the fused kernel on `stream` for the batch set above */
 af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel_dev,
                                  void* stream);
@@ -370,17 +377,20 @@ af_status af_mel_apply(af_mel* m, const float* power, size_t n_frames, float* me
 
 /* The whole chain of BASELINE config 4 behind one handle:
  * interleaved PCM -> to_mono (capture.rs:30-42) -> polyphase resample -> FIR -> STFT -> mel,
- * every stage a kernel of this library enqueued on the caller's stream.  Equal-length clips;
- * intermediates are allocated by set_batch, so run_device only launches (hipGraph-capturable).
+ * every stage a kernel of this library enqueued on the caller's stream.  Batches are equal-length
+ * clips (set_batch_uniform) or ragged ones (set_batch: AudioFrame is variable-length,
+ * capture.rs:13-28); PCM is f32 or the wire format's i16 (websocket.rs:246-251, scaled by 1/32768).
+ * Intermediates are allocated by set_batch*, so run_device only launches (hipGraph-capturable).
  * input_rate == output_rate skips the resampler, n_fir_taps == 0 skips the FIR.
  * Where af_chain_fused_plan_describe() says so, downmix + resampler + FIR are ONE launch (the
- * resampled signal before the FIR stays in LDS) and the chain is two launches; the values are
- * those of the separate launches bit for bit when both use the same MFMA step layout
- * (FIRs of 34..65 and 98..129 taps), and within the tolerance of docs/OPS.md otherwise. */
+ * resampled signal before the FIR stays in LDS) and the chain is two launches, for every batch
+ * shape and PCM format; the values are those of the separate launches bit for bit when both use
+ * the same MFMA step layout (FIRs of 34..65 and 98..129 taps), and within the tolerance of
+ * docs/OPS.md otherwise.  Without the fused launch a ragged batch runs resampler and FIR clip by clip. */
 typedef struct af_chain af_chain;
 typedef struct {
     uint32_t input_rate;     /* Hz of the PCM handed in */
-    uint32_t channels;       /* 1 or 2, interleaved f32 */
+    uint32_t channels;       /* 1 or 2, interleaved */
     uint32_t output_rate;    /* Hz the spectrogram is computed at */
     const float* fir_taps;   /* host pointer, copied at create; may be NULL */
     size_t   n_fir_taps;     /* 0..1024 */
@@ -388,15 +398,23 @@ typedef struct {
     uint32_t n_mels;
     float    f_min, f_max;   /* f_max 0 => output_rate/2 */
     int32_t  device;
+    uint32_t sample_format;  /* AF_PCM_F32 | AF_PCM_I16 */
 } af_chain_config;
-void      af_chain_default_config(af_chain_config* cfg);  /* 48 kHz stereo -> 16 kHz, no FIR, 1024/256, 80 mels */
+void      af_chain_default_config(af_chain_config* cfg);  /* 48 kHz stereo f32 -> 16 kHz, no FIR, 1024/256, 80 mels */
 af_status af_chain_create(const af_chain_config* cfg, af_chain** out);
 void      af_chain_destroy(af_chain* c);
 size_t    af_chain_n_frames(const af_chain* c, size_t n_pcm_frames);
 af_status af_chain_set_batch_uniform(af_chain* c, size_t n_clips, size_t frames_per_clip,
                                      size_t* total_frames_out);
-af_status af_chain_run_device(af_chain* c, const float* pcm_dev, float* mel_dev, void* stream);
-af_status af_chain_run(af_chain* c, const float* pcm, size_t pcm_len, float* mel, size_t mel_cap);
+/* ragged batch: clip i = PCM frames [clip_offsets[i], clip_offsets[i+1]) of the buffer (n_clips + 1 monotone
+ * offsets); output rows are the clips' spectrogram frames back to back */
+af_status af_chain_set_batch(af_chain* c, const int64_t* clip_offsets, size_t n_clips, size_t* total_frames_out);
+af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, void* stream);
+/* host buffers; pcm_len counts samples (frames x channels) */
+af_status af_chain_run(af_chain* c, const void* pcm, size_t pcm_len, float* mel, size_t mel_cap);
+/* per-handle diagnostics (unlike af_debug_set they touch no other handle):
+ *   "unfused"  1: resampler and FIR as separate launches; 0: fused where covered; -1: follow af_debug_set */
+af_status af_chain_set_option(af_chain* c, const char* key, int value);
 /* kernels af_chain_run_device enqueues per call for the configuration and batch described (2 when the
  * fused resampler + FIR launch applies; e.g. 3 for config 4 without it: resampler, FIR, STFT / mel) */
 int       af_chain_n_launches(const af_chain* c);
@@ -407,6 +425,30 @@ int       af_chain_n_launches(const af_chain* c);
  * resampler and the FIR as separate launches. */
 int       af_chain_fused_plan_describe(uint32_t input_rate, uint32_t output_rate, uint32_t channels,
                                        size_t n_fir_taps, int32_t* info);
+
+/* ChainStream: the same chain over an unbounded stream (BASELINE config 5 on the full chain).  The handle owns
+ * page-locked staging, the input history the resampler, the FIR (K - 1 samples) and the STFT (n_fft - hop
+ * samples) need, and ONE captured hipGraph per step: H2D of the new frames, the fused resampler + FIR launch,
+ * the STFT / mel launch, the history move, D2H of the rows.  A step is a whole number of tiles of both kernels
+ * (af_chain_stream_step_frames() input frames, the multiple of the step quantum nearest to the request) and the
+ * tiles are anchored at absolute sample 0, so the rows of all pushes and the flush, in order, equal af_chain_run
+ * on the whole stream bit for bit.  Needs a configuration with the fused launch (af_chain_fused_plan_describe);
+ * others get AF_ERR_UNSUPPORTED.  Reference analogue of the carry / flush: BatchResampler,
+ * modules/audio/resampler.rs:132-166; of the intended pipeline: specs/0002-design.md:1102-1125. */
+typedef struct af_chain_stream af_chain_stream;
+af_status af_chain_stream_create(const af_chain_config* cfg, size_t step_frames, af_chain_stream** out);
+void      af_chain_stream_destroy(af_chain_stream* s);
+size_t    af_chain_stream_step_frames(const af_chain_stream* s);        /* input frames per replayed step */
+size_t    af_chain_stream_rows_per_step(const af_chain_stream* s);
+size_t    af_chain_stream_row_len(const af_chain_stream* s);
+size_t    af_chain_stream_total_rows(const af_chain_stream* s, uint64_t n_frames);  /* after push(es) + flush */
+size_t    af_chain_stream_max_rows(const af_chain_stream* s, size_t n_frames);      /* of the next push of n_frames */
+af_status af_chain_stream_push(af_chain_stream* s, const void* pcm, size_t n_frames, float* rows_out,
+                               size_t rows_cap, size_t* n_rows);
+af_status af_chain_stream_flush(af_chain_stream* s, float* rows_out, size_t rows_cap, size_t* n_rows);
+af_status af_chain_stream_reset(af_chain_stream* s);
+/* stats[4] = {device ms of the last replayed step, host wall ms of it, steps so far, rows so far} */
+af_status af_chain_stream_stats(const af_chain_stream* s, double* stats);
 
 /* ------------------------------------------------------------------ [R]
  * RingBuffer, modules/audio/capture.rs:84-161 (tests :426-561): mutex-guarded f32 ring between

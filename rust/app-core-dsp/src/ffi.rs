@@ -21,7 +21,7 @@ pub const AF_CH_DOWNMIX: u32 = 0;
 pub const AF_CH_SEPARATE: u32 = 1;
 
 macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8; 0] } )* } }
-opaque!(af_vad, af_resampler, af_batch_resampler, af_fir, af_features, af_stft, af_mel, af_chain, af_ring, af_stream);
+opaque!(af_vad, af_resampler, af_batch_resampler, af_fir, af_features, af_stft, af_mel, af_chain, af_ring, af_stream, af_chain_stream);
 
 #[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct af_vad_config {
@@ -50,6 +50,7 @@ pub struct af_chain_config {
     pub input_rate: u32, pub channels: u32, pub output_rate: u32,
     pub fir_taps: *const f32, pub n_fir_taps: usize,
     pub hop: u32, pub n_mels: u32, pub f_min: f32, pub f_max: f32, pub device: i32,
+    pub sample_format: u32,
 }
 #[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct af_stream_config { pub features: af_features_config, pub step_frames: usize }
@@ -135,7 +136,24 @@ extern "C" {
     pub fn af_chain_destroy(c: *mut af_chain);
     pub fn af_chain_n_frames(c: *const af_chain, n_pcm_frames: usize) -> usize;
     pub fn af_chain_set_batch_uniform(c: *mut af_chain, n_clips: usize, frames_per_clip: usize, total_frames_out: *mut usize) -> af_status;
-    pub fn af_chain_run(c: *mut af_chain, pcm: *const f32, pcm_len: usize, mel: *mut f32, mel_cap: usize) -> af_status;
+    pub fn af_chain_set_batch(c: *mut af_chain, clip_offsets: *const i64, n_clips: usize, total_frames_out: *mut usize) -> af_status;
+    pub fn af_chain_run(c: *mut af_chain, pcm: *const c_void, pcm_len: usize, mel: *mut f32, mel_cap: usize) -> af_status;
+    pub fn af_chain_run_device(c: *mut af_chain, pcm_dev: *const c_void, mel_dev: *mut f32, stream: *mut c_void) -> af_status;
+    pub fn af_chain_set_option(c: *mut af_chain, key: *const c_char, value: c_int) -> af_status;
+    pub fn af_features_set_option(p: *mut af_features, key: *const c_char, value: c_int) -> af_status;
+    // config 5 on the whole chain: resampler / FIR / STFT history owned by the handle, one hipGraph per step
+    pub fn af_chain_stream_create(cfg: *const af_chain_config, step_frames: usize, out: *mut *mut af_chain_stream) -> af_status;
+    pub fn af_chain_stream_destroy(s: *mut af_chain_stream);
+    pub fn af_chain_stream_step_frames(s: *const af_chain_stream) -> usize;
+    pub fn af_chain_stream_rows_per_step(s: *const af_chain_stream) -> usize;
+    pub fn af_chain_stream_row_len(s: *const af_chain_stream) -> usize;
+    pub fn af_chain_stream_total_rows(s: *const af_chain_stream, n_frames: u64) -> usize;
+    pub fn af_chain_stream_max_rows(s: *const af_chain_stream, n_frames: usize) -> usize;
+    pub fn af_chain_stream_push(s: *mut af_chain_stream, pcm: *const c_void, n_frames: usize, rows_out: *mut f32, rows_cap: usize, n_rows: *mut usize) -> af_status;
+    pub fn af_chain_stream_flush(s: *mut af_chain_stream, rows_out: *mut f32, rows_cap: usize, n_rows: *mut usize) -> af_status;
+    pub fn af_chain_stream_reset(s: *mut af_chain_stream) -> af_status;
+    pub fn af_chain_stream_stats(s: *const af_chain_stream, stats: *mut f64) -> af_status;
+    pub fn af_resample_release_staging();
     pub fn af_chain_n_launches(c: *const af_chain) -> c_int;
     // RingBuffer, capture.rs:84-161
     pub fn af_ring_create(capacity_samples: usize, out: *mut *mut af_ring) -> af_status;

@@ -14,7 +14,7 @@
 pub mod ffi;
 
 use std::ffi::CStr;
-use std::os::raw::c_int;
+use std::os::raw::{c_int, c_void};
 use std::ptr;
 
 /// error.rs:94-111.  Library failures surface as `ResamplingFailed(msg)`, exactly like
@@ -479,34 +479,94 @@ impl FeatureStream {
 }
 impl Drop for FeatureStream { fn drop(&mut self) { unsafe { ffi::af_stream_destroy(self.h) } } }
 
-/// BASELINE config 4: to_mono -> polyphase resample -> FIR -> STFT -> mel on a uniform batch
-pub struct ChainPipeline { h: *mut ffi::af_chain, n_mels: usize }
-unsafe impl Send for ChainPipeline {}
+/// PCM sample types the chain takes: f32 in [-1, 1] (capture.rs:13-22) or the wire format's i16
+/// (websocket.rs:246-251, scaled by 1/32768).
+pub trait PcmSample: Copy { const FORMAT: u32; }
+impl PcmSample for f32 { const FORMAT: u32 = ffi::AF_PCM_F32; }
+impl PcmSample for i16 { const FORMAT: u32 = ffi::AF_PCM_I16; }
 
-impl ChainPipeline {
+fn chain_config(input_rate: u32, channels: u32, output_rate: u32, fir_taps: &[f32], format: u32) -> ffi::af_chain_config {
+    let mut cfg = unsafe { std::mem::zeroed::<ffi::af_chain_config>() };
+    unsafe { ffi::af_chain_default_config(&mut cfg) };
+    cfg.input_rate = input_rate;
+    cfg.channels = channels;
+    cfg.output_rate = output_rate;
+    cfg.fir_taps = if fir_taps.is_empty() { ptr::null() } else { fir_taps.as_ptr() };
+    cfg.n_fir_taps = fir_taps.len();
+    cfg.sample_format = format;
+    cfg
+}
+
+/// BASELINE config 4: to_mono -> polyphase resample -> FIR -> STFT -> mel on a batch of clips, equal-length or
+/// ragged (`AudioFrame` is variable-length, capture.rs:13-28)
+pub struct ChainPipeline<T: PcmSample = f32> { h: *mut ffi::af_chain, n_mels: usize, _t: std::marker::PhantomData<T> }
+unsafe impl<T: PcmSample> Send for ChainPipeline<T> {}
+
+impl<T: PcmSample> ChainPipeline<T> {
     pub fn new(input_rate: u32, channels: u32, output_rate: u32, fir_taps: &[f32]) -> Result<Self, AudioError> {
-        let mut cfg = unsafe { std::mem::zeroed::<ffi::af_chain_config>() };
-        unsafe { ffi::af_chain_default_config(&mut cfg) };
-        cfg.input_rate = input_rate;
-        cfg.channels = channels;
-        cfg.output_rate = output_rate;
-        cfg.fir_taps = if fir_taps.is_empty() { ptr::null() } else { fir_taps.as_ptr() };
-        cfg.n_fir_taps = fir_taps.len();
+        let cfg = chain_config(input_rate, channels, output_rate, fir_taps, T::FORMAT);
         let mut h = ptr::null_mut();
         check(unsafe { ffi::af_chain_create(&cfg, &mut h) })?;
-        Ok(Self { h, n_mels: cfg.n_mels as usize })
+        Ok(Self { h, n_mels: cfg.n_mels as usize, _t: std::marker::PhantomData })
     }
-    pub fn run(&mut self, pcm: &[f32], n_clips: usize, frames_per_clip: usize) -> Result<Vec<f32>, AudioError> {
+    pub fn run(&mut self, pcm: &[T], n_clips: usize, frames_per_clip: usize) -> Result<Vec<f32>, AudioError> {
         let mut total = 0usize;
         check(unsafe { ffi::af_chain_set_batch_uniform(self.h, n_clips, frames_per_clip, &mut total) })?;
+        self.run_described(pcm, total)
+    }
+    /// ragged batch: clip i = PCM frames [clip_offsets[i], clip_offsets[i + 1]) of `pcm`
+    pub fn run_ragged(&mut self, pcm: &[T], clip_offsets: &[i64]) -> Result<Vec<f32>, AudioError> {
+        let mut total = 0usize;
+        let n = clip_offsets.len().saturating_sub(1);
+        check(unsafe { ffi::af_chain_set_batch(self.h, clip_offsets.as_ptr(), n, &mut total) })?;
+        self.run_described(pcm, total)
+    }
+    fn run_described(&mut self, pcm: &[T], total: usize) -> Result<Vec<f32>, AudioError> {
         let mut mel = vec![0.0f32; total * self.n_mels];
-        check(unsafe { ffi::af_chain_run(self.h, pcm.as_ptr(), pcm.len(), mel.as_mut_ptr(), mel.len()) })?;
+        check(unsafe { ffi::af_chain_run(self.h, pcm.as_ptr() as *const c_void, pcm.len(), mel.as_mut_ptr(), mel.len()) })?;
         Ok(mel)
     }
     /// kernels one pass enqueues for the batch described last (2 with the fused resampler + FIR stage)
     pub fn n_launches(&self) -> usize { unsafe { ffi::af_chain_n_launches(self.h) as usize } }
 }
-impl Drop for ChainPipeline { fn drop(&mut self) { unsafe { ffi::af_chain_destroy(self.h) } } }
+impl<T: PcmSample> Drop for ChainPipeline<T> { fn drop(&mut self) { unsafe { ffi::af_chain_destroy(self.h) } } }
+
+/// BASELINE config 5 on the whole chain: the handle owns the resampler history, the FIR's K - 1 samples and the
+/// STFT's n_fft - hop carry, and replays one captured hipGraph per step; `push` returns the rows of every step it
+/// completed, `flush` the rest, and all rows in order equal `ChainPipeline::run` on the whole stream bit for bit.
+/// Reference analogue of the carry / flush: `BatchResampler::{process, flush}`, resampler.rs:132-166.
+pub struct ChainStream<T: PcmSample = f32> { h: *mut ffi::af_chain_stream, channels: usize, _t: std::marker::PhantomData<T> }
+unsafe impl<T: PcmSample> Send for ChainStream<T> {}
+
+impl<T: PcmSample> ChainStream<T> {
+    pub fn new(step_frames: usize, input_rate: u32, channels: u32, output_rate: u32, fir_taps: &[f32]) -> Result<Self, AudioError> {
+        let cfg = chain_config(input_rate, channels, output_rate, fir_taps, T::FORMAT);
+        let mut h = ptr::null_mut();
+        check(unsafe { ffi::af_chain_stream_create(&cfg, step_frames, &mut h) })?;
+        Ok(Self { h, channels: channels as usize, _t: std::marker::PhantomData })
+    }
+    /// input frames per replayed step (the multiple of the step quantum nearest to the request)
+    pub fn step_frames(&self) -> usize { unsafe { ffi::af_chain_stream_step_frames(self.h) } }
+    pub fn row_len(&self) -> usize { unsafe { ffi::af_chain_stream_row_len(self.h) } }
+    pub fn total_rows(&self, n_frames: u64) -> usize { unsafe { ffi::af_chain_stream_total_rows(self.h, n_frames) } }
+    pub fn push(&mut self, pcm: &[T]) -> Result<Vec<f32>, AudioError> {
+        let n_frames = pcm.len() / self.channels;
+        let mut rows = vec![0.0f32; unsafe { ffi::af_chain_stream_max_rows(self.h, n_frames) } * self.row_len()];
+        let mut n = 0usize;
+        check(unsafe { ffi::af_chain_stream_push(self.h, pcm.as_ptr() as *const c_void, n_frames, rows.as_mut_ptr(), rows.len(), &mut n) })?;
+        rows.truncate(n * self.row_len());
+        Ok(rows)
+    }
+    pub fn flush(&mut self) -> Result<Vec<f32>, AudioError> {
+        let mut rows = vec![0.0f32; unsafe { ffi::af_chain_stream_rows_per_step(self.h) } * self.row_len()];
+        let mut n = 0usize;
+        check(unsafe { ffi::af_chain_stream_flush(self.h, rows.as_mut_ptr(), rows.len(), &mut n) })?;
+        rows.truncate(n * self.row_len());
+        Ok(rows)
+    }
+    pub fn reset(&mut self) -> Result<(), AudioError> { check(unsafe { ffi::af_chain_stream_reset(self.h) }) }
+}
+impl<T: PcmSample> Drop for ChainStream<T> { fn drop(&mut self) { unsafe { ffi::af_chain_stream_destroy(self.h) } } }
 
 // ------------------------------------------------------------------------------------------------
 // The reference's own unit tests, to be run on a machine with the library and an MI355X

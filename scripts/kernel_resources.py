@@ -17,6 +17,6 @@ for ln in p.stderr.splitlines():
         k, v = t.rsplit(":", 1); vals[k.strip()] = v.strip()
         if k.strip().startswith("LDS Size"):
             name = subprocess.run(["c++filt", cur], capture_output=True, text=True).stdout.strip()
-            name = name.split("(")[0].replace("void ", "")
+            name = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             print(f"{name:78s} VGPR {vals.get('VGPRs'):>4s} spill {vals.get('VGPRs Spill'):>3s} scratch {vals.get('ScratchSize [bytes/lane]'):>4s} "
                   f"SGPR {vals.get('TotalSGPRs')} sspill {vals.get('SGPRs Spill')} occ {vals.get('Occupancy [waves/SIMD]')}")

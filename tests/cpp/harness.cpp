@@ -200,6 +200,29 @@ int main()
             if (mel[10 * 80 + m] > mel[10 * 80 + arg]) arg = m;
         // HTK mel of 1 kHz is 1000.0; 82 edges over mel(0..8 kHz) = 2840.0 -> filter centre index ~ 27.5
         CHECK(arg >= 26 && arg <= 29);
+        // the same clip twice in a ragged batch (with an empty clip between) gives the same rows twice
+        std::vector<float> xx(x);
+        xx.insert(xx.end(), x.begin(), x.end());
+        auto rag = chain.run_ragged(xx, {0, (int64_t)n, (int64_t)n, (int64_t)(2 * n)});
+        CHECK(rag.size() == 2 * mel.size() && std::equal(mel.begin(), mel.end(), rag.begin()) &&
+              std::equal(mel.begin(), mel.end(), rag.begin() + mel.size()));
+        // the wire format (websocket.rs:246-251) through the same chain: i16 in, rows close to the f32 ones
+        std::vector<int16_t> xi(x.size());
+        for (size_t i = 0; i < x.size(); ++i) xi[i] = (int16_t)(x[i] * 32767.0f);
+        ChainPipeline chain16(48000, 2, 16000, taps, 80, AF_PCM_I16);
+        auto mel16 = chain16.run_ragged(xi, {0, (int64_t)n});
+        CHECK(mel16.size() == mel.size() && std::fabs(mel16[10 * 80 + arg] / mel[10 * 80 + arg] - 1.0f) < 1e-3f);
+        // ChainStream (config 5 on the whole chain): two pushes + flush == the one-shot rows, bit for bit
+        ChainStream cs(1, 48000, 2, 16000, taps);
+        std::vector<float> long_x;
+        for (int r = 0; r < 5; ++r) long_x.insert(long_x.end(), x.begin(), x.end());      // 5 s: one step + a rest
+        std::vector<float> rows = cs.push(std::vector<float>(long_x.begin(), long_x.begin() + 2 * 100000));
+        auto r2 = cs.push(std::vector<float>(long_x.begin() + 2 * 100000, long_x.end()));
+        rows.insert(rows.end(), r2.begin(), r2.end());
+        auto r3 = cs.flush();
+        rows.insert(rows.end(), r3.begin(), r3.end());
+        auto whole = chain.run(long_x, 1, 5 * n);
+        CHECK(cs.step_frames() == 184320 && rows.size() == cs.total_rows(5 * n) * 80 && rows == whole);
     }
     std::printf(failures ? "%d check(s) failed\n" : "harness ok\n", failures);
     return failures ? 1 : 0;

@@ -316,3 +316,156 @@ def test_feature_stream_eight_hours_config5(af):
     assert torch.equal(rows, full.cpu())
     print(f"\n8 h stream: {st.stats()['steps']} steps, wall ms per step median {np.median(wall):.2f}, "
           f"{n / sr / (np.median(wall) * 1e-3 * st.stats()['steps']):.0f}x real time on the step path alone")
+
+
+# ---- ragged batches and i16 PCM through af_chain_* (capture.rs:13-28, websocket.rs:246-251) ----------------------
+def _as_i16(x):
+    return np.round(np.asarray(x) * 32767.0).astype(np.int16)
+
+
+@pytest.mark.parametrize("ch,fmt", [(2, 0), (1, 0), (2, 1), (1, 1)])
+def test_chain_ragged_and_i16_fused_equals_unfused_and_oracle(af, po, ch, fmt):
+    """A ragged batch (lengths from empty to several tiles, one shorter than n_fft at 16 kHz) in both PCM formats:
+    the fused launch (one record per tile) == the clip-by-clip stage path bit for bit (129 taps: same MFMA step
+    layout), both within tolerance of the chained oracle, frame counts exact."""
+    taps = lowpass_taps()
+    lens = [40000, 0, 11520 * 2, 3000, 123456, 11520 * 2 + 2, 70, 50001 + (ch == 1 and fmt == 1)]
+    if ch == 1 and fmt == 1:
+        lens = [n + (n & 1) for n in lens]              # mono i16: even clip offsets keep the fused launch
+    clips = [synth_clip(700 + i, n, ch, 48000) for i, n in enumerate(lens)]
+    pcm = np.concatenate([c for c in clips if c.size] or [np.zeros(0, np.float32)])
+    if fmt:
+        pcm = _as_i16(pcm)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    chain = af.ChainPipeline(input_rate=48000, channels=ch, output_rate=16000, fir_taps=taps, sample_format=fmt)
+    total = chain.set_batch(off)
+    nfs = [chain.n_frames(n) for n in lens]
+    assert total == sum(nfs) and nfs == [po.stft_n_frames(po.resample_out_len(n, 1, 3)) for n in lens]
+    assert chain.n_launches() == 2
+    fused = chain.run(pcm)
+    chain.set_option("unfused", 1)
+    assert chain.n_launches() > 2
+    staged = chain.run(pcm)
+    chain.set_option("unfused", -1)
+    assert np.array_equal(fused, staged)
+    row = 0
+    for x, nf in zip(clips, nfs):
+        if nf:
+            xf = _as_i16(x).astype(np.float32) / np.float32(32768.0) if fmt else x
+            assert frame_rel_err(fused[row:row + nf], oracle_chain(po, xf, ch, 48000, 16000, taps)) < 2e-5
+        row += nf
+    # the same clips as a uniform batch of one length: rows of equal clips agree bit for bit across batch shapes
+    uni = af.ChainPipeline(input_rate=48000, channels=ch, output_rate=16000, fir_taps=taps, sample_format=fmt)
+    uni.set_batch_uniform(1, lens[4])
+    x4 = clips[4] if not fmt else _as_i16(clips[4])
+    r0 = sum(nfs[:4])
+    assert np.array_equal(uni.run(x4), fused[r0:r0 + nfs[4]])
+
+
+def test_chain_ragged_without_a_fused_plan(af, po):
+    """44.1 -> 16 kHz has no fused launch: a ragged batch runs resampler and FIR clip by clip."""
+    taps = lowpass_taps()
+    lens = [30000, 44100, 5000]
+    clips = [synth_clip(800 + i, n, 2, 44100) for i, n in enumerate(lens)]
+    chain = af.ChainPipeline(input_rate=44100, channels=2, output_rate=16000, fir_taps=taps)
+    chain.set_batch(np.concatenate([[0], np.cumsum(lens)]))
+    mel = chain.run(np.concatenate(clips))
+    row = 0
+    for x, n in zip(clips, lens):
+        nf = chain.n_frames(n)
+        assert frame_rel_err(mel[row:row + nf], oracle_chain(po, x, 2, 44100, 16000, taps)) < 2e-5
+        row += nf
+    assert row == mel.shape[0]
+
+
+# ---- ChainStream (af_chain_stream_*): config 5 on the whole chain ----------------------------------------------
+@pytest.mark.parametrize("ch,fmt,n", [(2, 0, 184320 * 3 + 50001), (1, 1, 184320 * 2 + 7), (2, 0, 190000),
+                                      (2, 1, 184320 + 2200), (1, 0, 2000), (2, 0, 0)])
+def test_chain_stream_small_steps_equal_one_shot(af, po, ch, fmt, n):
+    """Ragged pushes over several steps (the smallest step: 184 320 input frames = 61 440 FIR outputs = 16 tiles of
+    the fused launch = 15 units of the feature kernel), a partial last step, streams shorter than one step, i16 and
+    mono: rows of pushes + flush == ChainPipeline.run on the whole stream, bit for bit."""
+    taps = lowpass_taps()
+    x = synth_clip(900 + ch + fmt, n, ch, 48000)
+    if fmt:
+        x = _as_i16(x)
+    st = af.ChainStream(step_frames=1, channels=ch, fir_taps=taps, sample_format=fmt)
+    assert st.step_frames == 184320 and st.rows_per_step == 240
+    rng = np.random.default_rng(n % 97)
+    rows, pos = [], 0
+    while pos < n:
+        k = int(rng.integers(0, 120000))
+        rows.append(st.push(x[pos * ch:(pos + k) * ch]))
+        pos += k
+    rows.append(st.flush())
+    got = np.concatenate(rows)
+    one = af.ChainPipeline(channels=ch, fir_taps=taps, sample_format=fmt)
+    one.set_batch_uniform(1, n)
+    assert got.shape[0] == st.total_rows(n) == one.n_frames(n)
+    if n:
+        full = one.run(x)
+        assert np.array_equal(got, full)
+        if got.shape[0]:
+            xf = x.astype(np.float32) / np.float32(32768.0) if fmt else x
+            assert frame_rel_err(got, oracle_chain(po, xf, ch, 48000, 16000, taps)) < 2e-5
+    with pytest.raises(af.AudioError):
+        st.push(x[:8 * ch] if n else np.zeros(8 * ch, x.dtype))                  # pushed after flush
+    st.reset()
+    assert st.push(np.zeros(100 * ch, x.dtype)).shape[0] == 0
+
+
+def test_chain_stream_ten_minutes_bit_equal_to_one_shot(af):
+    """>= 10 min of 48 kHz stereo pushed in ragged pieces through af_chain_stream_* (resampler history, FIR history
+    and STFT carry owned by the handle; one hipGraph replay per ~19 s step) == af_chain_run on the whole stream,
+    bit for bit; per-step latency printed."""
+    torch = pytest.importorskip("torch")
+    sr, ch = 48000, 2
+    n = 10 * 60 * sr + 54321
+    gen = torch.Generator().manual_seed(12)
+    x = (torch.rand(n, ch, generator=gen) * 2 - 1).mul_(0.4).numpy()
+    taps = lowpass_taps()
+    st = af.ChainStream(step_frames=1 << 20, fir_taps=taps)
+    assert st.step_frames == 6 * 184320                       # the multiple of the step quantum nearest to 2^20
+    rng = np.random.default_rng(8)
+    rows, dev_ms, wall_ms, pos = [], [], [], 0
+    while pos < n:
+        k = int(rng.integers(1, 700000))
+        r = st.push(x[pos:pos + k])
+        if r.shape[0] and st.stats()["steps"] > 1:
+            s = st.stats()
+            dev_ms.append(s["device_ms"]); wall_ms.append(s["wall_ms"])
+        rows.append(r)
+        pos += k
+    rows.append(st.flush())
+    got = np.concatenate(rows)
+    one = af.ChainPipeline(fir_taps=taps)
+    one.set_batch_uniform(1, n)
+    full = one.run(x.reshape(-1))
+    need0 = st.step_frames + 3 * 767 + 33                     # step 0 also needs the STFT halo and the resampler's look-ahead
+    assert got.shape == full.shape == (st.total_rows(n), 80) and st.stats()["steps"] == 1 + (n - need0) // st.step_frames == 26
+    assert np.array_equal(got, full)
+    step_s = st.step_frames / sr
+    print(f"\nchain stream: {len(dev_ms)} replayed steps of {step_s:.1f} s audio; device ms/step median "
+          f"{np.median(dev_ms):.2f} max {np.max(dev_ms):.2f}; wall ms/step median {np.median(wall_ms):.2f}; "
+          f"real-time factor {step_s / (np.median(wall_ms) * 1e-3):.0f}x")
+    assert np.median(wall_ms) * 1e-3 < step_s / 100
+
+
+def test_chain_stream_needs_the_fused_launch(af):
+    with pytest.raises(af.AudioError, match="no fused"):
+        af.ChainStream(input_rate=44100, fir_taps=lowpass_taps())
+    with pytest.raises(af.AudioError, match="no fused"):
+        af.ChainStream()                                          # no FIR
+
+
+def test_features_per_handle_option(af):
+    """af_features_set_option("kernel", 1) routes ONE handle to the general kernel; another handle is untouched."""
+    x = synth_clip(77, 30000, 2, 48000)
+    a, b = af.FeaturePipeline(), af.FeaturePipeline()
+    a.set_batch_uniform(1, 30000); b.set_batch_uniform(1, 30000)
+    base = a.run(x)
+    lib = af.library()
+    assert lib.af_features_set_option(a._h, b"kernel", 1) == 0
+    gen = a.run(x)
+    assert np.array_equal(b.run(x), base)                        # b still on the hop-256 kernel
+    assert frame_rel_err(gen, base) < 2e-6 and lib.af_features_set_option(a._h, b"bogus", 1) != 0
