@@ -37,7 +37,13 @@ struct Plan {
     int seg_stride = 0;       // odd, >= seg_len
     int64_t out_per_tile = 0; // 256 * G * nb
     size_t smem = 0;
-    size_t afrag_floats() const { return (size_t)nb * NK * 64; }
+    // Streamed form (ratios with more than 16 block matrices, e.g. 48 k -> 44.1 k: nb = 147): the matrices do
+    // not stay in registers, a tile is a RANGE of P consecutive matrices times 16 C periods and every wave
+    // fetches the fragments of its next matrix (L2-resident table) while it multiplies with the current one.
+    bool streamed = false;
+    int P = 0, C = 0;         // matrices per tile, column sets (of 16 periods) per tile
+    // fragments [nb][NK][64]; streamed plans keep q(16 p), p = 0..nb, as ints behind them
+    size_t afrag_floats() const { return (size_t)nb * NK * 64 + (streamed ? (size_t)nb + 1 : 0); }
 };
 
 // Decide whether (L, M, T) runs on the MFMA kernel and with which tile shape.

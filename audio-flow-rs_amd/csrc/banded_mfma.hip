@@ -59,6 +59,12 @@ __global__ void build_afrag_kernel(const float* __restrict__ proto, float* __res
     afrag[idx] = (k >= 0 && k < T) ? proto[(size_t)r + (size_t)k * L] : 0.0f;
 }
 
+__global__ void build_qtab_kernel(int* __restrict__ qtab, uint32_t L, uint32_t M, int nb)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= nb) qtab[p] = (int)(((uint64_t)16 * p * M) / L);       // q(16 p); q(16 nb) = S
+}
+
 // A zero the compiler cannot see through: offsets derived from it are recomputed where they
 // are used instead of being hoisted out of the tile loop into 30+ live registers.
 __device__ __forceinline__ int opaque_zero()
@@ -245,6 +251,170 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         };
         chain_pair(0, std::true_type{});
         for (int gi = kPair ? 2 : 1; gi < g.gpw; gi += kPair ? 2 : 1) chain_pair(gi, std::false_type{});
+    }
+}
+
+// ---- ratios with many block matrices: the matrices are streamed --------------------------------------------
+// nb = L / gcd(16, L) > 16 (48 k -> 44.1 k: 147, 16 k -> 44.1 k: 441): a wave cannot own "its" matrix for the whole
+// launch.  Blocks are numbered b = period * nb + p; a tile is the matrices [p0, p0 + P) of 16 C consecutive periods.
+// Every period has one LDS segment holding x[period S + q(16 p0) + lo_off ...) for all P matrices of the range
+// (their windows move on by about 16 M / L samples per matrix, so the range's windows overlap: each staged sample is
+// used by several matrices; the W-sample halo between neighbouring ranges is re-read, mostly from L2).  Wave w takes
+// the matrices p0 + w, p0 + w + 8, ...: it fetches the NK fragment registers of its NEXT matrix (a [nb][NK][64] table,
+// L2-resident) while it runs the C chains of the current one (16 periods = the 16 MFMA columns), so the fragment
+// traffic from L2 is 1 / C of what one chain per fetch would need.  k-slot mapping, fragment table and chain order
+// are those of banded_kernel: a block's bits depend on (p, window) only, never on the tiling.
+struct StreamGeom {
+    const float* x;
+    float* y;
+    const float* afrag;              // [nb][NK][64]
+    const int* qtab;                 // [nb + 1]: q(16 p), p = 0..nb (host-built; q(16 nb) = S)
+    int64_t x_abs0, x_len, x_stride, y_stride, m0, n_out;
+    int64_t pg0;                     // first period group (of 16 C periods) this launch touches
+    int64_t n_pg, n_pr;              // period groups per clip, matrix ranges
+    int64_t n_tiles;
+    int lo_off;
+    int nb, S, P, C, seg_len, seg_stride;
+};
+
+// wave-uniform table entry through the scalar cache (a vector load would count in vmcnt, and waiting for it would
+// wait for every x request in flight)
+__device__ __forceinline__ int sload_int(const int* base, int idx)
+{
+    typedef const __attribute__((address_space(4))) int* cptr;
+    return reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(base))[__builtin_amdgcn_readfirstlane(idx)];
+}
+
+template <int NK, int C>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void banded_stream_kernel(const StreamGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    constexpr int FULL = NK / 16, TAILQ = NK % 16;
+    constexpr int kSegs = 16 * C;                                   // one segment per period of the tile
+    constexpr int nthreads = 512;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g4 = lane >> 4;
+    const uint32_t tiles_per_clip = (uint32_t)(g.n_pg * g.n_pr), n_tiles = (uint32_t)g.n_tiles;
+    const bool first = tid < g.seg_len;                             // seg_len <= 512: one sample per thread and segment
+
+    constexpr uint32_t kOob = 0xFFF00000u;
+    float pf[kSegs];
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff;
+    // tile -> (clip, period group, matrix range); ranges vary fastest: neighbouring ranges share their halo in L2
+    auto prep_tile = [&](uint32_t tile, bool live) {
+        const uint32_t clip = tile / tiles_per_clip, r = tile - clip * tiles_per_clip;
+        const int64_t pg = g.pg0 + r / (uint32_t)g.n_pr;
+        const int p0 = (int)(r % (uint32_t)g.n_pr) * g.P;
+        const int64_t base = pg * (int64_t)kSegs * g.S + sload_int(g.qtab, p0) + g.lo_off - g.x_abs0;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride), 0,
+                                                 (int)(uint32_t)(g.x_len * 4), 0x00020000);
+        voff = live && first ? ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * 4u : kOob;
+    };
+    auto issue_load = [&](int sgm) {
+        pf[sgm] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff + (uint32_t)(sgm * g.S) * 4u), 0, 0));
+    };
+
+    float a[2][NK];                                                 // this matrix, the next one
+    auto load_a = [&](int slot, int p) {
+        const float* ap = g.afrag + ((size_t)p * NK) * 64 + lane + opaque_zero();
+#pragma unroll
+        for (int t = 0; t < NK; ++t) a[slot][t] = ap[t * 64];
+    };
+
+    uint32_t tile = blockIdx.x;
+    if (tile < n_tiles) {
+        prep_tile(tile, true);
+#pragma unroll
+        for (int sgm = 0; sgm < kSegs; ++sgm) issue_load(sgm);
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t clip = tile / tiles_per_clip, r = tile - clip * tiles_per_clip;
+        const int64_t pg = g.pg0 + r / (uint32_t)g.n_pr;
+        const int p0 = (int)(r % (uint32_t)g.n_pr) * g.P;
+        const int p_end = p0 + g.P < g.nb ? p0 + g.P : g.nb;
+        if (p0 + wave < p_end) load_a(0, p0 + wave);                // under the barrier and the LDS fill
+        __syncthreads();                                            // readers of the previous tile done
+        if (first) {
+            float* dst = xs + tid + opaque_zero();
+#pragma unroll
+            for (int sgm = 0; sgm < kSegs; ++sgm) dst[sgm * g.seg_stride] = pf[sgm];
+        }
+        __syncthreads();
+        {
+            const bool live = tile + gridDim.x < n_tiles;
+            prep_tile(live ? tile + gridDim.x : tile, live);
+        }
+        float* yc = g.y + (int64_t)clip * g.y_stride - g.m0;        // where absolute output 0 of the clip would be
+        const int q0 = sload_int(g.qtab, p0);
+        // one chain: matrix p (fragments in a[slot]) times the 16 periods of column set cs; the first chain of a
+        // wave also carries the next tile's x requests between its steps
+        auto chain = [&](int p, auto slot_c, int cs, auto with_loads) {
+            constexpr bool LOADS = decltype(with_loads)::value;
+            constexpr int SLOT = decltype(slot_c)::value;
+            const int qrel = sload_int(g.qtab, p) - q0;             // window start of matrix p inside a segment
+            const float* bfull = xs + (cs * 16 + col) * g.seg_stride + qrel + 16 * g4;
+            const float* btail = xs + (cs * 16 + col) * g.seg_stride + qrel + TAILQ * g4 + 64 * FULL;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            constexpr int kAhead = 3;
+            float w0[kAhead + 1];
+            auto read_b = [&](int t) {
+                w0[t % (kAhead + 1)] = t < 16 * FULL ? bfull[64 * (t / 16) + (t % 16)] : btail[t - 16 * FULL];
+            };
+#pragma unroll
+            for (int t = 0; t < kAhead && t < NK; ++t) read_b(t);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NK; ++t) {
+                if (t + kAhead < NK) read_b(t + kAhead);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SLOT][t], w0[t % (kAhead + 1)], acc, 0, 0, 0);
+                if (LOADS) {
+                    constexpr int kSpan = (NK + 1) / 2;
+                    if (t < kSpan) {
+#pragma unroll
+                        for (int s2 = (kSegs * t) / kSpan; s2 < (kSegs * (t + 1)) / kSpan; ++s2) issue_load(s2);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // block b = period * nb + p of column `col`: rows 4 g4 .. 4 g4 + 3
+            const int64_t period = pg * kSegs + cs * 16 + col;
+            const int64_t m = 16 * (period * g.nb + p) + 4 * g4;
+            float* o = yc + m;
+            if (m >= g.m0 && m + 4 <= g.m0 + g.n_out && ((reinterpret_cast<uintptr_t>(o) >> 2) & 3) == 0) {
+                *reinterpret_cast<f32x4*>(o) = acc;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (m + j >= g.m0 && m + j < g.m0 + g.n_out) o[j] = acc[j];
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        int p = p0 + wave;
+        if (p < p_end) {
+            // fragment slots alternate at compile time (a runtime slot index would cost a select per MFMA operand)
+            if (p + 8 < p_end) load_a(1, p + 8);                    // next matrix: lands under this one's chains
+            chain(p, S0{}, 0, std::true_type{});
+#pragma unroll
+            for (int cs = 1; cs < C; ++cs) chain(p, S0{}, cs, std::false_type{});
+            for (p += 8; p < p_end;) {
+                if (p + 8 < p_end) load_a(0, p + 8);
+#pragma unroll
+                for (int cs = 0; cs < C; ++cs) chain(p, S1{}, cs, std::false_type{});
+                p += 8;
+                if (p >= p_end) break;
+                if (p + 8 < p_end) load_a(1, p + 8);
+#pragma unroll
+                for (int cs = 0; cs < C; ++cs) chain(p, S0{}, cs, std::false_type{});
+                p += 8;
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < kSegs; ++s2) issue_load(s2);      // a wave without a matrix in this range
+        }
     }
 }
 
@@ -595,6 +765,55 @@ void launch_nk(const Geom& g, bool five, int ch, unsigned grid, unsigned block, 
 
 }  // namespace
 
+namespace {
+constexpr int kStreamC = 2;                    // column sets per tile of the streamed kernel (instances below)
+constexpr int kStreamNk[] = {20, 24, 28, 36};
+
+// Ratios with more than 16 block matrices (or block periods beyond an LDS segment): the streamed kernel.
+Plan make_stream_plan(Plan p, uint64_t nb, uint64_t S)
+{
+    if (p.ch != 1 || nb > 4096 || S >= (1ull << 24)) return p;
+    uint64_t d15 = 0;
+    for (uint64_t b = 0; b < nb; ++b) {
+        const uint64_t d = ((16 * b * p.M) % p.L + 15ull * p.M) / p.L;
+        if (d > d15) d15 = d;
+    }
+    const uint64_t W = (uint64_t)p.T + d15;
+    const uint64_t need = 16 * (W / 64) + ((W % 64) + 3) / 4;
+    int nk = 0;
+    for (int cand : kStreamNk)
+        if ((uint64_t)cand >= need) { nk = cand; break; }
+    if (!nk) return p;
+    // the largest range of matrices (a multiple of the 8 waves) whose windows fit one 512-sample segment
+    auto q16 = [&](uint64_t pp) { return (16 * pp * p.M) / p.L; };
+    int best = 0, best_len = 0;
+    for (int P = 32; P >= 8; P -= 8) {
+        uint64_t span = 0;
+        for (uint64_t p0 = 0; p0 < nb; p0 += P) {
+            const uint64_t last = std::min<uint64_t>(p0 + P, nb) - 1;
+            span = std::max(span, q16(last) - q16(p0));
+        }
+        if (span + 4 * nk <= 512) { best = P; best_len = (int)span + 4 * nk; break; }
+    }
+    if (!best) return p;
+    p.nb = (int)nb;
+    p.S = (int)S;
+    p.NK = nk;
+    p.streamed = true;
+    p.P = best;
+    p.C = kStreamC;
+    p.nwaves = 8;
+    p.wpp = 1;
+    p.G = 0;
+    p.seg_len = best_len;
+    p.seg_stride = best_len | 1;
+    p.out_per_tile = (int64_t)256 * best * kStreamC;
+    p.smem = (size_t)16 * kStreamC * p.seg_stride * sizeof(float);
+    p.ok = true;
+    return p;
+}
+}  // namespace
+
 Plan make_plan(uint32_t L, uint32_t M, int T, int c, int ch)
 {
     Plan p;
@@ -608,7 +827,7 @@ Plan make_plan(uint32_t L, uint32_t M, int T, int c, int ch)
     const uint32_t g16 = std::gcd(16u, L);
     const uint64_t nb = L / g16;
     const uint64_t S = (uint64_t)(16 / g16) * M;
-    if (nb > 16 || S > (uint64_t)kMaxSeg) return p;
+    if (nb > 16 || S > (uint64_t)kMaxSeg) return make_stream_plan(p, nb, S);
     p.nb = (int)nb;
     p.S = (int)S;
     uint64_t d15 = 0;
@@ -649,8 +868,66 @@ af_status build_afrag(const Plan& p, const float* proto_dev, float* afrag_dev, h
     hipLaunchKernelGGL(build_afrag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, proto_dev,
                        afrag_dev, p.L, p.M, p.T, p.nb, p.NK);
     AF_HIP(hipGetLastError());
+    if (p.streamed) {
+        hipLaunchKernelGGL(build_qtab_kernel, dim3((p.nb + 256) / 256), dim3(256), 0, stream,
+                           reinterpret_cast<int*>(afrag_dev + (size_t)p.nb * p.NK * 64), p.L, p.M, p.nb);
+        AF_HIP(hipGetLastError());
+    }
     return AF_OK;
 }
+
+namespace {
+template <int NK>
+af_status launch_stream_nk(const StreamGeom& g, unsigned grid, size_t smem, hipStream_t s)
+{
+    static LdsAttrFlags attr_set;
+    AF_HIP(allow_big_lds(banded_stream_kernel<NK, kStreamC>, 160 * 1024, attr_set));
+    hipLaunchKernelGGL((banded_stream_kernel<NK, kStreamC>), dim3(grid), dim3(512), smem, s, g);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+af_status launch_stream(const Plan& p, const float* afrag_dev, const float* x_dev, int64_t x_abs0, int64_t x_len,
+                        int64_t x_stride, float* y_dev, int64_t y_stride, int64_t m0, int64_t n_out, int64_t n_clips,
+                        hipStream_t stream)
+{
+    StreamGeom g{};
+    g.x = x_dev;
+    g.y = y_dev;
+    g.afrag = afrag_dev;
+    g.qtab = reinterpret_cast<const int*>(afrag_dev + (size_t)p.nb * p.NK * 64);
+    g.x_abs0 = x_abs0;
+    g.x_len = x_len;
+    g.x_stride = x_stride;
+    g.y_stride = y_stride;
+    g.m0 = m0;
+    g.n_out = n_out;
+    const int64_t per_group = (int64_t)16 * p.C;                    // periods per tile
+    const int64_t period_lo = (m0 / 16) / p.nb, period_hi = ((m0 + n_out - 1) / 16) / p.nb;
+    g.pg0 = period_lo / per_group;
+    g.n_pg = period_hi / per_group - g.pg0 + 1;
+    g.n_pr = (p.nb + p.P - 1) / p.P;
+    g.n_tiles = g.n_pg * g.n_pr * n_clips;
+    if (g.n_tiles >= (1ll << 31)) return fail(AF_ERR_UNSUPPORTED, "banded::launch: too many tiles");
+    g.lo_off = p.c - (p.T - 1);
+    g.nb = p.nb;
+    g.S = p.S;
+    g.P = p.P;
+    g.C = p.C;
+    g.seg_len = p.seg_len;
+    g.seg_stride = p.seg_stride;
+    int64_t grid = g.n_tiles;
+    const int64_t cap = 2 * (int64_t)device_cu_count(current_device());
+    if (grid > cap) grid = cap;
+    switch (p.NK) {
+    case 20: return launch_stream_nk<20>(g, (unsigned)grid, p.smem, stream);
+    case 24: return launch_stream_nk<24>(g, (unsigned)grid, p.smem, stream);
+    case 28: return launch_stream_nk<28>(g, (unsigned)grid, p.smem, stream);
+    case 36: return launch_stream_nk<36>(g, (unsigned)grid, p.smem, stream);
+    default: return fail(AF_ERR_UNSUPPORTED, "no streamed banded kernel for NK=%d", p.NK);
+    }
+}
+}  // namespace
 
 af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int64_t x_abs0,
                  int64_t x_len, int64_t x_stride, float* y_dev, int64_t y_stride, int64_t m0,
@@ -661,6 +938,10 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
     if (x_len * p.ch >= (int64_t)kMaxClip)
         return fail(AF_ERR_UNSUPPORTED, "clips of %lld samples are beyond the banded kernel's 32-bit offsets",
                     (long long)x_len);
+    if (p.streamed) {
+        if (accumulate) return fail(AF_ERR_UNSUPPORTED, "banded::launch: the streamed kernel does not accumulate");
+        return launch_stream(p, afrag_dev, x_dev, x_abs0, x_len, x_stride, y_dev, y_stride, m0, n_out, n_clips, stream);
+    }
     Geom g{};
     g.x = x_dev;
     g.y = y_dev;

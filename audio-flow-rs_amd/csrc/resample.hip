@@ -217,7 +217,7 @@ af_status launch(const Design& d, const float* x_dev, int64_t x_abs0, int64_t x_
                  hipStream_t stream)
 {
     if (n_out <= 0 || n_clips <= 0) return AF_OK;
-    if (banded::fits(d.plan, x_len))
+    if (banded::fits(d.plan, x_len) && !debug_knob(kKnobBandedOff))      // (the switch also works on a cached design)
         return banded::launch(d.plan, d.d_afrag.as<float>(), x_dev, x_abs0, x_len, x_stride, y_dev,
                               y_stride, m0, n_out, n_clips, stream);
     if (!d.valu_ok)

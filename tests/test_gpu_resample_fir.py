@@ -37,6 +37,32 @@ def test_resample_batch_vs_oracle(af, po, fi, fo, n):
         assert np.linalg.norm(y[i] - ref) <= TOL * max(np.linalg.norm(ref), 1e-30) + 1e-12
 
 
+@pytest.mark.parametrize("fi,fo", [(48000, 44100), (44100, 48000), (48000, 22050), (16000, 44100), (96000, 44100),
+                                   (44100, 32000)])
+@pytest.mark.parametrize("n", [2559, 81920 + 5, 200003])
+def test_resample_many_block_matrices_vs_oracle(af, po, fi, fo, n):
+    """Ratios whose L has no factor in common with 16 need L (147, 441, 320 ...) block matrices: the streamed
+    banded kernel (tiles = a range of matrices x 32 block periods; 48 -> 44.1 k: 2560 input samples per period,
+    81 920 per tile).  Lengths below one period, just past one tile and over several tiles."""
+    import ctypes as C
+    info = (C.c_int32 * 12)()
+    L, M = po.resample_ratio(fi, fo)
+    clips = np.stack([synth_clip(150 + i, n, 1, fi) for i in range(2)])
+    y = af.resample_batch(clips, fi, fo)
+    assert y.shape == (2, po.resample_out_len(n, L, M))
+    for i in range(2):
+        ref = po.resample(clips[i], fi, fo)
+        assert np.linalg.norm(y[i] - ref) <= TOL * max(np.linalg.norm(ref), 1e-30) + 1e-12
+    # and against the thread-per-output kernel it replaces (different summation order: tolerance, not bits)
+    lib = af.library()
+    try:
+        assert lib.af_debug_set(b"banded.off", 1) == 0
+        y2 = af.resample_batch(clips, fi, fo)
+    finally:
+        lib.af_debug_set(b"banded.off", 0)
+    assert np.linalg.norm(y - y2) <= 2e-6 * np.linalg.norm(y2)
+
+
 def test_resample_reference_surface(af):
     r = af.AudioResampler.new(48000, 16000)                      # resampler.rs:192-198
     assert r.input_rate() == 48000 and r.output_rate() == 16000 and r.needs_resampling()
@@ -49,9 +75,9 @@ def test_resample_reference_surface(af):
     assert af.AudioResampler.create_48k_to_16k().needs_resampling()   # :60-62
 
 
-@pytest.mark.parametrize("fi,fo", [(48000, 16000), (44100, 16000), (16000, 48000)])
+@pytest.mark.parametrize("fi,fo", [(48000, 16000), (44100, 16000), (16000, 48000), (48000, 44100), (16000, 44100)])
 def test_streaming_equals_one_shot_bit_exact(af, po, fi, fo):
-    x = synth_clip(60, 10007, 1, fi)
+    x = synth_clip(60, 10007 if fo != 44100 else 100003, 1, fi)
     one = af.resample_batch(x, fi, fo)[0]
     r = af.AudioResampler.new(fi, fo)
     rng = np.random.default_rng(1)
