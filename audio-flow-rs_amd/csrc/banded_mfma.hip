@@ -44,12 +44,19 @@ __device__ __forceinline__ int w_of(int t, int g4, int nk)
     return t < 16 * full ? 64 * (t / 16) + (t % 16) + 16 * g4 : 64 * full + (t - 16 * full) + tailq * g4;
 }
 
+// quads: the streamed kernel's table, [nb][NK / 4][64][4] (a lane's four consecutive steps are one 16-byte load)
 __global__ void build_afrag_kernel(const float* __restrict__ proto, float* __restrict__ afrag,
-                                   uint32_t L, uint32_t M, int T, int nb, int nk)
+                                   uint32_t L, uint32_t M, int T, int nb, int nk, int quads)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nb * nk * 64) return;
-    const int lane = idx & 63, t = (idx >> 6) % nk, p = (idx >> 6) / nk;
+    int lane = idx & 63, t = (idx >> 6) % nk;
+    const int p = (idx >> 6) / nk;
+    if (quads) {                                   // idx = ((p * nk / 4 + t4) * 64 + lane) * 4 + j
+        const int in_p = idx - p * nk * 64;
+        t = 4 * (in_p / 256) + (in_p & 3);
+        lane = (in_p >> 2) & 63;
+    }
     const int i = lane & 15, g4 = lane >> 4;
     const uint64_t r0 = ((uint64_t)16 * p * M) % L;
     const uint64_t pos = r0 + (uint64_t)i * M;           // = r_i + d_i L
@@ -296,12 +303,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g4 = lane >> 4;
     const uint32_t tiles_per_clip = (uint32_t)(g.n_pg * g.n_pr), n_tiles = (uint32_t)g.n_tiles;
-    const bool first = tid < g.seg_len;                             // seg_len <= 512: one sample per thread and segment
+    // x staging: a thread takes the sample pair (2 h, 2 h + 1), h = tid % 256, of every second segment (the upper
+    // half of the workgroup the odd ones): 8-byte requests halve the vector-memory instructions of a tile, and the
+    // two ds_write_b32 per pair are 2-way bank conflicts at most (free for stores)
+    // The pair grid is anchored at an EVEN sample of the clip (a pair that straddled sample 0 would have a wrapped
+    // byte offset and be dropped whole by the range check): when a tile's first sample is odd the pairs start one
+    // sample early (sh = 1); segments keep one lead-in word for that sample.
+    const int half = tid >> 8, pair = tid & 255;
 
     constexpr uint32_t kOob = 0xFFF00000u;
+    constexpr int kLoads = kSegs / 2;
     float pf[kSegs];
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff;
+    int sh = 0;                                                     // of the tile whose x is in flight (wave-uniform)
     // tile -> (clip, period group, matrix range); ranges vary fastest: neighbouring ranges share their halo in L2
     auto prep_tile = [&](uint32_t tile, bool live) {
         const uint32_t clip = tile / tiles_per_clip, r = tile - clip * tiles_per_clip;
@@ -310,58 +325,89 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int64_t base = pg * (int64_t)kSegs * g.S + sload_int(g.qtab, p0) + g.lo_off - g.x_abs0;
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride), 0,
                                                  (int)(uint32_t)(g.x_len * 4), 0x00020000);
-        voff = live && first ? ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * 4u : kOob;
+        sh = (int)(base & 1);
+        const bool first = 2 * pair < g.seg_len + sh;               // seg_len <= 511
+        voff = live && first ? ((uint32_t)(base - sh) + (uint32_t)(2 * pair + half * g.S + opaque_zero())) * 4u : kOob;
     };
-    auto issue_load = [&](int sgm) {
-        pf[sgm] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff + (uint32_t)(sgm * g.S) * 4u), 0, 0));
+    auto issue_load = [&](int i) {                                  // segment 2 i + half
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 v = __builtin_bit_cast(
+            f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff + (uint32_t)(2 * i * g.S) * 4u), 0, 0));
+        // (everything in the VECTOR offset: the scalar offset operand is added behind the hardware's range check)
+        pf[2 * i] = v[0];
+        pf[2 * i + 1] = v[1];
     };
 
     float a[2][NK];                                                 // this matrix, the next one
+    static_assert(NK % 4 == 0, "fragment quads");
     auto load_a = [&](int slot, int p) {
-        const float* ap = g.afrag + ((size_t)p * NK) * 64 + lane + opaque_zero();
+        const f32x4* ap = reinterpret_cast<const f32x4*>(g.afrag) + ((size_t)p * (NK / 4)) * 64 + lane + opaque_zero();
 #pragma unroll
-        for (int t = 0; t < NK; ++t) a[slot][t] = ap[t * 64];
+        for (int t4 = 0; t4 < NK / 4; ++t4) {
+            const f32x4 v = ap[t4 * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[slot][4 * t4 + j] = v[j];
+        }
+    };
+
+    // first matrix range of a tile
+    auto range_of = [&](uint32_t t, int& p0, int& p_end) {
+        const uint32_t r = t % tiles_per_clip;
+        p0 = (int)(r % (uint32_t)g.n_pr) * g.P;
+        p_end = p0 + g.P < g.nb ? p0 + g.P : g.nb;
     };
 
     uint32_t tile = blockIdx.x;
     if (tile < n_tiles) {
         prep_tile(tile, true);
 #pragma unroll
-        for (int sgm = 0; sgm < kSegs; ++sgm) issue_load(sgm);
+        for (int i = 0; i < kLoads; ++i) issue_load(i);
+        int p0, p_end;
+        range_of(tile, p0, p_end);
+        if (p0 + wave < p_end) load_a(0, p0 + wave);
     }
     for (; tile < n_tiles; tile += gridDim.x) {
         const uint32_t clip = tile / tiles_per_clip, r = tile - clip * tiles_per_clip;
         const int64_t pg = g.pg0 + r / (uint32_t)g.n_pr;
-        const int p0 = (int)(r % (uint32_t)g.n_pr) * g.P;
-        const int p_end = p0 + g.P < g.nb ? p0 + g.P : g.nb;
-        if (p0 + wave < p_end) load_a(0, p0 + wave);                // under the barrier and the LDS fill
+        int p0, p_end;
+        range_of(tile, p0, p_end);
+        // this wave's first matrix of the NEXT tile: requested under this tile's last chains (slot 0 is where
+        // every tile starts), so that no tile begins by waiting for an L2 round trip
+        const bool live = tile + gridDim.x < n_tiles;
+        int np0 = 0, np_end = 0;
+        if (live) range_of(tile + gridDim.x, np0, np_end);
+        const bool next_has = live && np0 + wave < np_end;
         __syncthreads();                                            // readers of the previous tile done
-        if (first) {
-            float* dst = xs + tid + opaque_zero();
+        if (2 * pair < g.seg_len + sh) {
+            float* dst = xs + 1 - sh + 2 * pair + half * g.seg_stride + opaque_zero();
 #pragma unroll
-            for (int sgm = 0; sgm < kSegs; ++sgm) dst[sgm * g.seg_stride] = pf[sgm];
+            for (int i = 0; i < kLoads; ++i) {
+                dst[2 * i * g.seg_stride] = pf[2 * i];
+                dst[2 * i * g.seg_stride + 1] = pf[2 * i + 1];
+            }
         }
         __syncthreads();
-        {
-            const bool live = tile + gridDim.x < n_tiles;
-            prep_tile(live ? tile + gridDim.x : tile, live);
-        }
+        prep_tile(live ? tile + gridDim.x : tile, live);
         float* yc = g.y + (int64_t)clip * g.y_stride - g.m0;        // where absolute output 0 of the clip would be
         const int q0 = sload_int(g.qtab, p0);
-        // one chain: matrix p (fragments in a[slot]) times the 16 periods of column set cs; the first chain of a
-        // wave also carries the next tile's x requests between its steps
-        auto chain = [&](int p, auto slot_c, int cs, auto with_loads) {
+        // one chain pair: matrix p (fragments in a[SLOT]) times the 16 periods of column set 0 and of column set 1, two
+        // independent accumulators fed by the same fragment registers; a wave's first pair also carries the next
+        // tile's x requests between its steps
+        static_assert(C == 2, "chain pairs");
+        auto chain = [&](int p, auto slot_c, auto with_loads) {
             constexpr bool LOADS = decltype(with_loads)::value;
             constexpr int SLOT = decltype(slot_c)::value;
             const int qrel = sload_int(g.qtab, p) - q0;             // window start of matrix p inside a segment
-            const float* bfull = xs + (cs * 16 + col) * g.seg_stride + qrel + 16 * g4;
-            const float* btail = xs + (cs * 16 + col) * g.seg_stride + qrel + TAILQ * g4 + 64 * FULL;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* bfull = xs + 1 + col * g.seg_stride + qrel + 16 * g4;       // (+ 1: the lead-in word)
+            const float* btail = xs + 1 + col * g.seg_stride + qrel + TAILQ * g4 + 64 * FULL;
+            const int set1 = 16 * g.seg_stride;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             constexpr int kAhead = 3;
-            float w0[kAhead + 1];
+            float w0[kAhead + 1], w1[kAhead + 1];
             auto read_b = [&](int t) {
-                w0[t % (kAhead + 1)] = t < 16 * FULL ? bfull[64 * (t / 16) + (t % 16)] : btail[t - 16 * FULL];
+                const float* src = t < 16 * FULL ? bfull + 64 * (t / 16) + (t % 16) : btail + (t - 16 * FULL);
+                w0[t % (kAhead + 1)] = src[0];
+                w1[t % (kAhead + 1)] = src[set1];
             };
 #pragma unroll
             for (int t = 0; t < kAhead && t < NK; ++t) read_b(t);
@@ -369,51 +415,59 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int t = 0; t < NK; ++t) {
                 if (t + kAhead < NK) read_b(t + kAhead);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SLOT][t], w0[t % (kAhead + 1)], acc, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SLOT][t], w0[t % (kAhead + 1)], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SLOT][t], w1[t % (kAhead + 1)], acc1, 0, 0, 0);
                 if (LOADS) {
                     constexpr int kSpan = (NK + 1) / 2;
                     if (t < kSpan) {
 #pragma unroll
-                        for (int s2 = (kSegs * t) / kSpan; s2 < (kSegs * (t + 1)) / kSpan; ++s2) issue_load(s2);
+                        for (int s2 = (kLoads * t) / kSpan; s2 < (kLoads * (t + 1)) / kSpan; ++s2) issue_load(s2);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             // block b = period * nb + p of column `col`: rows 4 g4 .. 4 g4 + 3
-            const int64_t period = pg * kSegs + cs * 16 + col;
-            const int64_t m = 16 * (period * g.nb + p) + 4 * g4;
-            float* o = yc + m;
-            if (m >= g.m0 && m + 4 <= g.m0 + g.n_out && ((reinterpret_cast<uintptr_t>(o) >> 2) & 3) == 0) {
-                *reinterpret_cast<f32x4*>(o) = acc;
-            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (m + j >= g.m0 && m + j < g.m0 + g.n_out) o[j] = acc[j];
+            for (int cs = 0; cs < 2; ++cs) {
+                const f32x4 acc = cs ? acc1 : acc0;
+                const int64_t period = pg * kSegs + cs * 16 + col;
+                const int64_t m = 16 * (period * g.nb + p) + 4 * g4;
+                float* o = yc + m;
+                if (m >= g.m0 && m + 4 <= g.m0 + g.n_out && ((reinterpret_cast<uintptr_t>(o) >> 2) & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(o) = acc;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (m + j >= g.m0 && m + j < g.m0 + g.n_out) o[j] = acc[j];
+                }
             }
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
-        int p = p0 + wave;
-        if (p < p_end) {
-            // fragment slots alternate at compile time (a runtime slot index would cost a select per MFMA operand)
-            if (p + 8 < p_end) load_a(1, p + 8);                    // next matrix: lands under this one's chains
-            chain(p, S0{}, 0, std::true_type{});
+        // matrices p0 + wave + 8 i, i < n_m, fragment slots alternating at compile time (a runtime slot index would
+        // cost a select per MFMA operand); the last one shares its chains with the next tile's first fragments
+        const int n_m = p0 + wave < p_end ? (p_end - p0 - wave + 7) / 8 : 0;
+        if (n_m == 0) {
 #pragma unroll
-            for (int cs = 1; cs < C; ++cs) chain(p, S0{}, cs, std::false_type{});
-            for (p += 8; p < p_end;) {
-                if (p + 8 < p_end) load_a(0, p + 8);
+            for (int s2 = 0; s2 < kLoads; ++s2) issue_load(s2);     // a wave without a matrix in this range
+            if (next_has) load_a(0, np0 + wave);
+        }
 #pragma unroll
-                for (int cs = 0; cs < C; ++cs) chain(p, S1{}, cs, std::false_type{});
-                p += 8;
-                if (p >= p_end) break;
-                if (p + 8 < p_end) load_a(1, p + 8);
+        for (int i = 0; i < 4; ++i) {                                // P <= 32: at most four matrices per wave
+            if (i < n_m) {
+                const int p = p0 + wave + 8 * i;
+                const bool last = i + 1 == n_m;
+                if (!last) load_a((i & 1) ^ 1, p + 8);
+                else if (next_has) load_a((i & 1) ^ 1, np0 + wave);  // into the free slot
+                if (i == 0) chain(p, S0{}, std::true_type{});
+                else if ((i & 1) == 0) chain(p, S0{}, std::false_type{});
+                else chain(p, S1{}, std::false_type{});
+                if (last && next_has && (i & 1) == 0) {
+                    // the free slot was 1: every tile starts in slot 0
 #pragma unroll
-                for (int cs = 0; cs < C; ++cs) chain(p, S0{}, cs, std::false_type{});
-                p += 8;
+                    for (int t = 0; t < NK; ++t) a[0][t] = a[1][t];
+                }
             }
-        } else {
-#pragma unroll
-            for (int s2 = 0; s2 < kSegs; ++s2) issue_load(s2);      // a wave without a matrix in this range
         }
     }
 }
@@ -793,7 +847,7 @@ Plan make_stream_plan(Plan p, uint64_t nb, uint64_t S)
             const uint64_t last = std::min<uint64_t>(p0 + P, nb) - 1;
             span = std::max(span, q16(last) - q16(p0));
         }
-        if (span + 4 * nk <= 512) { best = P; best_len = (int)span + 4 * nk; break; }
+        if (span + 4 * nk <= 511) { best = P; best_len = (int)span + 4 * nk; break; }
     }
     if (!best) return p;
     p.nb = (int)nb;
@@ -806,7 +860,7 @@ Plan make_stream_plan(Plan p, uint64_t nb, uint64_t S)
     p.wpp = 1;
     p.G = 0;
     p.seg_len = best_len;
-    p.seg_stride = best_len | 1;
+    p.seg_stride = (best_len + 2) | 1;         // odd (bank-conflict-free operand reads); a lead-in word and a pair's odd end
     p.out_per_tile = (int64_t)256 * best * kStreamC;
     p.smem = (size_t)16 * kStreamC * p.seg_stride * sizeof(float);
     p.ok = true;
@@ -866,7 +920,7 @@ af_status build_afrag(const Plan& p, const float* proto_dev, float* afrag_dev, h
 {
     const int n = (int)p.afrag_floats();
     hipLaunchKernelGGL(build_afrag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, proto_dev,
-                       afrag_dev, p.L, p.M, p.T, p.nb, p.NK);
+                       afrag_dev, p.L, p.M, p.T, p.nb, p.NK, p.streamed ? 1 : 0);
     AF_HIP(hipGetLastError());
     if (p.streamed) {
         hipLaunchKernelGGL(build_qtab_kernel, dim3((p.nb + 256) / 256), dim3(256), 0, stream,
@@ -1115,7 +1169,7 @@ af_status build_fused_fir_afrag(const FusedPlan& f, const float* taps_dev, float
 {
     const int n = f.NKB * 64;
     hipLaunchKernelGGL(build_afrag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, taps_dev, afrag_dev, 1u, 1u,
-                       f.K, 1, f.NKB);
+                       f.K, 1, f.NKB, 0);
     AF_HIP(hipGetLastError());
     return AF_OK;
 }

@@ -1,0 +1,122 @@
+"""Condense gpurun_out/r03p (scripts/profile_r03.sh) into the committed evidence under profiles/:
+   r03_*.txt copies, profiles/pmc_traffic.json (calibrated HBM bytes per launch = bench.py's roofline.traffic) and
+   profiles/pmc_resources.json (busy fractions of the other resources = bench.py's roofline.other).
+   python3 scripts/make_pmc_json.py [gpurun_out/r03p]"""
+import csv, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03p")
+dst = os.path.join(ROOT, "profiles")
+ROUND = 3
+
+
+def table(name):
+    """{kernel: {counter: mean}} of a pmc_*.txt summary"""
+    out = {}
+    path = os.path.join(src, name)
+    if not os.path.exists(path):
+        return out
+    for ln in open(path):
+        if ln.startswith("#") or ln.startswith("kernel,"):
+            continue
+        k, c, n, mean, lo, hi = ln.strip().rsplit(",", 5)
+        out.setdefault(k, {})[c] = float(mean)
+    return out
+
+
+def first(tab, key):
+    for k, v in tab.items():
+        if key in k:
+            return k, v
+    raise SystemExit(f"no kernel matching {key} in the table")
+
+
+copies = {"kernel_stats.txt": "r03_kernel_stats.txt", "pmc_fetch.txt": "r03_pmc_fetch.txt", "pmc_write.txt": "r03_pmc_write.txt",
+          "pmc_sq.txt": "r03_pmc_sq.txt", "pmc_sq2.txt": "r03_pmc_sq2.txt", "pmc_cal_fetch.txt": "r03_pmc_cal_fetch.txt",
+          "pmc_cal_write.txt": "r03_pmc_cal_write.txt", "bench.json": "r03_bench.json",
+          "bench_driver_args.json": "r03_bench_driver_args.json", "chain_kernel_stats.txt": "r03_chain_kernel_stats.txt",
+          "pmc_chain_fetch.txt": "r03_chain_pmc_fetch.txt", "pmc_chain_write.txt": "r03_chain_pmc_write.txt",
+          "pmc_chain_sq.txt": "r03_chain_pmc_sq.txt", "pmc_chain_sq2.txt": "r03_chain_pmc_sq2.txt",
+          "pmc_res_fetch.txt": "r03_res_pmc_fetch.txt", "pmc_res_write.txt": "r03_res_pmc_write.txt",
+          "pmc_res_sq.txt": "r03_res_pmc_sq.txt", "pmc_res_sq2.txt": "r03_res_pmc_sq2.txt",
+          "resample_ratios.json": "r03_resample_ratios.json", "ops.json": "r03_ops.json",
+          "ops_kernel_stats.txt": "r03_ops_kernel_stats.txt"}
+for a, b in copies.items():
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+
+# ---- calibration: af::to_mono2_kernel on 1 GiB in / 0.5 GiB out (scripts/pmc_calibrate.py)
+_, cf = first(table("pmc_cal_fetch.txt"), "to_mono")
+_, cw = first(table("pmc_cal_write.txt"), "to_mono")
+cal_f = cf["FETCH_SIZE"] * 1024 / (1 << 30)          # reported / true
+cal_w = cw["WRITE_SIZE"] * 1024 / (1 << 29)
+kname, f = first(table("pmc_fetch.txt"), "af_features")
+_, w = first(table("pmc_write.txt"), "af_features")
+rd = f["FETCH_SIZE"] * 1024 / cal_f
+wr = w["WRITE_SIZE"] * 1024 / cal_w
+ALG = 256 * 1440000 * 8 + 1439232 * 320
+old = json.load(open(os.path.join(dst, "pmc_traffic.json")))
+traffic = {
+    "round": ROUND, "kernel": kname, "workload": "BASELINE config 2 (256 x 30 s stereo 48 kHz f32 -> 80 mel), one launch",
+    "FETCH_SIZE_kb_raw": f["FETCH_SIZE"], "WRITE_SIZE_kb_raw": w["WRITE_SIZE"],
+    "calibration": {"kernel": "af::to_mono2_kernel on 1 GiB in / 0.5 GiB out (scripts/pmc_calibrate.py)",
+                    "FETCH_SIZE_reported_over_true": round(cal_f, 6), "WRITE_SIZE_reported_over_true": round(cal_w, 6),
+                    "note": "gfx950 FETCH_SIZE tallies 16-B-per-lane coalesced reads at exactly 1/2 (MI355X_MICROARCH.md, HBM); corrected below"},
+    "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
+    "algorithmic_bytes_per_launch": ALG, "traffic_over_algorithmic": round((rd + wr) / ALG, 4),
+    "source": ["profiles/r03_pmc_fetch.txt", "profiles/r03_pmc_write.txt", "profiles/r03_pmc_cal_fetch.txt", "profiles/r03_pmc_cal_write.txt"],
+    "round2": {k: old[k] for k in ("kernel", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch",
+                                   "traffic_over_algorithmic") if k in old},
+    "round1": old.get("round1"), "banded_kernel_config3": old.get("banded_kernel_config3"),
+}
+# chain
+cfch, cwch = table("pmc_chain_fetch.txt"), table("pmc_chain_write.txt")
+if cfch and cwch:
+    kern, tot = {}, 0.0
+    for k in cfch:
+        r_ = cfch[k]["FETCH_SIZE"] * 1024 / cal_f
+        w_ = cwch.get(k, {}).get("WRITE_SIZE", 0.0) * 1024 / cal_w
+        kern[k] = {"FETCH_SIZE_kb_raw": cfch[k]["FETCH_SIZE"], "WRITE_SIZE_kb_raw": cwch.get(k, {}).get("WRITE_SIZE"),
+                   "hbm_read_bytes_per_launch": int(r_), "hbm_write_bytes_per_launch": int(w_)}
+        tot += r_ + w_
+    alg4 = 256 * 1440000 * 8 + 479232 * 320
+    traffic["chain_config4"] = {"workload": "256 x 30 s stereo 48 kHz f32 -> downmix + 48->16 kHz + FIR 129 (one launch) -> STFT -> 80 mel (one launch); scripts/profile_r03.sh",
+                                "kernels": kern, "hbm_bytes_per_pass": int(tot), "algorithmic_bytes_per_pass": alg4,
+                                "traffic_over_algorithmic": round(tot / alg4, 4),
+                                "source": ["profiles/r03_chain_pmc_fetch.txt", "profiles/r03_chain_pmc_write.txt"]}
+rf, rw = table("pmc_res_fetch.txt"), table("pmc_res_write.txt")
+if rf and rw:
+    k, v = first(rf, "banded_stream")
+    r_ = v["FETCH_SIZE"] * 1024 / cal_f
+    # the streamed kernel stages x with 8-byte-per-lane loads and fragments with 16-byte ones: FETCH_SIZE's 1/2 is
+    # calibrated for 16-byte-per-lane streams only, so the read figure is indicative
+    w_ = first(rw, "banded_stream")[1]["WRITE_SIZE"] * 1024 / cal_w
+    alg = 1024 * (1440000 + 1323000) * 4
+    traffic["banded_stream_48k_44k1"] = {"workload": "1024 x 30 s mono 48 kHz -> 44.1 kHz, one launch", "kernel": k,
+                                         "hbm_read_bytes_per_launch_indicative": int(r_), "hbm_write_bytes_per_launch": int(w_),
+                                         "algorithmic_bytes_per_launch": alg,
+                                         "source": ["profiles/r03_res_pmc_fetch.txt", "profiles/r03_res_pmc_write.txt"]}
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+
+# ---- the other resources of the headline kernel (HBM fraction AND VALU / MFMA / LDS fractions)
+_, s1 = first(table("pmc_sq.txt"), "af_features")
+_, s2 = first(table("pmc_sq2.txt"), "af_features")
+cycles = s2["GRBM_GUI_ACTIVE"] / 8.0                   # the counter sums the 8 XCDs
+res = {
+    "round": ROUND, "kernel": kname, "workload": traffic["workload"],
+    "launch_cycles": cycles,
+    "lds_frac": round(s2["SQ_LDS_IDX_ACTIVE"] / 256 / cycles, 4),                  # LDS-array cycles per CU
+    "valu_frac": round(s1["SQ_INSTS_VALU"] * 2 / 1024 / cycles, 4),                 # 2 cycles per wave64 instruction per SIMD
+    "mfma_frac": round(s2["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cycles, 4),          # matrix pipe busy per SIMD
+    "hbm_frac_of_8TBps": None,
+    "counters": {"SQ_LDS_IDX_ACTIVE": s2["SQ_LDS_IDX_ACTIVE"], "SQ_LDS_BANK_CONFLICT": s2["SQ_LDS_BANK_CONFLICT"],
+                 "SQ_INSTS_VALU": s1["SQ_INSTS_VALU"], "SQ_INSTS_LDS": s1["SQ_INSTS_LDS"],
+                 "SQ_VALU_MFMA_BUSY_CYCLES": s2["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": s2["GRBM_GUI_ACTIVE"],
+                 "SQ_WAVE_CYCLES": s1["SQ_WAVE_CYCLES"], "SQ_WAIT_ANY": s1["SQ_WAIT_ANY"],
+                 "SQ_WAIT_INST_ANY": s1["SQ_WAIT_INST_ANY"], "SQ_ACTIVE_INST_ANY": s1["SQ_ACTIVE_INST_ANY"]},
+    "formulas": "lds = SQ_LDS_IDX_ACTIVE / 256 CUs; valu = SQ_INSTS_VALU x 2 cycles / 1024 SIMDs; mfma = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; all over GRBM_GUI_ACTIVE / 8 XCDs of the profiled launch",
+    "source": ["profiles/r03_pmc_sq.txt", "profiles/r03_pmc_sq2.txt"],
+    "note": "recorded by separate rocprofv3 --pmc passes (scripts/profile_r03.sh), not measured by the bench run that quotes it",
+}
+json.dump(res, open(os.path.join(dst, "pmc_resources.json"), "w"), indent=1)
+print(json.dumps({"traffic_over_algorithmic": traffic["traffic_over_algorithmic"], "lds": res["lds_frac"], "valu": res["valu_frac"],
+                  "mfma": res["mfma_frac"]}))
