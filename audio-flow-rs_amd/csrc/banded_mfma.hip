@@ -318,11 +318,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint32_t voff;
     int sh = 0;                                                     // of the tile whose x is in flight (wave-uniform)
     // tile -> (clip, period group, matrix range); ranges vary fastest: neighbouring ranges share their halo in L2
-    auto prep_tile = [&](uint32_t tile, bool live) {
+    auto prep_tile = [&](uint32_t tile, bool live, int q_p0) {          // q_p0 = q(16 p0) of that tile
         const uint32_t clip = tile / tiles_per_clip, r = tile - clip * tiles_per_clip;
         const int64_t pg = g.pg0 + r / (uint32_t)g.n_pr;
-        const int p0 = (int)(r % (uint32_t)g.n_pr) * g.P;
-        const int64_t base = pg * (int64_t)kSegs * g.S + sload_int(g.qtab, p0) + g.lo_off - g.x_abs0;
+        const int64_t base = pg * (int64_t)kSegs * g.S + q_p0 + g.lo_off - g.x_abs0;
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride), 0,
                                                  (int)(uint32_t)(g.x_len * 4), 0x00020000);
         sh = (int)(base & 1);
@@ -357,9 +356,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         p_end = p0 + g.P < g.nb ? p0 + g.P : g.nb;
     };
 
+    // q(16 p) of a tile's range start and of this wave's matrices in it, through the scalar cache -- requested a
+    // whole tile ahead (an s_load consumed where it is issued costs the wave a few hundred cycles per tile)
+    struct TileQ { int q0, q[4]; };
+    auto load_q = [&](uint32_t t) {
+        int p0, p_end;
+        range_of(t, p0, p_end);
+        TileQ v;
+        v.q0 = sload_int(g.qtab, p0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + wave + 8 * i;
+            v.q[i] = sload_int(g.qtab, p < g.nb ? p : g.nb);
+        }
+        return v;
+    };
+
     uint32_t tile = blockIdx.x;
+    TileQ tq{};
     if (tile < n_tiles) {
-        prep_tile(tile, true);
+        tq = load_q(tile);
+        prep_tile(tile, true, tq.q0);
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) issue_load(i);
         int p0, p_end;
@@ -377,6 +394,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         int np0 = 0, np_end = 0;
         if (live) range_of(tile + gridDim.x, np0, np_end);
         const bool next_has = live && np0 + wave < np_end;
+        const TileQ cq = tq;                                        // this tile's; the next tile's are requested now
+        if (live) tq = load_q(tile + gridDim.x);
         __syncthreads();                                            // readers of the previous tile done
         if (2 * pair < g.seg_len + sh) {
             float* dst = xs + 1 - sh + 2 * pair + half * g.seg_stride + opaque_zero();
@@ -387,17 +406,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
         __syncthreads();
-        prep_tile(live ? tile + gridDim.x : tile, live);
+        prep_tile(live ? tile + gridDim.x : tile, live, tq.q0);
         float* yc = g.y + (int64_t)clip * g.y_stride - g.m0;        // where absolute output 0 of the clip would be
-        const int q0 = sload_int(g.qtab, p0);
+        const int q0 = cq.q0;
         // one chain pair: matrix p (fragments in a[SLOT]) times the 16 periods of column set 0 and of column set 1, two
         // independent accumulators fed by the same fragment registers; a wave's first pair also carries the next
         // tile's x requests between its steps
         static_assert(C == 2, "chain pairs");
-        auto chain = [&](int p, auto slot_c, auto with_loads) {
+        auto chain = [&](int p, int qp, auto slot_c, auto with_loads) {   // qp = q(16 p)
             constexpr bool LOADS = decltype(with_loads)::value;
             constexpr int SLOT = decltype(slot_c)::value;
-            const int qrel = sload_int(g.qtab, p) - q0;             // window start of matrix p inside a segment
+            const int qrel = qp - q0;                               // window start of matrix p inside a segment
             const float* bfull = xs + 1 + col * g.seg_stride + qrel + 16 * g4;       // (+ 1: the lead-in word)
             const float* btail = xs + 1 + col * g.seg_stride + qrel + TAILQ * g4 + 64 * FULL;
             const int set1 = 16 * g.seg_stride;
@@ -459,9 +478,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const bool last = i + 1 == n_m;
                 if (!last) load_a((i & 1) ^ 1, p + 8);
                 else if (next_has) load_a((i & 1) ^ 1, np0 + wave);  // into the free slot
-                if (i == 0) chain(p, S0{}, std::true_type{});
-                else if ((i & 1) == 0) chain(p, S0{}, std::false_type{});
-                else chain(p, S1{}, std::false_type{});
+                if (i == 0) chain(p, cq.q[0], S0{}, std::true_type{});
+                else if ((i & 1) == 0) chain(p, cq.q[i], S0{}, std::false_type{});
+                else chain(p, cq.q[i], S1{}, std::false_type{});
                 if (last && next_has && (i & 1) == 0) {
                     // the free slot was 1: every tile starts in slot 0
 #pragma unroll
