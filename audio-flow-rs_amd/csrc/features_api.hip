@@ -692,30 +692,47 @@ af_status af_features_run(af_features* p, const void* pcm, size_t pcm_len, float
         AF_HIP(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
     }
     while (p->ev_in.size() < chunks.size()) {
+        // (the pair is pushed only when both exist: the two vectors stay the same length)
         hipEvent_t a = nullptr, b = nullptr;
         AF_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        if (hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+            (void)hipEventDestroy(a);
+            return fail(AF_ERR_HIP, "hipEventCreateWithFlags failed");
+        }
         p->ev_in.push_back(a);
-        AF_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
         p->ev_run.push_back(b);
     }
     const size_t row = af_features_row_len(p);
     const char* src = static_cast<const char*>(pcm);
-    for (size_t k = 0; k < chunks.size(); ++k) {
+    // The first error stops the loop, but nothing returns before the three streams have drained: the copies still in
+    // flight read and write the CALLER's buffers, which are likely to be freed after an error.
+    af_status st = AF_OK;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && st == AF_OK)
+            st = fail(e == hipErrorOutOfMemory ? AF_ERR_OUT_OF_MEMORY : AF_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    for (size_t k = 0; k < chunks.size() && st == AF_OK; ++k) {
         const Chunk& c = chunks[k];
-        AF_HIP(hipMemcpyAsync(p->d_pcm.as<char>() + c.f0 * bpf, src + c.f0 * bpf, (size_t)(c.f1 - c.f0) * bpf,
-                              hipMemcpyHostToDevice, p->s_in));
-        AF_HIP(hipEventRecord(p->ev_in[k], p->s_in));
-        AF_HIP(hipStreamWaitEvent(p->s_run, p->ev_in[k], 0));
-        AF_TRY(run_device_impl(p, p->d_pcm.p, p->d_mel.as<float>(), p->s_run, c.u0, c.u1 - c.u0, c.f0, c.f1));
-        AF_HIP(hipEventRecord(p->ev_run[k], p->s_run));
-        AF_HIP(hipStreamWaitEvent(p->s_out, p->ev_run[k], 0));
+        if (!hip_ok(hipMemcpyAsync(p->d_pcm.as<char>() + c.f0 * bpf, src + c.f0 * bpf, (size_t)(c.f1 - c.f0) * bpf,
+                                   hipMemcpyHostToDevice, p->s_in), "hipMemcpyAsync") ||
+            !hip_ok(hipEventRecord(p->ev_in[k], p->s_in), "hipEventRecord") ||
+            !hip_ok(hipStreamWaitEvent(p->s_run, p->ev_in[k], 0), "hipStreamWaitEvent"))
+            break;
+        const af_status ks = run_device_impl(p, p->d_pcm.p, p->d_mel.as<float>(), p->s_run, c.u0, c.u1 - c.u0, c.f0, c.f1);
+        if (ks != AF_OK) { st = ks; break; }
+        if (!hip_ok(hipEventRecord(p->ev_run[k], p->s_run), "hipEventRecord") ||
+            !hip_ok(hipStreamWaitEvent(p->s_out, p->ev_run[k], 0), "hipStreamWaitEvent"))
+            break;
         if (c.r1 > c.r0)
-            AF_HIP(hipMemcpyAsync(mel + (size_t)c.r0 * row, p->d_mel.as<float>() + (size_t)c.r0 * row,
-                                  (size_t)(c.r1 - c.r0) * row * sizeof(float), hipMemcpyDeviceToHost, p->s_out));
+            hip_ok(hipMemcpyAsync(mel + (size_t)c.r0 * row, p->d_mel.as<float>() + (size_t)c.r0 * row,
+                                  (size_t)(c.r1 - c.r0) * row * sizeof(float), hipMemcpyDeviceToHost, p->s_out),
+                   "hipMemcpyAsync");
     }
-    AF_HIP(hipStreamSynchronize(p->s_out));
-    AF_HIP(hipStreamSynchronize(p->s_run));
-    return AF_OK;
+    (void)hipStreamSynchronize(p->s_in);
+    (void)hipStreamSynchronize(p->s_run);
+    hip_ok(hipStreamSynchronize(p->s_out), "hipStreamSynchronize");
+    return st;
 }
 
 af_status af_pipeline_run(const af_batch_desc* batch, const void* pcm, size_t pcm_len, float* out,
