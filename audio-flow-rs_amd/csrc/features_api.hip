@@ -54,7 +54,8 @@ struct af_features {
     int64_t total_pcm_frames = 0;
     int64_t total_frames = 0;
     int64_t total_units = 0;
-    bool offsets_aligned = false;
+    bool offsets_aligned = false;    // every clip base on a 16-byte boundary (the general kernel's vector loads)
+    bool offsets_aligned4 = false;   // ... on a 4-byte boundary (enough for the hop-256 kernel)
     // staging for the host-buffer entry point
     DevBuf d_pcm, d_mel;
     DevBuf d_stamps;                 // diagnostics: per-phase cycle sums (af_features_debug_stamps)
@@ -283,6 +284,10 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     unit_off[0] = 0;
     const size_t bpf = kernel_bytes_per_frame(p->cfg);
     bool aligned = (p->cfg.hop * bpf) % 16 == 0;
+    // the hop-256 kernel's 16-byte global loads only need DWORD-aligned addresses (global memory is in unaligned
+    // access mode): every clip base a multiple of 4 bytes is enough -- i.e. everything but i16 mono clips that
+    // start on an odd frame
+    bool aligned4 = true;
     int64_t end = 0;
     for (size_t c = 0; c < n; ++c) {
         if (start[c] < 0 || len[c] < 0) return fail(AF_ERR_INVALID_ARG, "negative clip start or length");
@@ -292,6 +297,7 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
         out_off[c + 1] = out_off[c] + nf;
         unit_off[c + 1] = unit_off[c] + (nf + kFramesPerIter - 1) / kFramesPerIter;
         if ((start[c] * (int64_t)bpf) % 16 != 0) aligned = false;
+        if ((start[c] * (int64_t)bpf) % 4 != 0) aligned4 = false;
         end = std::max(end, start[c] + len[c]);
     }
     p->h_start.assign(t_start, t_start + n);
@@ -306,12 +312,13 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     p->total_frames = out_off[n];
     p->total_units = unit_off[n];
     p->offsets_aligned = aligned;
+    p->offsets_aligned4 = aligned4;
     if (p->cfg.channels > 2) AF_TRY(p->d_mono.reserve((size_t)end * sizeof(float) + 64));
     AF_TRY(p->d_tables.reserve((tab.size() ? tab.size() : 1) * sizeof(int64_t)));
     AF_HIP(hipMemcpy(p->d_tables.p, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     // hop-256 kernel: one 32-byte record per 16-frame unit
     p->units_ok = false;
-    if (p->plan8.n_waves == v2::kW && aligned && p->total_units > 0 && p->total_units < (1ll << 26)) {
+    if (p->plan8.n_waves == v2::kW && aligned4 && p->total_units > 0 && p->total_units < (1ll << 26)) {
         std::vector<v2::UnitDesc> units((size_t)p->total_units + 1);   // + one zero record: the kernel reads a unit ahead
         const bool sep = p->cfg.channel_mode == AF_CH_SEPARATE;
         size_t k = 0;
@@ -607,8 +614,8 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
     const int wg_knob = p->opt_wg_per_cu >= 0 ? p->opt_wg_per_cu : debug_knob(kKnobFeaturesWgPerCu);
     const int general = p->opt_kernel >= 0 ? p->opt_kernel : debug_knob(kKnobFeaturesKernel);
-    if (p->units_ok && prm.aligned16 && !general) {
-        // hop 256, 16-byte aligned clips: the 8-wave kernel, two workgroups per CU
+    if (p->units_ok && p->offsets_aligned4 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 == 0 && !general) {
+        // hop 256, dword-aligned clips: the 8-wave kernel, two workgroups per CU
         v2::Params q{};
         q.pcm = pcm_dev;
         q.out = mel_dev;

@@ -308,3 +308,37 @@ def test_one_shot_pipeline_run(af, po):
     with pytest.raises(af.AudioError) as e:
         pipe.run(pcm[:-2])
     assert e.value.status == af._ffi.AF_ERR_BUFFER_TOO_SMALL
+
+
+@pytest.mark.parametrize("ch,fmt", [(2, 0), (1, 0), (2, 1), (1, 1)])
+def test_hop256_kernel_on_clips_off_16_byte_boundaries(af, po, ch, fmt):
+    """Clip bases that are only dword-aligned (odd frame offsets) stay on the hop-256 kernel (its 16-byte global loads
+    need 4-byte alignment only); i16 mono clips on odd frames are the one case left to the general kernel.  Rows equal
+    the general kernel's within rounding and the oracle's within tolerance; a clip's rows do not depend on where it
+    starts."""
+    import ctypes as C
+    lens = [30001, 5003, 12345, 40007]
+    clips = [synth_clip(500 + i, n, ch, 48000) for i, n in enumerate(lens)]
+    if fmt:
+        clips = [np.round(c * 32767.0).astype(np.int16) for c in clips]
+    pcm = np.concatenate(clips)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    pipe = af.FeaturePipeline(channels=ch, sample_format=fmt)
+    pipe.set_batch(off)
+    got = pipe.run(pcm)
+    name = af.library().af_features_kernel_name().decode()
+    lib = af.library()
+    assert lib.af_features_set_option(pipe._h, b"kernel", 1) == 0
+    gen = pipe.run(pcm)
+    assert frame_rel_err(got, gen) < 2e-6
+    row = 0
+    for x, n in zip(clips, lens):
+        nf = pipe.n_frames(n)
+        xf = x.astype(np.float32) / np.float32(32768.0) if fmt else x
+        assert frame_rel_err(got[row:row + nf], po.features(xf, ch, 48000.0)) < 1e-5
+        # the same clip alone, at offset 0 (16-byte aligned): identical rows on the hop-256 kernel
+        alone = af.FeaturePipeline(channels=ch, sample_format=fmt)
+        alone.set_batch_uniform(1, n)
+        if not (ch == 1 and fmt == 1):
+            assert np.array_equal(alone.run(x), got[row:row + nf])
+        row += nf
