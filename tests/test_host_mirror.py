@@ -146,14 +146,21 @@ def test_banded_plan_invariants(af):
     p = plan(48000, 16000)
     assert (p["ok"], p["L"], p["M"], p["nb"], p["S"], p["NK"], p["nwaves"]) == (1, 1, 3, 1, 48, 28, 8)
     assert plan(48000, 16000, 2)["ok"] == 1 and plan(44100, 16000, 2)["ok"] == 0
-    assert plan(48000, 44100)["ok"] == 0                      # 147 block matrices: VALU kernel
+    # more than 16 block matrices: the streamed form (G = 0 marks it): 8 waves, matrices fetched per tile, a tile =
+    # a range of matrices x 32 block periods, one LDS segment (<= 511 samples, odd stride) per period
+    for fi, fo, nb, S, nk in [(48000, 44100, 147, 2560, 24), (16000, 44100, 441, 2560, 20), (48000, 22050, 147, 5120, 28)]:
+        p = plan(fi, fo)
+        assert (p["ok"], p["nb"], p["S"], p["NK"], p["G"], p["nwaves"]) == (1, nb, S, nk, 0, 8)
+        assert p["seg_len"] <= 511 and p["seg_stride"] % 2 == 1 and p["seg_stride"] >= p["seg_len"] + 2
+        assert p["smem"] == 32 * p["seg_stride"] * 4 <= 80 * 1024
+        assert plan(fi, fo, 2)["ok"] == 0                     # stereo staging: resident matrices only
     short = 0
     for fi, fo in [(44100, 16000), (48000, 16000), (16000, 48000), (8000, 16000), (22050, 16000),
                    (44100, 48000), (32000, 16000), (96000, 16000), (11025, 16000), (16000, 8000),
                    (48000, 45000), (16000, 15000), (8000, 15000), (24000, 45000)]:
         for ch in (1, 2):
             p = plan(fi, fo, ch)
-            if not p["ok"]:
+            if not p["ok"] or p["G"] == 0:                    # not covered / the streamed form (checked above)
                 continue
             g = gcd(fi, fo)
             L, M = fo // g, fi // g
