@@ -29,12 +29,13 @@ from .errors import AudioError
 from .audio import (AudioFrame, AudioResampler, BatchResampler, ChainPipeline, ChainStream, FeaturePipeline, FeatureStream, FirFilter,
                     MelSpectrogram, MessageBuilder, RingBuffer, VadConfig, VadLevel, VadState,
                     VoiceActivityDetector, device_count, library, quantize_pcm16, to_mono,
-                    vad_energy, resample_batch, fir_batch, AudioLevel, level_meter, Stft, MelFilterbank, resample_stereo_batch)
+                    vad_energy, resample_batch, fir_batch, AudioLevel, level_meter, Stft, MelFilterbank, resample_stereo_batch,
+                    resample_cubic_batch)
 
 __all__ = [
     "AudioError", "AudioFrame", "AudioResampler", "BatchResampler", "ChainPipeline", "ChainStream", "FeaturePipeline", "FeatureStream",
     "FirFilter",
     "MelSpectrogram", "MessageBuilder", "RingBuffer", "VadConfig", "VadLevel", "VadState",
     "VoiceActivityDetector", "device_count", "library", "quantize_pcm16", "to_mono", "vad_energy",
-    "resample_batch", "fir_batch", "AudioLevel", "level_meter", "Stft", "MelFilterbank", "resample_stereo_batch",
+    "resample_batch", "fir_batch", "AudioLevel", "level_meter", "Stft", "MelFilterbank", "resample_stereo_batch", "resample_cubic_batch",
 ]

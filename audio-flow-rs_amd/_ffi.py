@@ -103,6 +103,8 @@ SIGNATURES = {
     "af_vad_detect_frames": (_st, [_vp, _vp, _sz, _sz, _vp]),
     "af_vad_reset": (None, [_vp]),
     "af_resample_release_staging": (None, []),
+    "af_resample_cubic_batch": (_st, [_u32, _u32, _vp, _sz, _sz, _vp, _sz]),
+    "af_resample_cubic_batch_device": (_st, [_u32, _u32, _vp, _sz, _sz, _vp, _vp]),
     "af_vad_detect_batch_device": (_st, [C.POINTER(VadConfig), _vp, _sz, _sz, _sz, _vp, _vp, _sz, _vp]),
     "af_vad_detect_batch": (_st, [C.POINTER(VadConfig), _vp, _sz, _sz, _sz, _vp]),
     "af_vad_state": (C.c_int, [_vp]),

@@ -103,6 +103,19 @@ def resample_batch(clips, input_rate: int, output_rate: int) -> np.ndarray:
     return out
 
 
+def resample_cubic_batch(clips, input_rate: int, output_rate: int) -> np.ndarray:
+    """Optional cubic mode [B, unpinned]: what resampler.rs:43-49 configures (rubato FastFixedIn, Cubic) as defined
+    in docs/OPS.md "Cubic interpolation"; equal-length mono clips ``[n_clips, n_in]``."""
+    x = np.ascontiguousarray(clips, np.float32)
+    if x.ndim == 1:
+        x = x[None, :]
+    lib = library()
+    n_out = lib.af_resample_out_len(input_rate, output_rate, x.shape[1])
+    out = np.empty((x.shape[0], n_out), np.float32)
+    _check(lib.af_resample_cubic_batch(input_rate, output_rate, _ptr(x), x.shape[0], x.shape[1], _ptr(out), out.size))
+    return out
+
+
 def resample_stereo_batch(clips, input_rate: int, output_rate: int) -> np.ndarray:
     """``to_mono`` fused into the resampler (af_resample_batch_stereo_device): ``clips`` is
     ``[n_clips, n_frames * 2]`` interleaved stereo; returns ``[n_clips, ceil(n_frames L / M)]``."""

@@ -49,6 +49,28 @@ inline Staging& staging_slot(int dev)
     return slots[dev >= 0 && dev < kMaxDevices ? dev : 0];
 }
 
+// Cubic mode: the polynomial through (-1, y0), (0, y1), (1, y2), (2, y3) evaluated at t in [0, 1) (Horner, f32);
+// the position m * in / out and its split into sample index and fraction are float64.
+__global__ void cubic_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n_in, int64_t n_out,
+                             int64_t total, double step)
+{
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t clip = idx / n_out, m = idx - clip * n_out;
+        const double pos = (double)m * step;
+        const int64_t i = (int64_t)pos;                       // pos >= 0: truncation = floor
+        const float t = (float)(pos - (double)i);
+        const float* xc = x + clip * n_in;
+        const float y0 = i - 1 >= 0 && i - 1 < n_in ? xc[i - 1] : 0.0f;
+        const float y1 = i < n_in ? xc[i] : 0.0f;
+        const float y2 = i + 1 < n_in ? xc[i + 1] : 0.0f;
+        const float y3 = i + 2 < n_in ? xc[i + 2] : 0.0f;
+        const float a1 = -y0 * (1.0f / 3.0f) - y1 * 0.5f + y2 - y3 * (1.0f / 6.0f);
+        const float a2 = (y0 + y2) * 0.5f - y1;
+        const float a3 = (y1 - y2) * 0.5f + (y3 - y0) * (1.0f / 6.0f);
+        y[idx] = y1 + t * (a1 + t * (a2 + t * a3));
+    }
+}
+
 struct Geometry {
     const float* x;          // clip 0, element at absolute stream index x_abs0
     float* y;
@@ -591,6 +613,45 @@ af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate, const flo
     AF_HIP(hipMemcpy(din.p, in, n_clips * n_in * sizeof(float), hipMemcpyHostToDevice));
     AF_TRY(af_resample_batch_device(input_rate, output_rate, din.as<float>(), n_clips, n_in,
                                     dout.as<float>(), nullptr));
+    AF_HIP(hipMemcpy(out, dout.p, n_clips * n_out * sizeof(float), hipMemcpyDeviceToHost));
+    return AF_OK;
+}
+
+// ---- optional cubic mode (what the reference CONFIGURES: rubato FastFixedIn, PolynomialDegree::Cubic) ----------
+// docs/OPS.md "Cubic interpolation": y[m] = the cubic through x[i - 1 .. i + 2] at i + t, i + t = m * in / out in
+// float64, zero extension at both ends, out_len = ceil(n L / M).  One thread per output, one clip row per blockIdx.y
+// range: 4 B out + 4 B * M / L in per output, HBM-bound.
+af_status af_resample_cubic_batch_device(uint32_t input_rate, uint32_t output_rate, const float* in_dev, size_t n_clips,
+                                         size_t n_in, float* out_dev, void* stream)
+{
+    AF_REQUIRE(input_rate > 0 && output_rate > 0, "sample rates must be positive");
+    if (n_clips == 0 || n_in == 0) return AF_OK;
+    AF_REQUIRE(in_dev && out_dev, "af_resample_cubic_batch_device: null buffer");
+    AF_TRY(ensure_device(-1));
+    const size_t n_out = af_resample_out_len(input_rate, output_rate, n_in);
+    const size_t total = n_clips * n_out;
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, (size_t)1 << 30);
+    hipLaunchKernelGGL(rs::cubic_kernel, dim3(grid), dim3(256), 0, as_stream(stream), in_dev, out_dev, (int64_t)n_in,
+                       (int64_t)n_out, (int64_t)total, (double)input_rate / (double)output_rate);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+af_status af_resample_cubic_batch(uint32_t input_rate, uint32_t output_rate, const float* in, size_t n_clips, size_t n_in,
+                                  float* out, size_t out_cap)
+{
+    AF_REQUIRE(input_rate > 0 && output_rate > 0, "sample rates must be positive");
+    const size_t n_out = af_resample_out_len(input_rate, output_rate, n_in);
+    if (out_cap < n_out * n_clips)
+        return fail(AF_ERR_BUFFER_TOO_SMALL, "resample_cubic_batch: need %zu floats", n_out * n_clips);
+    if (n_clips == 0 || n_in == 0) return AF_OK;
+    AF_REQUIRE(in && out, "af_resample_cubic_batch: null buffer");
+    AF_TRY(ensure_device(-1));
+    DevBuf din, dout;
+    AF_TRY(din.reserve(n_clips * n_in * sizeof(float)));
+    AF_TRY(dout.reserve(n_clips * n_out * sizeof(float)));
+    AF_HIP(hipMemcpy(din.p, in, n_clips * n_in * sizeof(float), hipMemcpyHostToDevice));
+    AF_TRY(af_resample_cubic_batch_device(input_rate, output_rate, din.as<float>(), n_clips, n_in, dout.as<float>(), nullptr));
     AF_HIP(hipMemcpy(out, dout.p, n_clips * n_out * sizeof(float), hipMemcpyDeviceToHost));
     return AF_OK;
 }

@@ -181,6 +181,16 @@ size_t    af_resample_out_len(uint32_t input_rate, uint32_t output_rate, size_t 
 af_status af_resample_batch(uint32_t input_rate, uint32_t output_rate,
                             const float* in, size_t n_clips, size_t n_in,
                             float* out, size_t out_cap);
+/* Optional cubic mode [B, parity unpinned]: what the reference CONFIGURES but never runs (resampler.rs:43-49: rubato
+ * FastFixedIn with PolynomialDegree::Cubic; no reference test has in != out, the crate's source is not in the
+ * tree): docs/OPS.md "Cubic interpolation" -- the cubic through x[i-1 .. i+2] at position m * in / out (float64),
+ * zero extension, out_len as above.  No anti-alias filter: the polyphase entry points above are the product path. */
+af_status af_resample_cubic_batch(uint32_t input_rate, uint32_t output_rate,
+                                  const float* in, size_t n_clips, size_t n_in,
+                                  float* out, size_t out_cap);
+af_status af_resample_cubic_batch_device(uint32_t input_rate, uint32_t output_rate,
+                                         const float* in_dev, size_t n_clips, size_t n_in,
+                                         float* out_dev, void* stream);
 /* af_resample_batch keeps up to 256 MB of device staging per device between calls (what a larger call needed is
  * freed when it returns); this frees the rest.  No reference counterpart (resampler.rs:78 allocates per call). */
 void      af_resample_release_staging(void);

@@ -498,3 +498,24 @@ size_t afo_features_f64(const float* pcm, size_t n_frames_pcm, unsigned channels
     free(mono);
     return nf;
 }
+
+/* [B, parity unpinned] Cubic interpolation mode (docs/OPS.md): the configuration of resampler.rs:43-49 (rubato
+ * FastFixedIn, PolynomialDegree::Cubic) as a closed formula -- the cubic through (-1, x[i-1]), (0, x[i]), (1, x[i+1]),
+ * (2, x[i+2]) at i + t = m * in_hz / out_hz, zero extension, n_out outputs.  float64 throughout. */
+void afo_resample_cubic(const float* x, size_t n, unsigned in_hz, unsigned out_hz, size_t n_out, double* y)
+{
+    for (size_t m = 0; m < n_out; ++m) {
+        const double pos = (double)m * ((double)in_hz / (double)out_hz);
+        const long long i = (long long)pos;
+        const double t = pos - (double)i;
+        double v[4];
+        for (int k = 0; k < 4; ++k) {
+            const long long j = i - 1 + k;
+            v[k] = (j >= 0 && (size_t)j < n) ? (double)x[j] : 0.0;
+        }
+        const double a1 = -v[0] / 3.0 - v[1] / 2.0 + v[2] - v[3] / 6.0;
+        const double a2 = (v[0] + v[2]) / 2.0 - v[1];
+        const double a3 = (v[1] - v[2]) / 2.0 + (v[3] - v[0]) / 6.0;
+        y[m] = v[1] + t * (a1 + t * (a2 + t * a3));
+    }
+}

@@ -174,4 +174,7 @@ int afo_max_threads(void);
 #ifdef __cplusplus
 }
 #endif
+/* [B, unpinned] cubic interpolation mode (docs/OPS.md "Cubic interpolation"; the configuration of resampler.rs:43-49) */
+void afo_resample_cubic(const float* x, size_t n, unsigned in_hz, unsigned out_hz, size_t n_out, double* y);
+
 #endif

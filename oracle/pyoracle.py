@@ -261,6 +261,19 @@ def resample(x, in_hz: int, out_hz: int, T: int = 64, m0: int = 0, n_out=None) -
     return y
 
 
+_cubic = _sig("afo_resample_cubic", None, _f32p, C.c_size_t, C.c_uint, C.c_uint, C.c_size_t,
+              np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"))
+
+
+def resample_cubic(x, in_hz: int, out_hz: int) -> np.ndarray:
+    """docs/OPS.md "Cubic interpolation" (the mode resampler.rs:43-49 configures), float64."""
+    x = _f32(x).ravel()
+    L, M = resample_ratio(in_hz, out_hz)
+    y = np.empty(resample_out_len(x.size, L, M), np.float64)
+    _cubic(x, x.size, in_hz, out_hz, y.size, y)
+    return y
+
+
 def resample_f32(x, in_hz: int, out_hz: int, T: int = 64) -> np.ndarray:
     x = _f32(x).ravel()
     L, M = resample_ratio(in_hz, out_hz)

@@ -154,6 +154,9 @@ extern "C" {
     pub fn af_chain_stream_reset(s: *mut af_chain_stream) -> af_status;
     pub fn af_chain_stream_stats(s: *const af_chain_stream, stats: *mut f64) -> af_status;
     pub fn af_resample_release_staging();
+    // optional cubic mode (what resampler.rs:43-49 configures; docs/OPS.md "Cubic interpolation", parity unpinned)
+    pub fn af_resample_cubic_batch(input_rate: u32, output_rate: u32, input: *const f32, n_clips: usize, n_in: usize,
+                                   out: *mut f32, out_cap: usize) -> af_status;
     pub fn af_chain_n_launches(c: *const af_chain) -> c_int;
     // RingBuffer, capture.rs:84-161
     pub fn af_ring_create(capacity_samples: usize, out: *mut *mut af_ring) -> af_status;

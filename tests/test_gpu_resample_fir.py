@@ -63,6 +63,26 @@ def test_resample_many_block_matrices_vs_oracle(af, po, fi, fo, n):
     assert np.linalg.norm(y - y2) <= 2e-6 * np.linalg.norm(y2)
 
 
+@pytest.mark.parametrize("fi,fo", [(48000, 16000), (44100, 16000), (16000, 48000), (48000, 44100)])
+@pytest.mark.parametrize("n", [1, 2, 5, 1000, 30011])
+def test_resample_cubic_mode_vs_oracle(af, po, fi, fo, n):
+    """The optional cubic mode (what resampler.rs:43-49 configures; docs/OPS.md, parity unpinned): output length as the
+    polyphase resampler, values within 1e-6 of the peak of the float64 formula; a slow sine is reproduced closely."""
+    clips = np.stack([synth_clip(170 + i, n, 1, fi) for i in range(2)])
+    y = af.resample_cubic_batch(clips, fi, fo)
+    L, M = po.resample_ratio(fi, fo)
+    assert y.shape == (2, po.resample_out_len(n, L, M))
+    for i in range(2):
+        ref = po.resample_cubic(clips[i], fi, fo)
+        assert np.max(np.abs(y[i] - ref)) <= 1e-6 * max(np.max(np.abs(ref)), 1e-30) + 1e-9
+    if n >= 1000:
+        t = np.arange(n) / fi
+        x = (0.5 * np.sin(2 * np.pi * 220.0 * t)).astype(np.float32)
+        yy = af.resample_cubic_batch(x, fi, fo)[0]
+        want = 0.5 * np.sin(2 * np.pi * 220.0 * np.arange(yy.size) / fo)
+        assert np.max(np.abs(yy[10:-20] - want[10:-20])) < 2e-4   # interpolation error of a 220 Hz tone (clip edges: zero extension)
+
+
 def test_resample_reference_surface(af):
     r = af.AudioResampler.new(48000, 16000)                      # resampler.rs:192-198
     assert r.input_rate() == 48000 and r.output_rate() == 16000 and r.needs_resampling()

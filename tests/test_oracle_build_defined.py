@@ -184,3 +184,19 @@ def test_slaney_mel_weights_against_numpy(po):
     assert np.max(np.abs(po.mel_weights(16000.0, scale=1, norm=1) - Wn)) < 1e-15
     # HTK default unchanged by the new entry point
     assert np.array_equal(po.mel_weights(16000.0), po.mel_weights(16000.0, scale=0, norm=0))
+
+
+def test_cubic_mode_formula_against_numpy_polyfit(po):
+    """The cubic mode's closed formula == the interpolating cubic through the four neighbours (numpy polyfit)."""
+    rng = np.random.default_rng(21)
+    x = rng.uniform(-1, 1, 200).astype(np.float32)
+    for fi, fo in [(48000, 16000), (16000, 48000), (44100, 16000)]:
+        y = po.resample_cubic(x, fi, fo)
+        L, M = po.resample_ratio(fi, fo)
+        assert y.size == po.resample_out_len(x.size, L, M)
+        xp = np.concatenate([[0.0], x.astype(np.float64), [0.0, 0.0, 0.0]])      # zero extension
+        for m in range(0, y.size, 7):
+            pos = m * fi / fo
+            i = int(pos)
+            c = np.polyfit([-1.0, 0.0, 1.0, 2.0], xp[i:i + 4], 3)
+            assert abs(np.polyval(c, pos - i) - y[m]) < 1e-12
