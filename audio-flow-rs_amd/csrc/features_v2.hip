@@ -197,6 +197,16 @@ __device__ __forceinline__ void fft_pair_1(const float (&s)[20], const float (&w
 {
     const int k1 = lane & 15, hi = lane >> 4;
     float re[16], im[16];
+#ifdef AF_V2_TW_EARLY
+    // (experiment) the twiddle row requested by hand in front of the transform: hipcc sinks plain loads below it
+    f32x4 twr[8];
+    {
+        const unsigned ta = (unsigned)reinterpret_cast<uintptr_t>(tw1 + lane * kTw1Row);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(twr[jj]) : "v"(ta), "n"(16 * jj));
+    }
+#endif
 
     // ---- stage 1: z[64 n1 + n2] = w * (a + i b); frame b = frame a shifted by
     // kHop samples = 4 registers.  The window multiply is fused into the twiddle-free first DIT
@@ -220,10 +230,20 @@ __device__ __forceinline__ void fft_pair_1(const float (&s)[20], const float (&w
     // of 36 dwords collide) and the eight reads cost 116 LDS cycles per frame pair instead of 32
     // (scripts/ablate/lds_groups.sh: all of SQ_LDS_BANK_CONFLICT came from here).
     {
+#ifdef AF_V2_TW_EARLY
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(twr[0]), "+v"(twr[1]), "+v"(twr[2]), "+v"(twr[3]), "+v"(twr[4]), "+v"(twr[5]),
+                       "+v"(twr[6]), "+v"(twr[7]));
+#else
         const float4* trow = reinterpret_cast<const float4*>(tw1 + lane * kTw1Row);
+#endif
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
+#ifdef AF_V2_TW_EARLY
+            const float4 t = float4{twr[jj][0], twr[jj][1], twr[jj][2], twr[jj][3]};
+#else
             const float4 t = (AF_ABL & 4) ? float4{abl_val(lane, jj), 0.5f, 0.25f, 0.125f} : trow[jj];
+#endif
             {
                 const float xr = re[2 * jj + 1], xi = im[2 * jj + 1];
                 re[2 * jj + 1] = __builtin_fmaf(xr, t.x, xi * t.y);
@@ -450,7 +470,6 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     for (int i = tid; i < kW * kMaxSlotsW; i += kT) lmeta[i] = p.meta[i];
 
     // this wave's share of the mel plan
-    const float4* __restrict__ wfrag_w = reinterpret_cast<const float4*>(p.wfrag) + ((size_t)w * kMaxSlotsW) * 64 + lane;
     int slot_end_w[NSLOT];
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) slot_end_w[q] = p.plan.slot_end[w][q];
@@ -504,22 +523,27 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
 
         const bool has_next = (u + 1 < u_end) && (ud.flags & 1);
         uint4 pf[PFU];
-        if (has_next) {
-            // (lane offsets from an opaque copy of tid: hoisted out of the unit loop they end up in scratch,
-            // and a scratch reload waits for every outstanding vector memory operation)
-            const int t0 = opaque_tid(tid);
-            if (n_avail >= kTile + 16 * kHop) {      // wave-uniform: the new region lies inside the clip
-                const char* src = static_cast<const char*>(p.pcm) +
-                                  (ud.pcm0 + kTile) * St::kBytesPerFrame;
+        const auto issue_prefetch = [&]() {
+            if (has_next) {
+                // (lane offsets from an opaque copy of tid: hoisted out of the unit loop they end up in scratch,
+                // and a scratch reload waits for every outstanding vector memory operation)
+                const int t0 = opaque_tid(tid);
+                if (n_avail >= kTile + 16 * kHop) {  // wave-uniform: the new region lies inside the clip
+                    const char* src = static_cast<const char*>(p.pcm) +
+                                      (ud.pcm0 + kTile) * St::kBytesPerFrame;
 #pragma unroll
-                for (int i = 0; i < PFU; ++i)
-                    pf[i] = *reinterpret_cast<const uint4*>(src + (unsigned)(t0 + i * kT) * 16u);
-            } else {
+                    for (int i = 0; i < PFU; ++i)
+                        pf[i] = *reinterpret_cast<const uint4*>(src + (unsigned)(t0 + i * kT) * 16u);
+                } else {
 #pragma unroll
-                for (int i = 0; i < PFU; ++i)
-                    pf[i] = St::load_raw(p.pcm, ud.pcm0, kTile + (int64_t)(t0 + i * kT) * MS, n_avail, true);
+                    for (int i = 0; i < PFU; ++i)
+                        pf[i] = St::load_raw(p.pcm, ud.pcm0, kTile + (int64_t)(t0 + i * kT) * MS, n_avail, true);
+                }
             }
-        }
+        };
+#ifndef AF_V2_PF_LATE
+        issue_prefetch();
+#endif
 
         float wf[NSLOT * kSlotSteps];
         {
@@ -531,6 +555,9 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             float s1[20], win[16];
             stage1_load(tile, w, lane, wtab, s1, win);
             fft_pair_1(s1, win, wb, wv, lane, tw1, ur, ui);
+#ifdef AF_V2_PF_LATE
+            issue_prefetch();                        // (experiment) behind part 1: 16 more free registers in it
+#endif
 
             AF_STAMP2(2);
             // This wave's filterbank fragments (L2-resident, one float4 per slot), issued where the
@@ -538,10 +565,12 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             if constexpr (!POWER) {
                 int opaque_zero;                     // pins the loads here (and defeats hoisting)
                 asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
-                const float4* wp = wfrag_w + opaque_zero;
+                // (scalar base + 32-bit lane offset: a hoisted 64-bit lane pointer is one more loop-carried register pair)
+                const float4* wbase = reinterpret_cast<const float4*>(p.wfrag) + (size_t)w * kMaxSlotsW * 64;
+                const unsigned wo = (unsigned)(lane + opaque_zero);
 #pragma unroll
                 for (int q = 0; q < NSLOT; ++q) {
-                    const float4 v = wp[q * 64];
+                    const float4 v = wbase[wo + q * 64];
                     wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
                 }
             } else {
