@@ -845,7 +845,9 @@ constexpr int kStreamNk[] = {20, 24, 28, 36};
 // Ratios with more than 16 block matrices (or block periods beyond an LDS segment): the streamed kernel.
 Plan make_stream_plan(Plan p, uint64_t nb, uint64_t S)
 {
-    if (p.ch != 1 || nb > 4096 || S >= (1ull << 24)) return p;
+    // S: an idle lane's byte offset is kOob = 0xFFF00000 plus up to 2 (16 C - 1) S 4 bytes of segment offset and must
+    // stay below 2^32 (out of range for the hardware check), so S is bounded well below 2^20 / (32 C) samples
+    if (p.ch != 1 || nb > 4096 || S > 6000) return p;
     uint64_t d15 = 0;
     for (uint64_t b = 0; b < nb; ++b) {
         const uint64_t d = ((16 * b * p.M) % p.L + 15ull * p.M) / p.L;
