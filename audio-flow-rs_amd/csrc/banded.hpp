@@ -33,6 +33,7 @@ struct Plan {
     int nwaves = 0;           // nb * wpp
     int G = 0;                // block periods per column and tile
     int ch = 1;               // 2: x is interleaved stereo, downmixed while it is staged
+    bool pairs = false;       // mono x staged in sample pairs: segments start with a lead-in word
     int seg_len = 0;          // floats of x per column segment
     int seg_stride = 0;       // odd, >= seg_len
     int64_t out_per_tile = 0; // 256 * G * nb

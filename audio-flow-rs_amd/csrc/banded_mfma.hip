@@ -14,6 +14,11 @@
 
 #include "banded.hpp"
 
+// AF_BANDED_PAIRS (0: ablation): mono x is staged in sample pairs (8-byte buffer loads) instead of single dwords
+#ifndef AF_BANDED_PAIRS
+#define AF_BANDED_PAIRS 1
+#endif
+
 namespace af {
 namespace banded {
 namespace {
@@ -103,8 +108,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 #pragma unroll
     for (int t = 0; t < NK; ++t) a[t] = g.afrag[((size_t)p * NK + t) * 64 + lane];
 
+    // PAIR (mono input): a thread stages the sample pair (2 tid, 2 tid + 1) of every column segment with ONE 8-byte
+    // load -- half the vector-memory instructions of a tile -- on a pair grid anchored at an even sample of the clip
+    // (a pair that straddled sample 0 would have a wrapped byte offset and be dropped whole by the range check): a
+    // tile whose first sample is odd starts its pairs one sample early (sh), segments keep one lead-in word for it.
+    // col_span = G S is even (G is), so every column of a tile has the same parity.
+    // (Not in the five-waves-per-SIMD shapes: config 3's ten-wave workgroup measured 2.21 ms with pairs against 2.12
+    // without on one box, while the eight-wave shapes gain 1-3 %; banded.hpp Plan::pairs tells the host which it is.)
+    constexpr bool PAIR = CH == 1 && WPE != 5 && AF_BANDED_PAIRS;
+    constexpr int kLead = PAIR ? 1 : 0;
     const int col = lane & 15, g4 = lane >> 4;
-    const int wave_off = qp + gsub * g.gpw * g.S;
+    const int wave_off = qp + gsub * g.gpw * g.S + kLead;
     const int base_full = col * g.seg_stride + 16 * g4 + wave_off;
     const int base_tail = col * g.seg_stride + TAILQ * g4 + 64 * FULL + wave_off;
     // this lane's outputs: rows 4 g4 .. 4 g4 + 3 of block (p, column col, period g)
@@ -116,6 +130,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     // past the segment neither load nor store, or they would land in the neighbouring column
     const bool first = tid < g.seg_len;
     const bool second = tid + nthreads < g.seg_len;             // this thread fills two samples per segment
+    int sh = 0;                                                 // PAIR: of the tile whose x is in flight
     const uint32_t tpc = (uint32_t)g.tiles_per_clip, n_tiles = (uint32_t)g.n_tiles;
 
     // x comes through a buffer resource over the clip: samples before / after the clip read as
@@ -132,13 +147,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         const int64_t base = t_abs * (16 * (int64_t)col_span) + g.lo_off - g.x_abs0;
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)clip * g.x_stride * CH), 0,
                                                  (int)(uint32_t)(g.x_len * 4 * CH), 0x00020000);
-        const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * (4u * CH);
-        voff[0] = live && first ? v0 : kOob;
-        voff[1] = live && second ? v0 + (uint32_t)nthreads * (4u * CH) : kOob;
+        if constexpr (PAIR) {
+            sh = (int)(base & 1);
+            const uint32_t v0 = ((uint32_t)(base - sh) + 2u * (uint32_t)(tid + opaque_zero())) * 4u;
+            voff[0] = live && 2 * tid < g.seg_len + sh ? v0 : kOob;
+        } else {
+            const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * (4u * CH);
+            voff[0] = live && first ? v0 : kOob;
+            voff[1] = live && second ? v0 + (uint32_t)nthreads * (4u * CH) : kOob;
+        }
     };
-    auto issue_load = [&](int s) {                              // s = h * 16 + cc
+    auto issue_load = [&](int s) {                              // s = h * 16 + cc  (PAIR: s = cc)
         const int cc = s % kCols, h = s / kCols;
-        if constexpr (CH == 1) {
+        if constexpr (PAIR) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            // (everything in the VECTOR offset: the scalar offset operand is added behind the range check)
+            const f32x2 v = __builtin_bit_cast(
+                f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 4u), 0, 0));
+            pf[s * kPfSlots] = v[0];
+            pf[s * kPfSlots + 1] = v[1];
+        } else if constexpr (CH == 1) {
             pf[cc * kPfSlots + h] = __builtin_bit_cast(
                 float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
         } else {
@@ -151,7 +179,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             pf[(cc * kPfSlots + h) * 2 + 1] = v[1];
         }
     };
-    constexpr int kLoads = kCols * kPfSlots;
+    constexpr int kLoads = PAIR ? kCols : kCols * kPfSlots;
 
     uint32_t tile = blockIdx.x;
     if (tile < n_tiles) {
@@ -167,13 +195,24 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 if constexpr (CH == 1) return pf[cc * kPfSlots + h];
                 else return (pf[(cc * kPfSlots + h) * 2] + pf[(cc * kPfSlots + h) * 2 + 1]) * 0.5f;
             };
-            if (first) {
+            if constexpr (PAIR) {
+                if (2 * tid < g.seg_len + sh) {
+                    float* d2 = xs + 1 - sh + 2 * (tid + opaque_zero());
 #pragma unroll
-                for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = staged(cc, 0);
-            }
-            if (second) {
+                    for (int cc = 0; cc < kCols; ++cc) {
+                        d2[cc * g.seg_stride] = pf[cc * kPfSlots];
+                        d2[cc * g.seg_stride + 1] = pf[cc * kPfSlots + 1];
+                    }
+                }
+            } else {
+                if (first) {
 #pragma unroll
-                for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = staged(cc, 1);
+                    for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = staged(cc, 0);
+                }
+                if (second) {
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = staged(cc, 1);
+                }
             }
         }
         __syncthreads();
@@ -920,7 +959,10 @@ Plan make_plan(uint32_t L, uint32_t M, int T, int c, int ch)
     p.nwaves = p.nb * p.wpp;
     const int nthreads = 64 * p.nwaves;
     if (ch == 2 && (p.nwaves > 8 || p.NK > 32)) return p;     // stereo staging: 8-wave shapes only
-    const int seg_cap = kPfSlots * nthreads < kMaxSeg ? kPfSlots * nthreads : kMaxSeg;
+    // mono x is staged in sample pairs (lead-in word, odd end) except in the shapes launch() runs at five waves per SIMD
+    const bool pairs = ch == 1 && AF_BANDED_PAIRS && !(p.nwaves > 8 && p.NK <= 32);
+    p.pairs = pairs;
+    const int seg_cap = (kPfSlots * nthreads < kMaxSeg ? kPfSlots * nthreads : kMaxSeg) - (pairs ? 1 : 0);
     const int qp_last = (int)((16ull * (nb - 1) * M) / L);
     const int unit = 2 * p.wpp;                              // every wave runs chains in pairs
     int G = 0;
@@ -928,7 +970,7 @@ Plan make_plan(uint32_t L, uint32_t M, int T, int c, int ch)
     if (!G) return p;
     p.G = G;
     p.seg_len = (G - 1) * p.S + qp_last + 4 * p.NK;
-    p.seg_stride = p.seg_len | 1;
+    p.seg_stride = pairs ? (p.seg_len + 2) | 1 : p.seg_len | 1;
     p.out_per_tile = (int64_t)256 * G * p.nb;
     p.smem = (size_t)kCols * p.seg_stride * sizeof(float);
     p.ok = true;
@@ -1048,6 +1090,13 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
     if (grid > n_cus * wg_per_cu) grid = n_cus * wg_per_cu;
     const unsigned block = 64u * p.nwaves;
     const bool five = wg_per_cu == 2 && 2 * p.nwaves > 16;
+    if (five && p.NK <= 32 && p.pairs)
+        return fail(AF_ERR_UNSUPPORTED, "banded::launch: plan staged in pairs for a five-wave shape");
+    if (!(five && p.NK <= 32) && p.ch == 1 && AF_BANDED_PAIRS && !p.pairs) {
+        // a ten-wave plan (no pairs) that does not get two workgroups per CU after all: the four-wave instance would
+        // stage pairs into segments laid out without the lead-in word
+        return fail(AF_ERR_UNSUPPORTED, "banded::launch: %d-wave plan without room for two workgroups per CU", p.nwaves);
+    }
     switch (p.NK) {
     case 8: launch_nk<8>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
     case 12: launch_nk<12>(g, five, p.ch, (unsigned)grid, block, p.smem, stream); break;
