@@ -183,6 +183,36 @@ def test_resample_config3_full_size(af, po):
         assert rel_err(y[c].cpu().numpy(), ref) < TOL
 
 
+def test_resample_48k_to_44k1_full_size(af, po):
+    # the everyday device pair (capture.rs:60-80 defaults to 48 kHz; config 3 is 44.1 kHz) at batch size: 1024 mono
+    # clips x 30 s @48 k (5.9 GB) -> 1 323 000 samples @44.1 k through the streamed banded kernel (147 block
+    # matrices): every output written, duplicate clips identical, determinism, sampled clips against the oracle,
+    # DC gain 1 in the interior
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    dev = torch.device("cuda:0")
+    n_clips, n_in = 1024, 1440000
+    lib = af.library()
+    n_out = lib.af_resample_out_len(48000, 44100, n_in)
+    assert n_out == 1323000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(78)
+    x = torch.rand(n_clips, n_in, device=dev, generator=gen).sub_(0.5)
+    x[1023] = x[9]
+    x[500] = 0.25
+    y = torch.full((n_clips, n_out), float("nan"), device=dev)
+    y2 = torch.empty_like(y)
+    for dst in (y, y2):
+        assert lib.af_resample_batch_device(48000, 44100, C.c_void_p(x.data_ptr()), n_clips, n_in,
+                                            C.c_void_p(dst.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all()) and torch.equal(y, y2) and torch.equal(y[1023], y[9])
+    assert float((y[500, 100:-100] - 0.25).abs().max()) < 1e-6
+    for c in (0, 511, 1022):
+        ref = po.resample(x[c].cpu().numpy(), 48000, 44100)
+        assert rel_err(y[c].cpu().numpy(), ref) < TOL
+
+
 def test_resample_full_size_property(af):
     # BASELINE config 3 shapes (a 64-clip slice): DC gain 1 and linearity at full length
     torch = pytest.importorskip("torch")
