@@ -200,6 +200,9 @@ SIGNATURES = {
     "af_chain_stream_flush": (_st, [_vp, _vp, _sz, _szp]),
     "af_chain_stream_reset": (_st, [_vp]),
     "af_chain_stream_stats": (_st, [_vp, _vp]),
+    "af_chain_stream_first_step_frames": (_sz, [_vp]),
+    "af_chain_stream_history_frames": (_sz, [_vp]),
+    "af_chain_stream_seek": (_st, [_vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     # RingBuffer (capture.rs:84-161)
     "af_ring_create": (_st, [_sz, C.POINTER(_vp)]),
     "af_ring_destroy": (None, [_vp]),

@@ -847,6 +847,21 @@ class ChainStream:
     def total_rows(self, n_frames: int) -> int:
         return int(self._lib.af_chain_stream_total_rows(self._h, int(n_frames)))
 
+    @property
+    def first_step_frames(self) -> int:
+        return int(self._lib.af_chain_stream_first_step_frames(self._h))
+
+    @property
+    def history_frames(self) -> int:
+        return int(self._lib.af_chain_stream_history_frames(self._h))
+
+    def seek(self, step: int) -> int:
+        """Time sharding (shard.chain_stream_shards): continue as if ``step`` steps had already run.  Returns the
+        frame of the recording the next ``push`` must start at (the step's history comes first and yields no rows)."""
+        first = C.c_uint64()
+        _check(self._lib.af_chain_stream_seek(self._h, int(step), C.byref(first)))
+        return int(first.value)
+
     def stats(self) -> dict:
         v = (C.c_double * 4)()
         _check(self._lib.af_chain_stream_stats(self._h, v))

@@ -419,6 +419,7 @@ struct af_chain_stream {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_device_ms = 0.0f, last_wall_ms = 0.0f;
     bool flushed = false;
+    bool priming = false;             // after a seek: the next `carry` frames are history only
 };
 
 namespace {
@@ -630,7 +631,10 @@ size_t af_chain_stream_max_rows(const af_chain_stream* s, size_t n_frames)
     if (!s) return 0;
     int64_t pending = s->fill + (int64_t)n_frames;
     size_t steps = 0;
-    if (s->steps == 0) {
+    if (s->priming) {
+        if (pending < s->carry) return 0;
+        pending -= s->carry;
+    } else if (s->steps == 0) {
         if (pending < s->need0) return 0;
         pending -= s->need0;
         steps = 1;
@@ -655,7 +659,7 @@ af_status af_chain_stream_push(af_chain_stream* s, const void* pcm, size_t n_fra
     int64_t left = (int64_t)n_frames;
     size_t wrote = 0;
     while (left > 0) {
-        const int64_t target = s->steps == 0 ? s->need0 : s->Cx;
+        const int64_t target = s->priming ? s->carry : s->steps == 0 ? s->need0 : s->Cx;
         const int64_t take = std::min(left, target - s->fill);
         std::memcpy(static_cast<char*>(s->h_in) + (size_t)s->fill * s->bpf, src, (size_t)take * s->bpf);
         s->fill += take;
@@ -663,6 +667,13 @@ af_status af_chain_stream_push(af_chain_stream* s, const void* pcm, size_t n_fra
         left -= take;
         s->frames_in += (uint64_t)take;
         if (s->fill < target) break;
+        if (s->priming) {       // the history of the step the stream was moved to: to the front of the buffer, no rows
+            AF_HIP(hipMemcpyAsync(s->d_x.p, s->h_in, (size_t)s->carry * s->bpf, hipMemcpyHostToDevice, s->stream));
+            AF_HIP(hipStreamSynchronize(s->stream));
+            s->priming = false;
+            s->fill = 0;
+            continue;
+        }
         if (s->steps == 0) AF_TRY(cs_first_step(s));
         else AF_TRY(cs_timed(s, true));
         std::memcpy(rows_out + wrote * s->row_len, s->h_out, s->rows_per_step * s->row_len * sizeof(float));
@@ -680,6 +691,8 @@ af_status af_chain_stream_flush(af_chain_stream* s, float* rows_out, size_t rows
     AF_REQUIRE(s && n_rows, "af_chain_stream_flush: null argument");
     *n_rows = 0;
     if (s->flushed) return AF_OK;
+    AF_REQUIRE(!s->priming, "af_chain_stream_flush: the stream was moved to step %llu and has not received that step's "
+               "%lld history frames yet", (unsigned long long)s->steps, (long long)s->carry);
     af_chain* c = s->chain;
     const size_t total = af_chain_stream_total_rows(s, s->frames_in);
     const size_t rows = total - (size_t)s->rows_out;               // what the partial step still owes
@@ -725,6 +738,34 @@ af_status af_chain_stream_reset(af_chain_stream* s)
     s->steps = 0;
     s->frames_in = s->rows_out = 0;
     s->flushed = false;
+    s->priming = false;
+    return AF_OK;
+}
+
+/* frames step 0 consumes (every later step: af_chain_stream_step_frames) and frames of history a step reads in front
+ * of its own -- what a time-sharding caller needs to cut a stream into per-GPU step ranges */
+size_t af_chain_stream_first_step_frames(const af_chain_stream* s) { return s ? (size_t)s->need0 : 0; }
+size_t af_chain_stream_history_frames(const af_chain_stream* s) { return s ? (size_t)s->carry : 0; }
+
+/* Time sharding (BASELINE config 5 across GPUs): continue as if `step` steps had already run.  The next frames pushed
+ * must be the stream's frames from *first_frame on: first the step's history (af_chain_stream_history_frames, no rows),
+ * then the steps' own frames; rows come out from row step * rows_per_step on and are the rows an unbroken stream (or
+ * af_chain_run on the whole recording) has there, bit for bit -- a steady step's launch does not depend on its index. */
+af_status af_chain_stream_seek(af_chain_stream* s, uint64_t step, uint64_t* first_frame)
+{
+    AF_REQUIRE(s, "af_chain_stream_seek: null handle");
+    AF_TRY(af_chain_stream_reset(s));
+    uint64_t first = 0;
+    if (step > 0) {
+        AF_REQUIRE(step < ((uint64_t)1 << 40) / (uint64_t)s->Cx, "af_chain_stream_seek: step %llu out of range",
+                   (unsigned long long)step);
+        first = (uint64_t)(s->need0 - s->carry) + (step - 1) * (uint64_t)s->Cx;   // = base of the step's first tile
+        s->steps = step;
+        s->frames_in = first;
+        s->rows_out = step * s->rows_per_step;
+        s->priming = true;
+    }
+    if (first_frame) *first_frame = first;
     return AF_OK;
 }
 

@@ -44,6 +44,33 @@ def stream_shards(n_total: int, world_size: int, chunk: int, n_fft: int = 1024,
     return [spans[b:e] for b, e in all_shards(len(spans), world_size)]
 
 
+def chain_stream_shards(n_frames: int, world_size: int, first_step_frames: int, step_frames: int,
+                        history_frames: int) -> List[Tuple[int, int, int, int, bool]]:
+    """One long recording through the full chain on ``world_size`` GPUs (BASELINE config 5 on the chain): the
+    recording's steps (``ChainStream``: step 0 takes ``first_step_frames`` frames, every later one ``step_frames``)
+    are dealt to the ranks in contiguous ranges.  Returns, per rank, ``(step0, step1, frame_lo, frame_hi, flush)``:
+    the rank calls ``ChainStream.seek(step0)`` (which answers ``frame_lo``), pushes the recording's frames
+    ``[frame_lo, frame_hi)`` -- ``history_frames`` of them are the read-only history in front of step ``step0`` --
+    and, when ``flush`` is set (the rank that holds the end of the recording), flushes.  The ranks' rows in rank order
+    are the unbroken stream's rows; a rank with ``step0 == step1`` and no flush has nothing to do."""
+    if min(first_step_frames, step_frames) <= 0 or not (0 < history_frames <= step_frames) or n_frames < 0:
+        raise ValueError("bad step geometry")
+    n_steps = 0 if n_frames < first_step_frames else 1 + (n_frames - first_step_frames) // step_frames
+
+    def end_of(step):            # first frame NOT needed by steps < step
+        return 0 if step == 0 else first_step_frames + (step - 1) * step_frames
+
+    out = []
+    for rank, (k0, k1) in enumerate(all_shards(n_steps, world_size)):
+        last = rank == world_size - 1
+        lo = 0 if k0 == 0 else end_of(k0) - history_frames
+        hi = n_frames if last else end_of(k1)
+        if k0 == k1 and not last:
+            lo = hi = 0
+        out.append((k0, k1, lo, hi, last))
+    return out
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """MAX all-reduce of a python float (identity when not distributed)."""
     import torch

@@ -545,6 +545,15 @@ public:
         return rows;
     }
     void reset() { detail::check(af_chain_stream_reset(h_)); }
+    // time sharding: continue as if `step` steps had run; the next push starts at the returned frame
+    size_t first_step_frames() const { return af_chain_stream_first_step_frames(h_); }
+    size_t history_frames() const { return af_chain_stream_history_frames(h_); }
+    uint64_t seek(uint64_t step)
+    {
+        uint64_t first = 0;
+        detail::check(af_chain_stream_seek(h_, step, &first));
+        return first;
+    }
 
 private:
     af_chain_stream* h_ = nullptr;

@@ -457,6 +457,16 @@ af_status af_chain_stream_push(af_chain_stream* s, const void* pcm, size_t n_fra
                                size_t rows_cap, size_t* n_rows);
 af_status af_chain_stream_flush(af_chain_stream* s, float* rows_out, size_t rows_cap, size_t* n_rows);
 af_status af_chain_stream_reset(af_chain_stream* s);
+/* Time sharding of ONE long recording across GPUs (BASELINE config 5): every rank owns a
+ * contiguous range of steps.  af_chain_stream_seek(s, k, &first) continues as if k steps had already run: the frames
+ * pushed next must be the recording's frames from `first` on -- the step's history (af_chain_stream_history_frames(),
+ * no rows) and then the steps' own frames; step 0 consumes af_chain_stream_first_step_frames() frames, every later
+ * step af_chain_stream_step_frames().  Rows come out from row k * rows_per_step on and equal the unbroken stream's
+ * rows bit for bit (a steady step's launch does not depend on its index); the rank that holds the end of the
+ * recording flushes.  No collective: every rank reads its history from the source like the rest of its range. */
+size_t    af_chain_stream_first_step_frames(const af_chain_stream* s);
+size_t    af_chain_stream_history_frames(const af_chain_stream* s);
+af_status af_chain_stream_seek(af_chain_stream* s, uint64_t step, uint64_t* first_frame);
 /* stats[4] = {device ms of the last replayed step, host wall ms of it, steps so far, rows so far} */
 af_status af_chain_stream_stats(const af_chain_stream* s, double* stats);
 

@@ -153,6 +153,9 @@ extern "C" {
     pub fn af_chain_stream_flush(s: *mut af_chain_stream, rows_out: *mut f32, rows_cap: usize, n_rows: *mut usize) -> af_status;
     pub fn af_chain_stream_reset(s: *mut af_chain_stream) -> af_status;
     pub fn af_chain_stream_stats(s: *const af_chain_stream, stats: *mut f64) -> af_status;
+    pub fn af_chain_stream_first_step_frames(s: *const af_chain_stream) -> usize;
+    pub fn af_chain_stream_history_frames(s: *const af_chain_stream) -> usize;
+    pub fn af_chain_stream_seek(s: *mut af_chain_stream, step: u64, first_frame: *mut u64) -> af_status;
     pub fn af_resample_release_staging();
     // optional cubic mode (what resampler.rs:43-49 configures; docs/OPS.md "Cubic interpolation", parity unpinned)
     pub fn af_resample_cubic_batch(input_rate: u32, output_rate: u32, input: *const f32, n_clips: usize, n_in: usize,

@@ -565,6 +565,15 @@ impl<T: PcmSample> ChainStream<T> {
         Ok(rows)
     }
     pub fn reset(&mut self) -> Result<(), AudioError> { check(unsafe { ffi::af_chain_stream_reset(self.h) }) }
+    /// Frames step 0 consumes / frames of history every later step reads in front of its own.
+    pub fn first_step_frames(&self) -> usize { unsafe { ffi::af_chain_stream_first_step_frames(self.h) } }
+    pub fn history_frames(&self) -> usize { unsafe { ffi::af_chain_stream_history_frames(self.h) } }
+    /// Time sharding: continue as if `step` steps had run; returns the frame the next push must start at.
+    pub fn seek(&mut self, step: u64) -> Result<u64, AudioError> {
+        let mut first = 0u64;
+        check(unsafe { ffi::af_chain_stream_seek(self.h, step, &mut first) })?;
+        Ok(first)
+    }
 }
 impl<T: PcmSample> Drop for ChainStream<T> { fn drop(&mut self) { unsafe { ffi::af_chain_stream_destroy(self.h) } } }
 

@@ -223,6 +223,14 @@ int main()
         rows.insert(rows.end(), r3.begin(), r3.end());
         auto whole = chain.run(long_x, 1, 5 * n);
         CHECK(cs.step_frames() == 184320 && rows.size() == cs.total_rows(5 * n) * 80 && rows == whole);
+        // time sharding: a second "rank" starts at step 1 (history first) and produces the rest of the rows
+        const uint64_t first = cs.seek(1);
+        CHECK(first == cs.first_step_frames() - cs.history_frames());
+        auto tail_rows = cs.push(std::vector<float>(long_x.begin() + 2 * first, long_x.end()));
+        auto tail_flush = cs.flush();
+        tail_rows.insert(tail_rows.end(), tail_flush.begin(), tail_flush.end());
+        const size_t rows0 = 184320 / 3 / 256 * 80;
+        CHECK(tail_rows.size() == whole.size() - rows0 && std::equal(tail_rows.begin(), tail_rows.end(), whole.begin() + rows0));
     }
     std::printf(failures ? "%d check(s) failed\n" : "harness ok\n", failures);
     return failures ? 1 : 0;

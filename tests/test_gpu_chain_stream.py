@@ -451,6 +451,53 @@ def test_chain_stream_ten_minutes_bit_equal_to_one_shot(af):
     assert np.median(wall_ms) * 1e-3 < step_s / 100
 
 
+@pytest.mark.parametrize("ch,fmt,world", [(2, 0, 8), (2, 1, 3), (1, 0, 5), (1, 1, 2)])
+def test_chain_stream_time_sharded_equals_one_shot(af, ch, fmt, world):
+    """Config 5 on the chain across GPUs: the recording's steps dealt to `world` ranks (shard.chain_stream_shards), each
+    rank seeks to its first step, pushes ITS frames (history first) and the last one flushes; the ranks' rows in rank
+    order == af_chain_run on the whole recording, bit for bit.  The ranks run one after the other on this one GPU; the
+    world_size-2 gloo test covers the dealing across processes."""
+    torch = pytest.importorskip("torch")
+    from audio_flow_rs_amd.shard import chain_stream_shards
+    sr = 48000
+    taps = lowpass_taps()
+    st = af.ChainStream(step_frames=184320, channels=ch, fir_taps=taps, sample_format=fmt)
+    n = st.first_step_frames + 10 * st.step_frames + 70001         # 11 whole steps and a tail
+    gen = torch.Generator().manual_seed(100 + world)
+    x = (torch.rand(n, ch, generator=gen) * 2 - 1).mul_(0.4).numpy()
+    if fmt:
+        x = _as_i16(x)
+    one = af.ChainPipeline(channels=ch, fir_taps=taps, sample_format=fmt)
+    one.set_batch_uniform(1, n)
+    full = one.run(x.reshape(-1))
+    shards = chain_stream_shards(n, world, st.first_step_frames, st.step_frames, st.history_frames)
+    assert [s[0] for s in shards][0] == 0 and shards[-1][1] == 11 and shards[-1][4]
+    rows = []
+    for k0, k1, lo, hi, flush in shards:
+        if k0 == k1 and not flush:
+            continue
+        assert st.seek(k0) == lo
+        r = st.push(x[lo:hi])
+        rps = st.step_frames // 3 // 256                          # rows per step: 48 k -> 16 k, hop 256
+        assert r.shape[0] == (k1 - k0) * rps
+        assert np.array_equal(r, full[k0 * rps:k1 * rps])
+        rows.append(r)
+        if flush:
+            rows.append(st.flush())
+    got = np.concatenate(rows)
+    assert got.shape == full.shape
+    assert np.array_equal(got, full)
+    # a rank that is handed too few frames for its history cannot flush
+    st.seek(3)
+    st.push(x[:100])
+    with pytest.raises(af.AudioError, match="history"):
+        st.flush()
+    # seek(0) is a plain restart
+    assert st.seek(0) == 0
+    r0 = st.push(x[:st.first_step_frames])
+    assert np.array_equal(r0, full[:r0.shape[0]])
+
+
 def test_chain_stream_needs_the_fused_launch(af):
     with pytest.raises(af.AudioError, match="no fused"):
         af.ChainStream(input_rate=44100, fir_taps=lowpass_taps())

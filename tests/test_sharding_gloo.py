@@ -48,6 +48,32 @@ def test_stream_shards_reproduce_one_shot_framing(af, po):
         stream_shards(1000, 2, 1000)
 
 
+def test_chain_stream_shards_cover_the_recording():
+    # the chain's time sharding (ChainStream.seek): every step belongs to exactly one rank, a rank's frames start one
+    # history in front of its first step and end where its last step's input ends; the last rank holds the tail
+    from audio_flow_rs_amd.shard import chain_stream_shards
+    need0, step, hist = 186654, 184320, 3453
+    for n_frames in (0, 1000, need0 - 1, need0, need0 + step - 1, need0 + step, need0 + 17 * step + 999):
+        n_steps = 0 if n_frames < need0 else 1 + (n_frames - need0) // step
+        for world in (1, 2, 3, 8, 32):
+            shards = chain_stream_shards(n_frames, world, need0, step, hist)
+            assert len(shards) == world
+            assert [s[4] for s in shards] == [False] * (world - 1) + [True]
+            pos = 0
+            for k0, k1, lo, hi, flush in shards:
+                assert k0 == pos and k1 >= k0
+                pos = k1
+                if k0 == k1 and not flush:
+                    assert lo == hi == 0
+                    continue
+                assert lo == (0 if k0 == 0 else need0 + (k0 - 1) * step - hist)
+                assert hi == (n_frames if flush else need0 + (k1 - 1) * step)
+                assert 0 <= lo <= hi <= n_frames
+            assert pos == n_steps
+    with pytest.raises(ValueError):
+        chain_stream_shards(100, 2, 10, 10, 11)
+
+
 def _worker(rank, world, port, n_clips, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
