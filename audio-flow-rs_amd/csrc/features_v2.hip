@@ -37,6 +37,13 @@
 #ifndef AF_V2_ALL_SLOTS
 #define AF_V2_ALL_SLOTS 0
 #endif
+// staging loads of the next unit requested at the top of a unit; the others go out behind FFT part 1 (99: all at the top)
+#ifndef AF_V2_PF_EARLY
+#define AF_V2_PF_EARLY 99
+#endif
+#ifndef AF_V2_TW_EARLY
+#define AF_V2_TW_EARLY 0
+#endif
 
 namespace af {
 namespace feat {
@@ -197,16 +204,16 @@ __device__ __forceinline__ void fft_pair_1(const float (&s)[20], const float (&w
 {
     const int k1 = lane & 15, hi = lane >> 4;
     float re[16], im[16];
-#ifdef AF_V2_TW_EARLY
-    // (experiment) the twiddle row requested by hand in front of the transform: hipcc sinks plain loads below it
-    f32x4 twr[8];
-    {
+    // (experiment, AF_V2_TW_EARLY = n > 0) the first n pieces of the twiddle row requested by hand in front of the
+    // transform: hipcc sinks plain loads below it
+    constexpr int kTwEarly = AF_V2_TW_EARLY;
+    f32x4 twr[kTwEarly > 0 ? kTwEarly : 1];
+    if constexpr (kTwEarly > 0) {
         const unsigned ta = (unsigned)reinterpret_cast<uintptr_t>(tw1 + lane * kTw1Row);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
+        for (int jj = 0; jj < kTwEarly; ++jj)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(twr[jj]) : "v"(ta), "n"(16 * jj));
     }
-#endif
 
     // ---- stage 1: z[64 n1 + n2] = w * (a + i b); frame b = frame a shifted by
     // kHop samples = 4 registers.  The window multiply is fused into the twiddle-free first DIT
@@ -230,20 +237,20 @@ __device__ __forceinline__ void fft_pair_1(const float (&s)[20], const float (&w
     // of 36 dwords collide) and the eight reads cost 116 LDS cycles per frame pair instead of 32
     // (scripts/ablate/lds_groups.sh: all of SQ_LDS_BANK_CONFLICT came from here).
     {
-#ifdef AF_V2_TW_EARLY
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(twr[0]), "+v"(twr[1]), "+v"(twr[2]), "+v"(twr[3]), "+v"(twr[4]), "+v"(twr[5]),
-                       "+v"(twr[6]), "+v"(twr[7]));
-#else
         const float4* trow = reinterpret_cast<const float4*>(tw1 + lane * kTw1Row);
-#endif
+        float4 late[8];
+#pragma unroll
+        for (int jj = kTwEarly; jj < 8; ++jj) late[jj] = (AF_ABL & 4) ? float4{abl_val(lane, jj), 0.5f, 0.25f, 0.125f} : trow[jj];
+        if constexpr (kTwEarly > 0) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the hand-issued reads (and the ones above)
+#pragma unroll
+            for (int jj = 0; jj < kTwEarly; ++jj) asm volatile("" : "+v"(twr[jj]));
+        }
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-#ifdef AF_V2_TW_EARLY
-            const float4 t = float4{twr[jj][0], twr[jj][1], twr[jj][2], twr[jj][3]};
-#else
-            const float4 t = (AF_ABL & 4) ? float4{abl_val(lane, jj), 0.5f, 0.25f, 0.125f} : trow[jj];
-#endif
+            const float4 t = jj < kTwEarly ? float4{twr[jj < kTwEarly ? jj : 0][0], twr[jj < kTwEarly ? jj : 0][1],
+                                                    twr[jj < kTwEarly ? jj : 0][2], twr[jj < kTwEarly ? jj : 0][3]}
+                                           : late[jj];
             {
                 const float xr = re[2 * jj + 1], xi = im[2 * jj + 1];
                 re[2 * jj + 1] = __builtin_fmaf(xr, t.x, xi * t.y);
@@ -523,8 +530,9 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
 
         const bool has_next = (u + 1 < u_end) && (ud.flags & 1);
         uint4 pf[PFU];
-        const auto issue_prefetch = [&]() {
-            if (has_next) {
+        const auto issue_prefetch = [&](auto lo_c, auto hi_c) {
+            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+            if (has_next && LO < HI) {
                 // (lane offsets from an opaque copy of tid: hoisted out of the unit loop they end up in scratch,
                 // and a scratch reload waits for every outstanding vector memory operation)
                 const int t0 = opaque_tid(tid);
@@ -532,18 +540,18 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                     const char* src = static_cast<const char*>(p.pcm) +
                                       (ud.pcm0 + kTile) * St::kBytesPerFrame;
 #pragma unroll
-                    for (int i = 0; i < PFU; ++i)
+                    for (int i = LO; i < HI; ++i)
                         pf[i] = *reinterpret_cast<const uint4*>(src + (unsigned)(t0 + i * kT) * 16u);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < PFU; ++i)
+                    for (int i = LO; i < HI; ++i)
                         pf[i] = St::load_raw(p.pcm, ud.pcm0, kTile + (int64_t)(t0 + i * kT) * MS, n_avail, true);
                 }
             }
         };
-#ifndef AF_V2_PF_LATE
-        issue_prefetch();
-#endif
+        // AF_V2_PF_EARLY of the PFU staging loads go out here, the rest behind part 1 (experiment: default all here)
+        constexpr int kPfEarly = AF_V2_PF_EARLY < PFU ? AF_V2_PF_EARLY : PFU;
+        issue_prefetch(std::integral_constant<int, 0>{}, std::integral_constant<int, kPfEarly>{});
 
         float wf[NSLOT * kSlotSteps];
         {
@@ -555,9 +563,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             float s1[20], win[16];
             stage1_load(tile, w, lane, wtab, s1, win);
             fft_pair_1(s1, win, wb, wv, lane, tw1, ur, ui);
-#ifdef AF_V2_PF_LATE
-            issue_prefetch();                        // (experiment) behind part 1: 16 more free registers in it
-#endif
+            issue_prefetch(std::integral_constant<int, kPfEarly>{}, std::integral_constant<int, PFU>{});
 
             AF_STAMP2(2);
             // This wave's filterbank fragments (L2-resident, one float4 per slot), issued where the

@@ -25,7 +25,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement):
   roofline  = algorithmic bytes per launch / measured launch time vs 8 TB/s HBM
   cpu_baseline = the oracle's float32 port timed on this host (rank 0, N=1 only)
   check     = three clips of the result against the float64 oracle, after the timed region
-  secondary = BASELINE config 4's chain on the same shard (N=1 only)
+  secondary = BASELINE config 4's chain on the same shard, north_star's own 1024-clip batch, and the resampler
+              alone on config 3 and on 48 -> 44.1 kHz (N=1 only; each with its own oracle check, none is `value`)
 """
 from __future__ import annotations
 
@@ -252,6 +253,51 @@ def chain_secondary(torch, af, dev, pcm, n_clips: int, n_frames_pcm: int, stream
                       "algorithmic_bytes": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9,
                       "frac_hbm": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "launches": chain.n_launches()}}
+
+
+def resample_secondary(torch, af, dev) -> dict:
+    """The polyphase resampler on its own, device-resident, HIP events: BASELINE config 3 (4096 mono clips of 10 s,
+    44.1 -> 16 kHz: ten block matrices, banded_kernel) and the everyday device ratio 48 -> 44.1 kHz (147 block
+    matrices: banded_stream_kernel) on 1024 x 30 s; first clip of each against the float64 oracle."""
+    import ctypes as C
+    import numpy as np
+    from oracle import pyoracle as po
+    lib = af.library()
+    out = {}
+    for key, fi, fo, nc, secs in (("resample_config3", 44100, 16000, 4096, 10), ("resample_48k_44k1", 48000, 44100, 1024, 30)):
+        nin = fi * secs
+        nout = int(lib.af_resample_out_len(fi, fo, nin))
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(SEED0 + fi)
+        x = (torch.rand(nc, nin, device=dev, generator=gen) - 0.5) * 0.8
+        y = torch.empty(nc, nout, device=dev)
+        run = lambda: lib.af_resample_batch_device(fi, fo, C.c_void_p(x.data_ptr()), nc, nin, C.c_void_p(y.data_ptr()), None)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.2:
+            st = run()
+            torch.cuda.synchronize()
+            if st != 0:
+                raise SystemExit(f"af_resample_batch_device({fi}, {fo}) failed: "
+                                 f"{lib.af_last_error().decode('utf-8', 'replace')}")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        ref = po.resample(x[0].cpu().numpy(), fi, fo)
+        got = y[0].cpu().numpy().astype(np.float64)
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        alg = (x.numel() + y.numel()) * 4
+        out[key] = {"workload": f"{nc} x {secs} s mono {fi} -> {fo} Hz, 64 taps per phase", "ms": ms,
+                    "samples_out_per_s": nc * nout / (ms * 1e-3), "rtf": nc * secs / (ms * 1e-3),
+                    "algorithmic_bytes": alg, "frac_hbm": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "useful_tflops": 2 * 64 * nc * nout / (ms * 1e-3) / 1e12,
+                    "max_err_vs_oracle": err, "ok": err < 1e-5}
+        del x, y
+    return out
 
 
 def parse_args(argv=None):
@@ -524,6 +570,7 @@ def run_rank(args) -> None:
         if args.northstar_clips > 0:
             m["secondary"].update(northstar_secondary(torch, af, dev, args.northstar_clips, n_frames_pcm,
                                                       stream, local_rank))
+            m["secondary"].update(resample_secondary(torch, af, dev))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         k = max(1, min(args.cpu_clips, n_clips))
         m["cpu_baseline"] = cpu_baseline(pcm[:k].cpu().numpy(), k, n_frames_pcm)
