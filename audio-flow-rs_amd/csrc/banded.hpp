@@ -43,6 +43,7 @@ struct Plan {
     // fetches the fragments of its next matrix (L2-resident table) while it multiplies with the current one.
     bool streamed = false;
     int P = 0, C = 0;         // matrices per tile, column sets (of 16 periods) per tile
+    int ob_off = 0, ob_stride = 0;   // streamed, deferred stores: LDS image of a tile's outputs (floats), 0: direct stores
     // fragments [nb][NK][64]; streamed plans keep q(16 p), p = 0..nb, as ints behind them
     size_t afrag_floats() const { return (size_t)nb * NK * 64 + (streamed ? (size_t)nb + 1 : 0); }
 };

@@ -321,6 +321,7 @@ struct StreamGeom {
     int64_t n_tiles;
     int lo_off;
     int nb, S, P, C, seg_len, seg_stride;
+    int ob_off, ob_stride;           // deferred stores: the tile's outputs in LDS, [16 C periods][ob_stride] floats from ob_off
 };
 
 // wave-uniform table entry through the scalar cache (a vector load would count in vmcnt, and waiting for it would
@@ -331,13 +332,35 @@ __device__ __forceinline__ int sload_int(const int* base, int idx)
     return reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(base))[__builtin_amdgcn_readfirstlane(idx)];
 }
 
-template <int NK, int C>
+// AF_STREAM_ABL (diagnostic builds only, scripts/ablate/): parts of the streamed kernel compiled OUT, to see which
+// resource its time belongs to: 1 x requests, 2 stores, 4 fragment requests (first tile's stay), 8 MFMAs (one VALU
+// operation each instead), 16 staging writes, 32 barriers, 64 the whole chain arithmetic (memory side only), 128 stores go to the
+// wrong place, 1 KB contiguous per instruction, 256 to the wrong place in 128-byte runs from two consecutive instructions,
+// 512 to the wrong place in 128-byte runs inside one instruction.  Results are garbage; bounds stay checked by the hardware.
+#ifndef AF_STREAM_ABL
+#define AF_STREAM_ABL 0
+#endif
+#ifndef AF_STREAM_OB
+#define AF_STREAM_OB 1
+#endif
+// largest matrix range of a tile (experiment: 16 = always small enough for the deferred stores)
+#ifndef AF_STREAM_PMAX
+#define AF_STREAM_PMAX 32
+#endif
+// OB (deferred stores; where two workgroups per CU still fit): a chain's lane holds 16 bytes of one block, and a store
+// instruction straight from the accumulators writes 16 runs of 64 bytes, 16 nb floats apart -- measured on 48 -> 44.1 kHz
+// (scripts/ablate/stream_groups.sh): the same bytes in 1 KB runs per instruction make the whole launch 10 % shorter, in
+// 128-byte runs 4.6 %, and 64-byte pieces that are neighbours in TIME (two instructions) gain nothing.  So the chains
+// put their blocks into an LDS image of the tile's outputs, [16 C periods][P blocks], and the workgroup sends it out at
+// the top of the NEXT tile, between the two barriers that are there anyway: a period's row is P 64 bytes of consecutive
+// output, one store instruction covers a whole row or more.
+template <int NK, int C, bool OB>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void banded_stream_kernel(const StreamGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     constexpr int FULL = NK / 16, TAILQ = NK % 16;
     constexpr int kSegs = 16 * C;                                   // one segment per period of the tile
-    constexpr int nthreads = 512;
+    float* ob = xs + g.ob_off;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g4 = lane >> 4;
@@ -368,6 +391,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         voff = live && first ? ((uint32_t)(base - sh) + (uint32_t)(2 * pair + half * g.S + opaque_zero())) * 4u : kOob;
     };
     auto issue_load = [&](int i) {                                  // segment 2 i + half
+        if constexpr (AF_STREAM_ABL & 1) return;
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 v = __builtin_bit_cast(
             f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff + (uint32_t)(2 * i * g.S) * 4u), 0, 0));
@@ -378,7 +402,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     float a[2][NK];                                                 // this matrix, the next one
     static_assert(NK % 4 == 0, "fragment quads");
+    bool have_a = false;
     auto load_a = [&](int slot, int p) {
+        if ((AF_STREAM_ABL & 4) && have_a && slot == 0) return;
+        if ((AF_STREAM_ABL & 4) && slot == 1) return;
+        have_a = true;
         const f32x4* ap = reinterpret_cast<const f32x4*>(g.afrag) + ((size_t)p * (NK / 4)) * 64 + lane + opaque_zero();
 #pragma unroll
         for (int t4 = 0; t4 < NK / 4; ++t4) {
@@ -411,6 +439,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         return v;
     };
 
+    // OB: the previous tile's outputs wait in LDS (wave-uniform description)
+    bool prev = false;
+    const float* prev_y = nullptr;                                  // its clip's row of y
+    int64_t prev_m = 0;                                             // output index of its first block, minus m0
+    int prev_np = 0;                                                // matrices in its range
+    constexpr int kFlush = 4;                                       // 512 threads x 4 x 16 bytes: 32 KB, P <= 16
+    auto flush = [&]() {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        // (every thread issues kFlush stores whatever the range holds: what lies outside goes to an offset the range
+        // check drops, so the number of vector memory operations in front of the waits below does not depend on it)
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(prev_y), 0, (int)(uint32_t)(g.n_out * 4), 0x00020000);
+        const uint32_t n4row = (uint32_t)prev_np * 4u;              // 16-byte pieces per period
+        const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)prev_m);
+#pragma unroll
+        for (int k = 0; k < kFlush; ++k) {
+            const uint32_t f4 = (uint32_t)tid + 512u * k;
+            const uint32_t row = f4 / n4row, c4 = f4 - row * n4row;
+            const bool valid = row < (uint32_t)kSegs;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ob + (valid ? row : 0u) * (uint32_t)g.ob_stride + 4u * c4);
+            // 32 bits are enough: the tile grid reaches less than one tile past either end of the wanted outputs and
+            // launch_stream bounds n_out, so nothing wraps INTO the range the hardware accepts
+            const uint32_t off = (m_lo + row * (uint32_t)(16 * g.nb) + 4u * c4) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, (int)(valid ? off : kOob), 0, 0);
+        }
+    };
+
     uint32_t tile = blockIdx.x;
     TileQ tq{};
     if (tile < n_tiles) {
@@ -418,25 +473,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         prep_tile(tile, true, tq.q0);
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) issue_load(i);
-        int p0, p_end;
-        range_of(tile, p0, p_end);
-        if (p0 + wave < p_end) load_a(0, p0 + wave);
     }
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (; tile < n_tiles;) {
+        const uint32_t next_tile = tile + gridDim.x;
         const uint32_t clip = tile / tiles_per_clip, r = tile - clip * tiles_per_clip;
         const int64_t pg = g.pg0 + r / (uint32_t)g.n_pr;
         int p0, p_end;
         range_of(tile, p0, p_end);
-        // this wave's first matrix of the NEXT tile: requested under this tile's last chains (slot 0 is where
-        // every tile starts), so that no tile begins by waiting for an L2 round trip
-        const bool live = tile + gridDim.x < n_tiles;
-        int np0 = 0, np_end = 0;
-        if (live) range_of(tile + gridDim.x, np0, np_end);
-        const bool next_has = live && np0 + wave < np_end;
+        const bool live = next_tile < n_tiles;
         const TileQ cq = tq;                                        // this tile's; the next tile's are requested now
-        if (live) tq = load_q(tile + gridDim.x);
-        __syncthreads();                                            // readers of the previous tile done
-        if (2 * pair < g.seg_len + sh) {
+        if (live) tq = load_q(next_tile);
+        // matrices p0 + wave + 8 i, i < n_m.  Both fragment slots are free here: the first matrix is requested now and
+        // lands under the staging below.  (The first version requested it under the previous tile's last chain, into
+        // whichever slot was free, and moved it to slot 0 when that was slot 1: with three matrices per wave -- the
+        // 48 <-> 44.1 kHz case -- every tile ended on a full L2 round trip in front of 20 v_mov.)
+        // A wave without a matrix in this range (the last, shorter range of a period only) still runs ONE chain, on the
+        // range's last matrix with its stores switched off: the x requests of the next tile then sit in the same place
+        // of the instruction stream for every wave (as a separate branch their staging registers were "possibly in
+        // flight" at the join in front of the first chain, and that chain began with s_waitcnt vmcnt(0) in every tile).
+        const bool idle = p0 + wave >= p_end;
+        const int n_m = idle ? 1 : (p_end - p0 - wave + 7) / 8;
+        const int pw = idle ? p_end - 1 : p0 + wave;
+        load_a(0, pw);
+        if constexpr (!(AF_STREAM_ABL & 32)) __syncthreads();       // readers of the previous tile done
+        if constexpr (OB) {
+            if (prev) flush();                                      // (its chains are all behind the barrier above)
+        }
+        if (2 * pair < g.seg_len + sh && !(AF_STREAM_ABL & 16)) {
             float* dst = xs + 1 - sh + 2 * pair + half * g.seg_stride + opaque_zero();
 #pragma unroll
             for (int i = 0; i < kLoads; ++i) {
@@ -444,8 +507,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 dst[2 * i * g.seg_stride + 1] = pf[2 * i + 1];
             }
         }
-        __syncthreads();
-        prep_tile(live ? tile + gridDim.x : tile, live, tq.q0);
+        if constexpr (!(AF_STREAM_ABL & 32)) __syncthreads();
+        prep_tile(live ? next_tile : tile, live, tq.q0);
         float* yc = g.y + (int64_t)clip * g.y_stride - g.m0;        // where absolute output 0 of the clip would be
         const int q0 = cq.q0;
         // one chain pair: matrix p (fragments in a[SLOT]) times the 16 periods of column set 0 and of column set 1, two
@@ -467,14 +530,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 w0[t % (kAhead + 1)] = src[0];
                 w1[t % (kAhead + 1)] = src[set1];
             };
+            if constexpr (AF_STREAM_ABL & 64) {                      // memory side only: requests, no LDS reads, no MFMA
+                acc0[0] = a[SLOT][0] + a[SLOT][NK - 1];
+                acc1[0] = a[SLOT][1];
+                if (LOADS) {
 #pragma unroll
-            for (int t = 0; t < kAhead && t < NK; ++t) read_b(t);
+                    for (int s2 = 0; s2 < kLoads; ++s2) issue_load(s2);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kAhead && t < NK && !(AF_STREAM_ABL & 64); ++t) read_b(t);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < NK; ++t) {
+            for (int t = 0; t < ((AF_STREAM_ABL & 64) ? 0 : NK); ++t) {
                 if (t + kAhead < NK) read_b(t + kAhead);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SLOT][t], w0[t % (kAhead + 1)], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SLOT][t], w1[t % (kAhead + 1)], acc1, 0, 0, 0);
+                if constexpr (AF_STREAM_ABL & 8) {
+                    acc0[t & 3] = __builtin_fmaf(a[SLOT][t], w0[t % (kAhead + 1)], acc0[t & 3]);
+                    acc1[t & 3] = __builtin_fmaf(a[SLOT][t], w1[t % (kAhead + 1)], acc1[t & 3]);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SLOT][t], w0[t % (kAhead + 1)], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SLOT][t], w1[t % (kAhead + 1)], acc1, 0, 0, 0);
+                }
                 if (LOADS) {
                     constexpr int kSpan = (NK + 1) / 2;
                     if (t < kSpan) {
@@ -485,11 +561,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
             // block b = period * nb + p of column `col`: rows 4 g4 .. 4 g4 + 3
+            if constexpr (OB) {
+                if (!idle) {
+                    float* o = ob + col * g.ob_stride + (p - p0) * 16 + 4 * g4;
+                    *reinterpret_cast<f32x4*>(o) = acc0;
+                    *reinterpret_cast<f32x4*>(o + 16 * g.ob_stride) = acc1;
+                }
+                return;
+            }
 #pragma unroll
             for (int cs = 0; cs < 2; ++cs) {
                 const f32x4 acc = cs ? acc1 : acc0;
                 const int64_t period = pg * kSegs + cs * 16 + col;
-                const int64_t m = 16 * (period * g.nb + p) + 4 * g4;
+                int64_t m = (idle || (AF_STREAM_ABL & 2)) ? -8 : 16 * (period * g.nb + p) + 4 * g4;     // (idle: in front of every m0)
+                if constexpr (AF_STREAM_ABL & 256)                  // (diagnostic: the two column sets' chunks side by side: 128 B runs)
+                    m = 16 * ((pg * kSegs + col) * (int64_t)g.nb + (p & ~1) + cs) + 4 * g4 + ((p & 1) ? 16 * (int64_t)g.nb * 16 : 0);
+                if constexpr (AF_STREAM_ABL & 512)                  // (diagnostic: wrong place, 128-byte runs inside ONE instruction)
+                    m = 16 * ((pg * kSegs + cs * 16 + (col & ~1) + (p & 1)) * (int64_t)g.nb + (p & ~1) + (col & 1)) + 4 * g4;
+                if constexpr (AF_STREAM_ABL & 128)                  // (diagnostic: wrong place, 1 KB contiguous per instruction)
+                    m = 16 * ((pg * kSegs + cs * 16) * (int64_t)g.nb + (int64_t)p * 16) + 4 * lane;
                 float* o = yc + m;
                 if (m >= g.m0 && m + 4 <= g.m0 + g.n_out && ((reinterpret_cast<uintptr_t>(o) >> 2) & 3) == 0) {
                     *reinterpret_cast<f32x4*>(o) = acc;
@@ -502,30 +592,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
-        // matrices p0 + wave + 8 i, i < n_m, fragment slots alternating at compile time (a runtime slot index would
-        // cost a select per MFMA operand); the last one shares its chains with the next tile's first fragments
-        const int n_m = p0 + wave < p_end ? (p_end - p0 - wave + 7) / 8 : 0;
-        if (n_m == 0) {
-#pragma unroll
-            for (int s2 = 0; s2 < kLoads; ++s2) issue_load(s2);     // a wave without a matrix in this range
-            if (next_has) load_a(0, np0 + wave);
-        }
+        // fragment slots alternate at compile time (a runtime slot index would cost a select per MFMA operand)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                // P <= 32: at most four matrices per wave
-            if (i < n_m) {
-                const int p = p0 + wave + 8 * i;
-                const bool last = i + 1 == n_m;
-                if (!last) load_a((i & 1) ^ 1, p + 8);
-                else if (next_has) load_a((i & 1) ^ 1, np0 + wave);  // into the free slot
-                if (i == 0) chain(p, cq.q[0], S0{}, std::true_type{});
+            if (i == 0 || i < n_m) {                                 // (n_m >= 1: the first chain is unconditional)
+                const int p = pw + 8 * i;
+                if (i + 1 < n_m) load_a((i & 1) ^ 1, p + 8);
+                if (i == 0) chain(p, idle ? sload_int(g.qtab, p) : cq.q[0], S0{}, std::true_type{});
                 else if ((i & 1) == 0) chain(p, cq.q[i], S0{}, std::false_type{});
                 else chain(p, cq.q[i], S1{}, std::false_type{});
-                if (last && next_has && (i & 1) == 0) {
-                    // the free slot was 1: every tile starts in slot 0
-#pragma unroll
-                    for (int t = 0; t < NK; ++t) a[0][t] = a[1][t];
-                }
             }
+        }
+        if constexpr (OB) {
+            prev = true;
+            prev_y = g.y + (int64_t)clip * g.y_stride;
+            prev_m = 16 * ((pg * kSegs) * (int64_t)g.nb + p0) - g.m0;
+            prev_np = p_end - p0;
+        }
+        tile = next_tile;
+    }
+    if constexpr (OB) {
+        if (prev) {
+            __syncthreads();
+            flush();
         }
     }
 }
@@ -901,7 +990,7 @@ Plan make_stream_plan(Plan p, uint64_t nb, uint64_t S)
     // the largest range of matrices (a multiple of the 8 waves) whose windows fit one 512-sample segment
     auto q16 = [&](uint64_t pp) { return (16 * pp * p.M) / p.L; };
     int best = 0, best_len = 0;
-    for (int P = 32; P >= 8; P -= 8) {
+    for (int P = AF_STREAM_PMAX; P >= 8; P -= 8) {
         uint64_t span = 0;
         for (uint64_t p0 = 0; p0 < nb; p0 += P) {
             const uint64_t last = std::min<uint64_t>(p0 + P, nb) - 1;
@@ -923,6 +1012,19 @@ Plan make_stream_plan(Plan p, uint64_t nb, uint64_t S)
     p.seg_stride = (best_len + 2) | 1;         // odd (bank-conflict-free operand reads); a lead-in word and a pair's odd end
     p.out_per_tile = (int64_t)256 * best * kStreamC;
     p.smem = (size_t)16 * kStreamC * p.seg_stride * sizeof(float);
+    // deferred stores (banded_stream_kernel, OB): an LDS image of the tile's outputs behind the segments, rows padded by
+    // four floats (the chains' 16-byte writes of one column group then hit 16 different bank quads) -- where two
+    // workgroups per CU still fit
+    if (AF_STREAM_OB && best <= 16) {
+        const int ob_off = (16 * kStreamC * p.seg_stride + 3) & ~3;
+        const int ob_stride = best * 16 + 4;
+        const size_t total = ((size_t)ob_off + (size_t)16 * kStreamC * ob_stride) * sizeof(float);
+        if (total <= 80 * 1024) {
+            p.ob_off = ob_off;
+            p.ob_stride = ob_stride;
+            p.smem = total;
+        }
+    }
     p.ok = true;
     return p;
 }
@@ -997,9 +1099,15 @@ namespace {
 template <int NK>
 af_status launch_stream_nk(const StreamGeom& g, unsigned grid, size_t smem, hipStream_t s)
 {
-    static LdsAttrFlags attr_set;
-    AF_HIP(allow_big_lds(banded_stream_kernel<NK, kStreamC>, 160 * 1024, attr_set));
-    hipLaunchKernelGGL((banded_stream_kernel<NK, kStreamC>), dim3(grid), dim3(512), smem, s, g);
+    if (g.ob_stride) {
+        static LdsAttrFlags attr_set;
+        AF_HIP(allow_big_lds(banded_stream_kernel<NK, kStreamC, true>, 160 * 1024, attr_set));
+        hipLaunchKernelGGL((banded_stream_kernel<NK, kStreamC, true>), dim3(grid), dim3(512), smem, s, g);
+    } else {
+        static LdsAttrFlags attr_set;
+        AF_HIP(allow_big_lds(banded_stream_kernel<NK, kStreamC, false>, 160 * 1024, attr_set));
+        hipLaunchKernelGGL((banded_stream_kernel<NK, kStreamC, false>), dim3(grid), dim3(512), smem, s, g);
+    }
     AF_HIP(hipGetLastError());
     return AF_OK;
 }
@@ -1026,6 +1134,11 @@ af_status launch_stream(const Plan& p, const float* afrag_dev, const float* x_de
     g.n_pr = (p.nb + p.P - 1) / p.P;
     g.n_tiles = g.n_pg * g.n_pr * n_clips;
     if (g.n_tiles >= (1ll << 31)) return fail(AF_ERR_UNSUPPORTED, "banded::launch: too many tiles");
+    // deferred stores address y with 32-bit byte offsets from output m0 of a clip; a tile reaches at most 16 * 16 C * nb
+    // outputs past either end of [m0, m0 + n_out), and neither side may wrap into the range the hardware accepts
+    const bool ob = p.ob_stride != 0 && n_out + (int64_t)2 * 256 * p.C * p.nb < (1ll << 29);
+    g.ob_off = ob ? p.ob_off : 0;
+    g.ob_stride = ob ? p.ob_stride : 0;
     g.lo_off = p.c - (p.T - 1);
     g.nb = p.nb;
     g.S = p.S;
