@@ -6,7 +6,7 @@ set -e
 cd "$GRAFT_REPO_ROOT"
 TAG="$1"; shift
 O="gpurun_out/r03/$TAG"; mkdir -p "$O"
-export AF_BENCH_ONLY=48000_44100
+export AF_BENCH_ONLY="${AF_BENCH_ONLY:-48000_44100}"
 python3 scripts/gpu_bench_resample_ratios.py > "$O/product.json" 2> "$O/product.err"
 for n in "$@"; do
   AF_BENCH_LIB="build/ablate/libaf_$n.so" python3 scripts/gpu_bench_resample_ratios.py > "$O/$n.json" 2> "$O/$n.err" || true

@@ -152,7 +152,8 @@ def test_banded_plan_invariants(af):
         p = plan(fi, fo)
         assert (p["ok"], p["nb"], p["S"], p["NK"], p["G"], p["nwaves"]) == (1, nb, S, nk, 0, 8)
         assert p["seg_len"] <= 511 and p["seg_stride"] % 2 == 1 and p["seg_stride"] >= p["seg_len"] + 2
-        assert p["smem"] == 32 * p["seg_stride"] * 4 <= 80 * 1024
+        # (segments, plus the image of the tile's outputs where the deferred stores fit: two workgroups per CU either way)
+        assert 32 * p["seg_stride"] * 4 <= p["smem"] <= 80 * 1024
         assert plan(fi, fo, 2)["ok"] == 0                     # stereo staging: resident matrices only
     short = 0
     for fi, fo in [(44100, 16000), (48000, 16000), (16000, 48000), (8000, 16000), (22050, 16000),
