@@ -1060,7 +1060,10 @@ Plan make_plan(uint32_t L, uint32_t M, int T, int c, int ch)
     p.wpp = nb >= 5 ? 1 : nb == 1 ? 8 : nb == 2 ? 4 : 2;
     p.nwaves = p.nb * p.wpp;
     const int nthreads = 64 * p.nwaves;
-    if (ch == 2 && (p.nwaves > 8 || p.NK > 32)) return p;     // stereo staging: 8-wave shapes only
+    // stereo staging holds (L, R) pairs: 128 registers (four waves per SIMD), i.e. ONE workgroup per CU for the shapes
+    // with more than eight waves (44.1 k -> 16 k: ten) -- still one pass over the stereo PCM instead of to_mono + a
+    // mono resampler pass
+    if (ch == 2 && (p.nwaves > 16 || p.NK > 32)) return p;
     // mono x is staged in sample pairs (lead-in word, odd end) except in the shapes launch() runs at five waves per SIMD
     const bool pairs = ch == 1 && AF_BANDED_PAIRS && !(p.nwaves > 8 && p.NK <= 32);
     p.pairs = pairs;
@@ -1197,7 +1200,7 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
     g.seg_len = p.seg_len;
     g.seg_stride = p.seg_stride;
     g.accumulate = accumulate ? 1 : 0;
-    const int wg_per_cu = (2 * 64 * p.nwaves <= 2048 && 2 * p.smem <= 150 * 1024) ? 2 : 1;
+    const int wg_per_cu = (2 * 64 * p.nwaves <= 2048 && 2 * p.smem <= 150 * 1024 && !(p.ch == 2 && p.nwaves > 8)) ? 2 : 1;
     int64_t grid = g.n_tiles;
     const int64_t n_cus = device_cu_count(current_device());
     if (grid > n_cus * wg_per_cu) grid = n_cus * wg_per_cu;

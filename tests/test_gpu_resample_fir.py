@@ -340,7 +340,8 @@ def test_fir_streaming_chunk_invariance_mfma(af, po):
     assert rel_err(whole, po.fir(x, taps)) < 1e-5
 
 
-@pytest.mark.parametrize("fi,fo", [(48000, 16000), (16000, 48000), (8000, 16000), (16000, 16000)])
+@pytest.mark.parametrize("fi,fo", [(48000, 16000), (16000, 48000), (8000, 16000), (16000, 16000), (44100, 16000),
+                                   (44100, 48000)])
 @pytest.mark.parametrize("n", [1, 33, 1000, 30011])
 def test_fused_stereo_downmix_resample(af, po, fi, fo, n):
     # to_mono (capture.rs:30-42) inside the resampler's loads == to_mono, then resample
@@ -356,8 +357,8 @@ def test_fused_stereo_downmix_resample(af, po, fi, fo, n):
 
 def test_fused_stereo_path_is_reported_per_ratio(af):
     lib = af.library()
-    assert lib.af_resample_has_stereo_path(44100, 16000) == 0     # 10-wave shape: separate to_mono
-    assert lib.af_resample_has_stereo_path(48000, 44100) == 0     # VALU kernel ratio
+    assert lib.af_resample_has_stereo_path(44100, 16000) == 1     # ten-wave shape: one workgroup per CU, still one pass
+    assert lib.af_resample_has_stereo_path(48000, 44100) == 0     # streamed matrices: separate to_mono
 
 
 def test_resample_batch_host_path_pipelined_from_pinned_memory(af):

@@ -145,7 +145,9 @@ def test_banded_plan_invariants(af):
     assert (p["ok"], p["L"], p["M"], p["nb"], p["S"], p["NK"], p["G"], p["nwaves"]) == (1, 160, 441, 10, 441, 28, 2, 10)
     p = plan(48000, 16000)
     assert (p["ok"], p["L"], p["M"], p["nb"], p["S"], p["NK"], p["nwaves"]) == (1, 1, 3, 1, 48, 28, 8)
-    assert plan(48000, 16000, 2)["ok"] == 1 and plan(44100, 16000, 2)["ok"] == 0
+    assert plan(48000, 16000, 2)["ok"] == 1
+    p2 = plan(44100, 16000, 2)                                # stereo staging of the ten-wave shape: same tiles as mono
+    assert (p2["ok"], p2["nb"], p2["NK"], p2["G"], p2["nwaves"]) == (1, 10, 28, 2, 10)
     # more than 16 block matrices: the streamed form (G = 0 marks it): 8 waves, matrices fetched per tile, a tile =
     # a range of matrices x 32 block periods, one LDS segment (<= 511 samples, odd stride) per period
     for fi, fo, nb, S, nk in [(48000, 44100, 147, 2560, 24), (16000, 44100, 441, 2560, 20), (48000, 22050, 147, 5120, 28)]:
