@@ -7,8 +7,8 @@
 // caller's stream.  All intermediate buffers are allocated when the batch is described, so
 // af_chain_run_device() only launches kernels (it can be captured into a hipGraph and replayed per
 // streaming step).  Batches are equal-length clips (af_chain_set_batch_uniform) or ragged ones
-// (af_chain_set_batch: AudioFrame is variable-length, capture.rs:13-28); PCM is f32 or the wire
-// format's i16 (websocket.rs:246-251).
+// (af_chain_set_batch: AudioFrame is variable-length, capture.rs:13-28; stage by stage they run as ONE
+// strip with zero gaps, see strip_layout); PCM is f32 or the wire format's i16 (websocket.rs:246-251).
 //
 // af_chain_stream_* (BASELINE config 5 on the whole chain): one handle owns the input history the
 // resampler, the FIR (K - 1 samples) and the STFT (n_fft - hop samples) need, and replays ONE captured
@@ -45,6 +45,13 @@ struct af_chain {
     size_t total_frames = 0;
     DevBuf d_tiles;                                  // ragged + fused: banded::FusedTile per tile
     int64_t n_tiles = 0;
+    // ragged, stage by stage: the clips as ONE strip with zero gaps (see strip_layout below)
+    struct StripGroup { int64_t p0, p_len, r0, r_len; };      // one launch of resampler / FIR each
+    std::vector<int64_t> p_off;                      // mono f32 sample at which clip i starts in the strip
+    std::vector<StripGroup> groups;
+    int64_t total_p = 0, total_r = 0;
+    bool strip_ready = false, strip_ok = true;
+    DevBuf d_strip, d_clips;                         // the strip; device table {src frame, frames, strip sample, gap begin, gap end}
     DevBuf d_f32, d_mono, d_res, d_fir, d_pcm, d_mel;
 };
 
@@ -77,6 +84,146 @@ __global__ void pcm16_to_f32_kernel(const int16_t* __restrict__ in, float* __res
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = (float)in[i] * (1.0f / 32768.0f);
+}
+
+// ---- ragged batches, stage by stage: one strip ---------------------------------------------------------------
+// The stand-alone resampler and FIR take equal-length clips.  A ragged batch is laid out as ONE signal instead: clip i
+// starts at mono sample p_off[i], a multiple of the input span of one full round of block matrices (lcm(16, L) outputs
+// = lcm(16, L) M / L input samples), and is followed by zeros that reach over the resampler's window and over K - 1
+// resampled samples.  One launch per stage then computes every clip with exactly the zeros a clip edge has, and -- the
+// tiles of the banded kernels being anchored at the strip's output 0, a multiple of the block round away from the
+// clip's own -- with the bits of a launch on that clip alone.  The resampler's tail past a clip's end (what it makes of
+// the clip's last samples beyond res_len) is zeroed before the FIR reads the strip.  Strips beyond the kernels' 32-bit
+// offsets are cut into groups at clip starts.
+struct ClipRow { int64_t src, len, dst, gap0, gap1; };            // frames, frames, strip sample, resampled gap [gap0, gap1)
+
+template <int CH, bool I16>
+__global__ void strip_gather_kernel(const void* __restrict__ pcm, float* __restrict__ strip, const ClipRow* __restrict__ rows)
+{
+    const ClipRow r = rows[blockIdx.y];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < r.len; j += stride) {
+        const int64_t f = r.src + j;
+        float v;
+        // the arithmetic of the stand-alone stages: x / 32768 (docs/OPS.md "PCM formats"), then (L + R) * 0.5 (capture.rs:30-42)
+        if constexpr (I16) {
+            const int16_t* q = static_cast<const int16_t*>(pcm) + f * CH;
+            const float a = (float)q[0] * (1.0f / 32768.0f);
+            v = CH == 2 ? (a + (float)q[CH - 1] * (1.0f / 32768.0f)) * 0.5f : a;
+        } else {
+            const float* q = static_cast<const float*>(pcm) + f * CH;
+            v = CH == 2 ? (q[0] + q[CH - 1]) * 0.5f : q[0];
+        }
+        strip[r.dst + j] = v;
+    }
+}
+
+__global__ void strip_zero_gaps_kernel(float* __restrict__ res, const ClipRow* __restrict__ rows)
+{
+    const ClipRow r = rows[blockIdx.x];
+    for (int64_t j = r.gap0 + threadIdx.x; j < r.gap1; j += blockDim.x) res[j] = 0.0f;
+}
+
+constexpr int64_t kStripGroupMax = (1ll << 30) - (1ll << 22);     // samples per launch (the banded kernels' 32-bit offsets)
+
+af_status strip_layout(af_chain* c)
+{
+    const size_t n = c->n_clips;
+    const bool resample = c->cfg.input_rate != c->cfg.output_rate;
+    const uint32_t g = std::gcd(c->cfg.input_rate, c->cfg.output_rate);
+    const int64_t L = c->cfg.output_rate / g, M = c->cfg.input_rate / g;
+    const int64_t round_out = std::lcm<int64_t>(16, L);             // outputs of one round of block matrices
+    const int64_t a_in = round_out / L * M;                         // ... and the input samples under them
+    const int64_t K = (int64_t)c->cfg.n_fir_taps;
+    // zeros behind a clip: the resampler's window (T taps each way is more than it reaches) + what K - 1 resampled
+    // samples need + one more resampled sample for out_len's rounding
+    const int64_t gap_in = (resample ? 2 * banded::kResamplerTaps : 0) + ((K > 0 ? K - 1 : 0) + 2) * M / L + M / L + 2;
+    c->p_off.assign(n, 0);
+    c->groups.clear();
+    c->strip_ok = true;
+    std::vector<ClipRow> rows(n);
+    int64_t pos = 0, g0 = 0;
+    for (size_t i = 0; i < n; ++i) {
+        int64_t end = pos + c->len[i] + gap_in;
+        end = (end + a_in - 1) / a_in * a_in;
+        if (end - g0 > kStripGroupMax && pos > g0) {                // close the group in front of this clip
+            c->groups.push_back({g0, pos - g0, g0 / M * L, (pos - g0) / M * L});
+            g0 = pos;
+        }
+        if (end - g0 > kStripGroupMax) c->strip_ok = false;         // (a single clip of hours: the fused launch only)
+        c->p_off[i] = pos;
+        c->z_off[i] = pos / M * L;                                  // (pos is a multiple of a_in = round_out M / L)
+        rows[i] = ClipRow{c->off[i], c->len[i], pos, c->z_off[i] + c->res_len[i], end / M * L};
+        AF_REQUIRE(rows[i].gap1 - rows[i].gap0 >= (K > 0 ? K - 1 : 0), "strip layout: gap of %lld resampled samples behind "
+                   "clip %zu, the FIR needs %lld", (long long)(rows[i].gap1 - rows[i].gap0), i, (long long)(K - 1));
+        pos = end;
+    }
+    if (pos > g0) c->groups.push_back({g0, pos - g0, g0 / M * L, (pos - g0) / M * L});
+    c->total_p = pos;
+    c->total_r = pos / M * L;
+    c->strip_ready = false;
+    if (K) AF_TRY(c->d_fir.reserve((size_t)(c->total_r ? c->total_r : 1) * sizeof(float)));
+    if (n) {
+        AF_TRY(c->d_clips.reserve(n * sizeof(ClipRow)));
+        AF_HIP(hipMemcpy(c->d_clips.p, rows.data(), n * sizeof(ClipRow), hipMemcpyHostToDevice));
+    }
+    return AF_OK;
+}
+
+// the strip itself and the resampled strip: at af_chain_set_batch where the stage-by-stage path is the one that runs,
+// on first use where it is only the fallback of a batch that has the fused launch (its mono strip would double the
+// memory of a batch that never needs it)
+af_status strip_alloc(af_chain* c)
+{
+    if (c->strip_ready) return AF_OK;
+    const bool resample = c->cfg.input_rate != c->cfg.output_rate;
+    const size_t np = (size_t)(c->total_p ? c->total_p : 1);
+    AF_TRY(c->d_strip.reserve(np * sizeof(float)));
+    AF_HIP(hipMemset(c->d_strip.p, 0, np * sizeof(float)));         // the gaps are never written again
+    if (resample) AF_TRY(c->d_res.reserve((size_t)(c->total_r ? c->total_r : 1) * sizeof(float)));
+    c->strip_ready = true;
+    return AF_OK;
+}
+
+// gather -> (resampler, zero its tails) -> FIR over the strip; *out = what the feature kernel reads
+af_status strip_run(af_chain* c, const void* pcm_dev, hipStream_t s, const float** out)
+{
+    const bool resample = c->cfg.input_rate != c->cfg.output_rate;
+    const bool i16 = c->cfg.sample_format == AF_PCM_I16;
+    if (!c->strip_ok)
+        return fail(AF_ERR_UNSUPPORTED, "af_chain: a clip of this ragged batch is beyond the stage-by-stage chain's 32-bit offsets");
+    AF_TRY(strip_alloc(c));
+    const ClipRow* rows = c->d_clips.as<ClipRow>();
+    int64_t longest = 1;
+    for (size_t i = 0; i < c->n_clips; ++i) longest = std::max(longest, c->len[i]);
+    const unsigned gx = (unsigned)std::min<int64_t>((longest + 256 * 8 - 1) / (256 * 8), 4096);
+    for (size_t y0 = 0; y0 < c->n_clips; y0 += 65535) {             // (grid.y is 16 bits)
+        const dim3 grid(gx, (unsigned)std::min<size_t>(65535, c->n_clips - y0));
+        float* strip = c->d_strip.as<float>();
+        if (c->cfg.channels == 2 && i16) hipLaunchKernelGGL((strip_gather_kernel<2, true>), grid, dim3(256), 0, s, pcm_dev, strip, rows + y0);
+        else if (c->cfg.channels == 2) hipLaunchKernelGGL((strip_gather_kernel<2, false>), grid, dim3(256), 0, s, pcm_dev, strip, rows + y0);
+        else if (i16) hipLaunchKernelGGL((strip_gather_kernel<1, true>), grid, dim3(256), 0, s, pcm_dev, strip, rows + y0);
+        else hipLaunchKernelGGL((strip_gather_kernel<1, false>), grid, dim3(256), 0, s, pcm_dev, strip, rows + y0);
+        AF_HIP(hipGetLastError());
+    }
+    const float* cur = c->d_strip.as<float>();
+    if (resample) {
+        for (const auto& gr : c->groups)
+            AF_TRY(af_resample_batch_device(c->cfg.input_rate, c->cfg.output_rate, cur + gr.p0, 1, (size_t)gr.p_len,
+                                            c->d_res.as<float>() + gr.r0, s));
+        if (c->cfg.n_fir_taps && c->n_clips) {
+            hipLaunchKernelGGL(strip_zero_gaps_kernel, dim3((unsigned)c->n_clips), dim3(256), 0, s, c->d_res.as<float>(), rows);
+            AF_HIP(hipGetLastError());
+        }
+        cur = c->d_res.as<float>();
+    }
+    if (c->cfg.n_fir_taps) {
+        for (const auto& gr : c->groups)
+            AF_TRY(af_fir_apply_batch_device(c->fir, cur + gr.r0, 1, (size_t)gr.r_len, c->d_fir.as<float>() + gr.r0, s));
+        cur = c->d_fir.as<float>();
+    }
+    *out = cur;
+    return AF_OK;
 }
 
 bool fused_applies(const af_chain* c)
@@ -201,7 +348,6 @@ af_status af_chain_set_batch(af_chain* c, const int64_t* clip_offsets, size_t n_
     c->len.assign(n_clips, 0);
     c->res_len.assign(n_clips, 0);
     c->z_off.assign(n_clips, 0);
-    int64_t z = 0;
     bool fused_ok = c->fused.ok;
     for (size_t i = 0; i < n_clips; ++i) {
         const int64_t b = clip_offsets[i], e = clip_offsets[i + 1];
@@ -210,19 +356,15 @@ af_status af_chain_set_batch(af_chain* c, const int64_t* clip_offsets, size_t n_
         c->off[i] = b;
         c->len[i] = e - b;
         c->res_len[i] = (int64_t)af_resample_out_len(c->cfg.input_rate, c->cfg.output_rate, (size_t)(e - b));
-        c->z_off[i] = z;
-        z += (c->res_len[i] + 3) / 4 * 4;            // every clip's 16 kHz signal starts on a 16-byte boundary
         // the fused launch: 32-bit offsets inside a clip; mono i16 frames are 2 bytes, its loads are dwords
         if (!banded::fits(c->fused, e - b) || c->res_len[i] >= (1ll << 31)) fused_ok = false;
         if (c->fmt == banded::kFmtMonoI16 && (b & 1)) fused_ok = false;
     }
     c->total_in = n_clips ? clip_offsets[n_clips] : 0;
-    c->total_z = z;
-    const bool resample = c->cfg.input_rate != c->cfg.output_rate;
-    if (c->cfg.sample_format == AF_PCM_I16) AF_TRY(c->d_f32.reserve((size_t)c->total_in * c->cfg.channels * sizeof(float)));
-    if (c->cfg.channels == 2) AF_TRY(c->d_mono.reserve((size_t)c->total_in * sizeof(float)));
-    if (resample) AF_TRY(c->d_res.reserve((size_t)(z ? z : 1) * sizeof(float)));
-    if (c->cfg.n_fir_taps) AF_TRY(c->d_fir.reserve((size_t)(z ? z : 1) * sizeof(float)));
+    // where the clips' 16 kHz signals live: the strip layout (shared by the fused launch and the stage-by-stage path, so
+    // that the feature kernel's spans do not depend on which of them runs)
+    AF_TRY(strip_layout(c));
+    c->total_z = c->total_r;
     // one record per tile of the fused launch
     c->n_tiles = 0;
     if (fused_ok && n_clips) {
@@ -239,8 +381,8 @@ af_status af_chain_set_batch(af_chain* c, const int64_t* clip_offsets, size_t n_
             AF_HIP(hipMemcpy(c->d_tiles.p, tiles.data(), tiles.size() * sizeof(banded::FusedTile), hipMemcpyHostToDevice));
         }
         c->n_tiles = (int64_t)tiles.size();
-        if (tiles.empty()) c->n_tiles = 0;
     }
+    if (!fused_applies(c) && c->strip_ok) AF_TRY(strip_alloc(c));
     size_t total = 0;
     AF_TRY(af_features_set_batch_spans(c->feat, c->z_off.data(), c->res_len.data(), n_clips, &total));
     c->total_frames = total;
@@ -271,6 +413,12 @@ af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, 
         return af_features_run_device(c->feat, c->d_fir.as<float>(), mel_dev, stream);
     }
     // ---- stage by stage ----
+    if (c->ragged) {
+        const float* z = nullptr;
+        AF_TRY(strip_run(c, pcm_dev, as_stream(stream), &z));
+        return af_features_run_device(c->feat, z, mel_dev, stream);
+    }
+    // equal-length clips: every stage is the corresponding batch entry point
     const float* cur = static_cast<const float*>(pcm_dev);
     if (i16) {
         const size_t n = (size_t)c->total_in * c->cfg.channels;
@@ -280,8 +428,7 @@ af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, 
         AF_HIP(hipGetLastError());
         cur = c->d_f32.as<float>();
     }
-    if (!c->ragged && c->cfg.channels == 2 && resample &&
-        af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate) &&
+    if (c->cfg.channels == 2 && resample && af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate) &&
         2 * (int64_t)c->n_in < ((1ll << 30) - (1ll << 20))) {
         // downmix fused into the resampler's loads: the mono signal never reaches HBM
         AF_TRY(af_resample_batch_stereo_device(c->cfg.input_rate, c->cfg.output_rate, cur, c->n_clips,
@@ -294,34 +441,13 @@ af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, 
             cur = c->d_mono.as<float>();
         }
         if (resample) {
-            if (!c->ragged) {
-                AF_TRY(af_resample_batch_device(c->cfg.input_rate, c->cfg.output_rate, cur, c->n_clips, c->n_in,
-                                                c->d_res.as<float>(), stream));
-            } else {
-                for (size_t i = 0; i < c->n_clips; ++i)   // clip by clip: the stand-alone kernels take uniform batches
-                    AF_TRY(af_resample_batch_device(c->cfg.input_rate, c->cfg.output_rate, cur + c->off[i], 1,
-                                                    (size_t)c->len[i], c->d_res.as<float>() + c->z_off[i], stream));
-            }
+            AF_TRY(af_resample_batch_device(c->cfg.input_rate, c->cfg.output_rate, cur, c->n_clips, c->n_in,
+                                            c->d_res.as<float>(), stream));
             cur = c->d_res.as<float>();
         }
     }
     if (c->cfg.n_fir_taps) {
-        if (!c->ragged) {
-            AF_TRY(af_fir_apply_batch_device(c->fir, cur, c->n_clips, c->n_res, c->d_fir.as<float>(), stream));
-        } else {
-            // without a resampler the clips sit at their PCM offsets, with one at their 16 kHz offsets
-            for (size_t i = 0; i < c->n_clips; ++i)
-                AF_TRY(af_fir_apply_batch_device(c->fir, cur + (resample ? c->z_off[i] : c->off[i]), 1,
-                                                 (size_t)c->res_len[i], c->d_fir.as<float>() + c->z_off[i], stream));
-        }
-        cur = c->d_fir.as<float>();
-    } else if (c->ragged && !resample) {
-        // neither resampler nor FIR: the feature spans were laid out at the padded offsets -- copy clip by clip
-        // (rare configuration; the feature handle alone serves it better)
-        AF_TRY(c->d_fir.reserve((size_t)(c->total_z ? c->total_z : 1) * sizeof(float)));
-        for (size_t i = 0; i < c->n_clips; ++i)
-            AF_HIP(hipMemcpyAsync(c->d_fir.as<float>() + c->z_off[i], cur + c->off[i], (size_t)c->len[i] * sizeof(float),
-                                  hipMemcpyDeviceToDevice, as_stream(stream)));
+        AF_TRY(af_fir_apply_batch_device(c->fir, cur, c->n_clips, c->n_res, c->d_fir.as<float>(), stream));
         cur = c->d_fir.as<float>();
     }
     return af_features_run_device(c->feat, cur, mel_dev, stream);
@@ -332,16 +458,22 @@ int af_chain_n_launches(const af_chain* c)
     if (!c) return 0;
     const bool resample = c->cfg.input_rate != c->cfg.output_rate;
     if (fused_applies(c)) return 2;
-    const int per_clip = c->ragged ? (int)c->n_clips : 1;
-    int n = 1;                                                  // the STFT / mel kernel
-    if (c->cfg.sample_format == AF_PCM_I16) n += 1;             // i16 -> f32
+    int fir_parts = 0;
     if (c->cfg.n_fir_taps) {
         const banded::FirParts fp = banded::make_fir_parts((int)c->cfg.n_fir_taps);
-        n += (fp.ok() ? fp.n : 1) * per_clip;
+        fir_parts = fp.ok() ? fp.n : 1;
     }
-    if (resample) n += per_clip;
-    if (c->cfg.channels == 2 &&
-        !(!c->ragged && resample && af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate)))
+    if (c->ragged) {
+        // the strip: gather, then one resampler / FIR launch per group (one group unless the batch is beyond 2^30 samples)
+        const int groups = (int)std::max<size_t>(1, c->groups.size());
+        int n = 1 + 1 + (int)((c->n_clips + 65534) / 65535) - 1;    // features + gather
+        if (resample) n += groups + (c->cfg.n_fir_taps ? 1 : 0);    // + the zeroing of the resampler's tails
+        return n + fir_parts * groups;
+    }
+    int n = 1 + fir_parts;                                      // the STFT / mel kernel, the FIR passes
+    if (c->cfg.sample_format == AF_PCM_I16) n += 1;             // i16 -> f32
+    if (resample) n += 1;
+    if (c->cfg.channels == 2 && !(resample && af_resample_has_stereo_path(c->cfg.input_rate, c->cfg.output_rate)))
         n += 1;                                                 // stand-alone to_mono
     return n;
 }

@@ -396,7 +396,8 @@ af_status af_mel_apply(af_mel* m, const float* power, size_t n_frames, float* me
  * resampled signal before the FIR stays in LDS) and the chain is two launches, for every batch
  * shape and PCM format; the values are those of the separate launches bit for bit when both use
  * the same MFMA step layout (FIRs of 34..65 and 98..129 taps), and within the tolerance of
- * docs/OPS.md otherwise.  Without the fused launch a ragged batch runs resampler and FIR clip by clip. */
+ * docs/OPS.md otherwise.  Without the fused launch a ragged batch runs as ONE zero-separated strip: a gather,
+ * one resampler launch, one FIR launch, the feature kernel -- every clip's rows are those of the clip alone. */
 typedef struct af_chain af_chain;
 typedef struct {
     uint32_t input_rate;     /* Hz of the PCM handed in */

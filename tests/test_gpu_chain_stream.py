@@ -362,20 +362,59 @@ def test_chain_ragged_and_i16_fused_equals_unfused_and_oracle(af, po, ch, fmt):
     assert np.array_equal(uni.run(x4), fused[r0:r0 + nfs[4]])
 
 
-def test_chain_ragged_without_a_fused_plan(af, po):
-    """44.1 -> 16 kHz has no fused launch: a ragged batch runs resampler and FIR clip by clip."""
-    taps = lowpass_taps()
-    lens = [30000, 44100, 5000]
-    clips = [synth_clip(800 + i, n, 2, 44100) for i, n in enumerate(lens)]
-    chain = af.ChainPipeline(input_rate=44100, channels=2, output_rate=16000, fir_taps=taps)
+@pytest.mark.parametrize("fi,fo,ch,fmt,with_fir", [(44100, 16000, 2, 0, True), (44100, 16000, 1, 1, True),
+                                                   (48000, 44100, 2, 1, True), (44100, 16000, 2, 0, False),
+                                                   (16000, 16000, 2, 0, True), (16000, 16000, 1, 0, False),
+                                                   (22050, 16000, 1, 0, True)])
+def test_chain_ragged_without_a_fused_plan(af, po, fi, fo, ch, fmt, with_fir):
+    """Configurations without the fused launch (44.1 k input: ten block matrices; 48 -> 44.1 k: streamed matrices; no
+    resampler; no FIR) on a ragged batch: the clips run as ONE strip with zero gaps -- a gather, one resampler launch,
+    one FIR launch, the feature kernel, whatever the number of clips -- and every clip's rows are the rows of that clip
+    alone through a uniform batch, bit for bit, and the oracle's within tolerance."""
+    taps = lowpass_taps() if with_fir else None
+    lens = [30000, 44100, 5000, 1, 0, 70001, 2047]
+    clips = [synth_clip(800 + i, n, ch, fi) for i, n in enumerate(lens)]
+    if fmt:
+        clips = [_as_i16(x) for x in clips]
+    chain = af.ChainPipeline(input_rate=fi, channels=ch, output_rate=fo, fir_taps=taps, sample_format=fmt)
     chain.set_batch(np.concatenate([[0], np.cumsum(lens)]))
-    mel = chain.run(np.concatenate(clips))
+    resample = fi != fo
+    assert chain.n_launches() == 2 + (2 if resample and with_fir else 1 if resample else 0) + (1 if with_fir else 0)
+    mel = chain.run(np.concatenate([x.reshape(-1) for x in clips]))
+    alone = af.ChainPipeline(input_rate=fi, channels=ch, output_rate=fo, fir_taps=taps, sample_format=fmt)
     row = 0
     for x, n in zip(clips, lens):
         nf = chain.n_frames(n)
-        assert frame_rel_err(mel[row:row + nf], oracle_chain(po, x, 2, 44100, 16000, taps)) < 2e-5
+        if nf:
+            alone.set_batch_uniform(1, n)
+            one = alone.run(x.reshape(-1))
+            assert np.array_equal(mel[row:row + nf], one)
+            xf = x.astype(np.float32) / 32768.0 if fmt else x
+            assert frame_rel_err(mel[row:row + nf], oracle_chain(po, xf, ch, fi, fo, taps)) < 2e-5
         row += nf
     assert row == mel.shape[0]
+
+
+def test_chain_ragged_strip_many_clips(af):
+    """600 ragged clips at 44.1 kHz stereo: still five launches, every clip bit-equal to itself alone."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    lens = [int(v) for v in rng.integers(2000, 90000, 600)]
+    taps = lowpass_taps()
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.rand(sum(lens), 2, generator=gen) * 2 - 1).mul_(0.4).numpy()
+    chain = af.ChainPipeline(input_rate=44100, channels=2, output_rate=16000, fir_taps=taps)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    chain.set_batch(offs)
+    assert chain.n_launches() == 5
+    mel = chain.run(x.reshape(-1))
+    alone = af.ChainPipeline(input_rate=44100, channels=2, output_rate=16000, fir_taps=taps)
+    rows = np.concatenate([[0], np.cumsum([chain.n_frames(n) for n in lens])])
+    for i in (0, 1, 299, 598, 599):
+        alone.set_batch_uniform(1, lens[i])
+        one = alone.run(x[offs[i]:offs[i + 1]].reshape(-1))
+        assert np.array_equal(mel[rows[i]:rows[i + 1]], one)
+    assert rows[-1] == mel.shape[0]
 
 
 # ---- ChainStream (af_chain_stream_*): config 5 on the whole chain ----------------------------------------------
