@@ -18,6 +18,10 @@
 #ifndef AF_BANDED_PAIRS
 #define AF_BANDED_PAIRS 1
 #endif
+// AF_BANDED_BS (0: ablation): the ten-wave shapes store through a range-checked buffer resource
+#ifndef AF_BANDED_BS
+#define AF_BANDED_BS 1
+#endif
 
 namespace af {
 namespace banded {
@@ -41,6 +45,7 @@ struct Geom {
     int lo_off;                      // c - (T - 1): first window sample relative to q(16 b)
     int nb, S, G, wpp, gpw, seg_len, seg_stride;
     int accumulate;                  // 1: y += (a later pass of a long FIR)
+    int buffer_stores;               // the ten-wave shapes: y through a range-checked buffer resource (BS)
 };
 
 __device__ __forceinline__ int w_of(int t, int g4, int nk)
@@ -93,9 +98,15 @@ __device__ __forceinline__ int opaque_zero()
 // ACC = 1: the accumulators start from y (a later pass of a long FIR).  A template parameter on purpose: as a
 // runtime branch its loads made hipcc's wait-count pass put s_waitcnt vmcnt(1) in front of every tile's first
 // MFMA -- a wait for the previous tile's output stores.
-template <int NK, int WPE, int CH, bool ACC = false>
+// BS = true (the ten-wave shapes, where launch() may): y goes out through a buffer resource over the wanted outputs
+// [m0, m0 + n_out) of the clip, one 16-byte store per chain whatever the tile's position -- the range check drops what
+// lies outside, dword by dword.  With predicated stores the number of vector memory operations behind the x requests
+// depends on the path, and the wait in front of the staging (one counter for loads and stores, retired in order) had to
+// be vmcnt(0): every tile began by waiting for the previous tile's last store to be acknowledged.
+template <int NK, int WPE, int CH, bool ACC = false, bool BS = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void banded_kernel(const Geom g)
 {
+    static_assert(!(BS && (ACC || WPE != 5)), "buffer stores: the one-chain-at-a-time shapes, plain passes");
     extern __shared__ __attribute__((aligned(16))) float xs[];
     constexpr int FULL = NK / 16, TAILQ = NK % 16;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -186,6 +197,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         prep_tile(tile, true);
 #pragma unroll
         for (int s2 = 0; s2 < kLoads; ++s2) issue_load(s2);
+        if constexpr (BS) {
+            // one store to nowhere (an offset the range check drops) behind the first tile's x requests: every later
+            // tile's requests are followed by at least one store, and with this one the compiler's count of "operations
+            // younger than the requests" is 1 on every path into the loop instead of 0 -- the staging waits with
+            // vmcnt(1) and leaves the previous tile's last store in flight
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t nowhere = __builtin_amdgcn_make_buffer_rsrc(g.y, 0, 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, nowhere, (int)kOob, 0, 0);
+        }
     }
     for (; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();                                        // readers of the previous tile done
@@ -225,6 +245,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 
         const int64_t mbase = t_abs * out_per_tile - g.m0;      // output index of the tile - m0
         float* yc = g.y + (int64_t)clip * g.y_stride + mbase;
+        // BS: 32 bits of mbase are enough -- the tile grid reaches less than one tile past either end of the wanted outputs
+        // and launch() bounds n_out, so no offset wraps INTO the range the hardware accepts
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+            g.y + (int64_t)clip * g.y_stride, 0, (int)(uint32_t)(g.n_out * 4), 0x00020000);
+        const uint32_t mb32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mbase);
         const bool whole = mbase >= 0 && mbase + out_per_tile <= g.n_out &&
                            ((reinterpret_cast<uintptr_t>(yc) >> 2) & 3) == 0;
         const int lo = mbase >= 0 ? 0 : -mbase > out_per_tile ? out_per_tile : (int)-mbase;
@@ -284,7 +309,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (whole) {
+            if constexpr (BS) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc0), yrs, (int)((mb32 + (uint32_t)o0) * 4u), 0, 0);
+            } else if (whole) {
                 *reinterpret_cast<f32x4*>(yc + o0) = acc0;
                 if (kPair) *reinterpret_cast<f32x4*>(yc + o1) = acc1;
             } else {                                            // clip edges, unaligned streams
@@ -953,7 +981,8 @@ void launch_nk(const Geom& g, bool five, int ch, unsigned grid, unsigned block, 
             return;
         }
         if (five) {
-            hipLaunchKernelGGL((banded_kernel<NK, 5, 1>), dim3(grid), dim3(block), smem, s, g);
+            if (g.buffer_stores) hipLaunchKernelGGL((banded_kernel<NK, 5, 1, false, true>), dim3(grid), dim3(block), smem, s, g);
+            else hipLaunchKernelGGL((banded_kernel<NK, 5, 1>), dim3(grid), dim3(block), smem, s, g);
             return;
         }
     }
@@ -1139,7 +1168,9 @@ af_status launch_stream(const Plan& p, const float* afrag_dev, const float* x_de
     if (g.n_tiles >= (1ll << 31)) return fail(AF_ERR_UNSUPPORTED, "banded::launch: too many tiles");
     // deferred stores address y with 32-bit byte offsets from output m0 of a clip; a tile reaches at most 16 * 16 C * nb
     // outputs past either end of [m0, m0 + n_out), and neither side may wrap into the range the hardware accepts
-    const bool ob = p.ob_stride != 0 && n_out + (int64_t)2 * 256 * p.C * p.nb < (1ll << 29);
+    // (and its 16-byte stores need 16-byte-aligned addresses: y itself, every clip's row and output m0 on that grid)
+    const bool y_aligned = (reinterpret_cast<uintptr_t>(y_dev) & 15) == 0 && (y_stride & 3) == 0 && (m0 & 3) == 0;
+    const bool ob = p.ob_stride != 0 && y_aligned && n_out + (int64_t)2 * 256 * p.C * p.nb < (1ll << 29);
     g.ob_off = ob ? p.ob_off : 0;
     g.ob_stride = ob ? p.ob_stride : 0;
     g.lo_off = p.c - (p.T - 1);
@@ -1200,6 +1231,10 @@ af_status launch(const Plan& p, const float* afrag_dev, const float* x_dev, int6
     g.seg_len = p.seg_len;
     g.seg_stride = p.seg_stride;
     g.accumulate = accumulate ? 1 : 0;
+    // (16-byte stores at 16-byte-aligned addresses only: y itself, every clip's row and output m0 on that grid -- a
+    // stream's chunks start anywhere and keep the predicated stores)
+    const bool y_aligned = (reinterpret_cast<uintptr_t>(y_dev) & 15) == 0 && (y_stride & 3) == 0 && (m0 & 3) == 0;
+    g.buffer_stores = AF_BANDED_BS && !accumulate && y_aligned && n_out + 2 * p.out_per_tile < (1ll << 29) ? 1 : 0;
     const int wg_per_cu = (2 * 64 * p.nwaves <= 2048 && 2 * p.smem <= 150 * 1024 && !(p.ch == 2 && p.nwaves > 8)) ? 2 : 1;
     int64_t grid = g.n_tiles;
     const int64_t n_cus = device_cu_count(current_device());

@@ -95,9 +95,12 @@ def test_resample_reference_surface(af):
     assert af.AudioResampler.create_48k_to_16k().needs_resampling()   # :60-62
 
 
-@pytest.mark.parametrize("fi,fo", [(48000, 16000), (44100, 16000), (16000, 48000), (48000, 44100), (16000, 44100)])
+@pytest.mark.parametrize("fi,fo", [(48000, 16000), (44100, 16000), (16000, 48000), (48000, 44100), (16000, 44100),
+                                   (48000, 22050), (44100, 48000)])
 def test_streaming_equals_one_shot_bit_exact(af, po, fi, fo):
-    x = synth_clip(60, 10007 if fo != 44100 else 100003, 1, fi)
+    # (chunks start at any output index: the kernels' 16-byte store paths -- deferred stores of the streamed kernel,
+    # buffer stores of the ten-wave shapes -- must hand unaligned chunks to the predicated stores)
+    x = synth_clip(60, 10007 if fo not in (44100, 22050) else 100003, 1, fi)
     one = af.resample_batch(x, fi, fo)[0]
     r = af.AudioResampler.new(fi, fo)
     rng = np.random.default_rng(1)
@@ -308,6 +311,29 @@ def test_fir_mfma_boundary(af, po, K):
     f = af.FirFilter.new(taps)
     got = np.concatenate([f.process(x[a:b]) for a, b in [(0, 5000), (5000, 5001), (5001, 20000), (20000, x.size)]])
     assert rel_err(got, ref) < 1e-5 and np.max(np.abs(got - y)) <= 2e-6 * np.max(np.abs(y))
+
+
+@pytest.mark.parametrize("fi,fo,n", [(44100, 16000, 44100 * 3), (44100, 48000, 44100 * 2), (48000, 22050, 96000 * 2),
+                                     (48000, 22050, 96000)])
+def test_resample_aligned_rows_take_the_16_byte_store_paths(af, po, fi, fo, n):
+    """Row pitches that are multiples of four floats: the ten-wave shapes store through the range-checked buffer
+    resource, the streamed kernel with ranges of <= 16 matrices through its LDS image of the tile -- same bits as the
+    predicated stores a stream's unaligned chunks take, partial tiles at the clip ends included."""
+    L, M = po.resample_ratio(fi, fo)
+    assert po.resample_out_len(n, L, M) % 4 == 0
+    clips = np.stack([synth_clip(170 + i, n, 1, fi) for i in range(3)])
+    y = af.resample_batch(clips, fi, fo)
+    rng = np.random.default_rng(4)
+    for i in range(3):
+        r = af.AudioResampler.new(fi, fo)
+        parts, pos = [], 0
+        while pos < n:
+            k = int(rng.integers(1, 9000))
+            parts.append(r.process(clips[i][pos:pos + k]))
+            pos += k
+        parts.append(r.flush())
+        assert np.array_equal(np.concatenate(parts), y[i])
+        assert rel_err(y[i], po.resample(clips[i], fi, fo)) < TOL
 
 
 @pytest.mark.parametrize("fi,fo", [(44100, 16000), (48000, 16000), (44100, 48000), (8000, 16000)])
