@@ -31,6 +31,7 @@
 // attribute SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT to them.  Every guard that bounds a global access stays in.
 //   1 tile reads (stage 1)   2 window rows   4 first twiddle rows   8 T1 stores   16 T1 reads   32 second twiddle rows
 //   64 exchange stores   128 exchange reads   256 power-row stores   512 mel operand reads   1024 tile update
+//   2048 (not LDS) mel stores go to the wrong place inside the unit's 5 KB, 1 KB contiguous per instruction
 #ifndef AF_ABL
 #define AF_ABL 0
 #endif
@@ -678,6 +679,8 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                         acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
                         const int mm = e & 255, cnt = (e >> 8) & 31;
                         float* o = obase + mm + row_off;            // uniform base + 32-bit lane offset
+                        if constexpr (AF_ABL & 2048)                // (diagnostic: wrong place, 1 KB contiguous per instruction)
+                            o = obase + (mm >> 4) * 256 + 4 * lane;
                         if (vec_ok && ((cnt | mm) & 3) == 0) {      // wave-uniform choice
                             if (fvalid && i0 < cnt) *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
                         } else if (fvalid) {
