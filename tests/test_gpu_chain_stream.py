@@ -417,6 +417,55 @@ def test_chain_ragged_strip_many_clips(af):
     assert rows[-1] == mel.shape[0]
 
 
+def test_chain_ragged_strip_more_clips_than_a_grid_dimension(af):
+    """66 000 short clips (the gather's grid.y is 16 bits: two launches of it), most of them too short for a row."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(5)
+    lens = rng.integers(50, 400, 66000)
+    lens[[7, 40000, 65999]] = [9000, 12000, 7000]                     # three clips long enough for rows
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    gen = torch.Generator().manual_seed(10)
+    x = (torch.rand(int(offs[-1]), 2, generator=gen) * 2 - 1).mul_(0.4).numpy()
+    taps = lowpass_taps()
+    chain = af.ChainPipeline(input_rate=44100, channels=2, output_rate=16000, fir_taps=taps)
+    total = chain.set_batch(offs)
+    assert chain.n_launches() == 6 and total == sum(chain.n_frames(int(n)) for n in lens[[7, 40000, 65999]])
+    mel = chain.run(x.reshape(-1))
+    alone = af.ChainPipeline(input_rate=44100, channels=2, output_rate=16000, fir_taps=taps)
+    row = 0
+    for i in (7, 40000, 65999):
+        alone.set_batch_uniform(1, int(lens[i]))
+        one = alone.run(x[offs[i]:offs[i + 1]].reshape(-1))
+        assert np.array_equal(mel[row:row + one.shape[0]], one)
+        row += one.shape[0]
+    assert row == mel.shape[0]
+
+
+def test_chain_ragged_strip_in_groups_beyond_2_30_samples(af):
+    """1.2e9 mono frames in 240 clips: the strip is cut into two groups at a clip start (the banded kernels address a
+    launch with 32-bit offsets); clips on both sides of the cut equal themselves alone."""
+    torch = pytest.importorskip("torch")
+    lens = np.full(240, 5_000_000, dtype=np.int64)
+    lens[::7] += 12345
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(11)
+    pcm = (torch.rand(int(offs[-1]), device=dev, generator=gen) * 2 - 1) * 0.4
+    taps = lowpass_taps()
+    chain = af.ChainPipeline(input_rate=44100, channels=1, output_rate=16000, fir_taps=taps)
+    total = chain.set_batch(offs)
+    assert chain.n_launches() == 1 + 1 + 2 + 1 + 2                    # features, gather, 2 x resampler, gap zeroing, 2 x FIR
+    mel = torch.empty(total, 80, device=dev)
+    chain.run_device(pcm.data_ptr(), mel.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    alone = af.ChainPipeline(input_rate=44100, channels=1, output_rate=16000, fir_taps=taps)
+    rows = np.concatenate([[0], np.cumsum([chain.n_frames(int(n)) for n in lens])])
+    for i in (0, 213, 214, 215, 239):                                 # (the cut falls behind clip 213 or 214)
+        alone.set_batch_uniform(1, int(lens[i]))
+        one = alone.run(pcm[offs[i]:offs[i + 1]].cpu().numpy())
+        assert np.array_equal(mel[rows[i]:rows[i + 1]].cpu().numpy(), one)
+
+
 # ---- ChainStream (af_chain_stream_*): config 5 on the whole chain ----------------------------------------------
 @pytest.mark.parametrize("ch,fmt,n", [(2, 0, 184320 * 3 + 50001), (1, 1, 184320 * 2 + 7), (2, 0, 190000),
                                       (2, 1, 184320 + 2200), (1, 0, 2000), (2, 0, 0)])
