@@ -18,6 +18,11 @@
 #ifndef AF_BANDED_PAIRS
 #define AF_BANDED_PAIRS 1
 #endif
+// AF_BANDED_ABL (diagnostic builds only, scripts/ablate/): parts of banded_kernel compiled OUT: 1 x requests, 2 stores,
+// 64 the chains' arithmetic (LDS reads + MFMA).  Results are garbage; bounds stay checked.
+#ifndef AF_BANDED_ABL
+#define AF_BANDED_ABL 0
+#endif
 // AF_BANDED_BS (0: ablation): the ten-wave shapes store through a range-checked buffer resource
 #ifndef AF_BANDED_BS
 #define AF_BANDED_BS 1
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         }
     };
     auto issue_load = [&](int s) {                              // s = h * 16 + cc  (PAIR: s = cc)
+        if constexpr (AF_BANDED_ABL & 1) return;
         const int cc = s % kCols, h = s / kCols;
         if constexpr (PAIR) {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -290,11 +296,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 w0[t % (kAhead + 1)] = t < 16 * FULL ? b0p[64 * (t / 16) + (t % 16)] : t0p[t - 16 * FULL];
                 if (kPair) w1[t % (kAhead + 1)] = t < 16 * FULL ? b1p[64 * (t / 16) + (t % 16)] : t1p[t - 16 * FULL];
             };
+            if constexpr (AF_BANDED_ABL & 64) {                  // memory side only
+                acc0[0] = a[0] + a[NK - 1];
+                if (LOADS) {
 #pragma unroll
-            for (int t = 0; t < kAhead && t < NK; ++t) read_b(t);
+                    for (int s2 = 0; s2 < kLoads; ++s2) issue_load(s2);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kAhead && t < NK && !(AF_BANDED_ABL & 64); ++t) read_b(t);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < NK; ++t) {
+            for (int t = 0; t < ((AF_BANDED_ABL & 64) ? 0 : NK); ++t) {
                 if (t + kAhead < NK) read_b(t + kAhead);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w0[t % (kAhead + 1)], acc0, 0, 0, 0);
                 if (kPair) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w1[t % (kAhead + 1)], acc1, 0, 0, 0);
@@ -309,7 +322,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (BS) {
+            if constexpr (AF_BANDED_ABL & 2) {
+                if (acc0[0] == 1.2345e-30f) yc[o0] = acc0[1];        // keeps the arithmetic alive, never taken in practice
+            } else if constexpr (BS) {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc0), yrs, (int)((mb32 + (uint32_t)o0) * 4u), 0, 0);
             } else if (whole) {
