@@ -18,6 +18,13 @@
 #ifndef AF_BANDED_PAIRS
 #define AF_BANDED_PAIRS 1
 #endif
+// cache policy bits of the x requests / the 16-byte y stores (experiment: 2 = nt, once-touched data)
+#ifndef AF_X_AUX
+#define AF_X_AUX 0
+#endif
+#ifndef AF_Y_AUX
+#define AF_Y_AUX 0
+#endif
 // AF_BANDED_ABL (diagnostic builds only, scripts/ablate/): parts of banded_kernel compiled OUT: 1 x requests, 2 stores,
 // 64 the chains' arithmetic (LDS reads + MFMA).  Results are garbage; bounds stay checked.
 #ifndef AF_BANDED_ABL
@@ -180,18 +187,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             // (everything in the VECTOR offset: the scalar offset operand is added behind the range check)
             const f32x2 v = __builtin_bit_cast(
-                f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 4u), 0, 0));
+                f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 4u), 0, AF_X_AUX));
             pf[s * kPfSlots] = v[0];
             pf[s * kPfSlots + 1] = v[1];
         } else if constexpr (CH == 1) {
             pf[cc * kPfSlots + h] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, AF_X_AUX));
         } else {
             // one 8-byte load per frame (cast the whole vector: hipcc 7.2 reads element 0 for
             // __builtin_bit_cast(float, v[i]))
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const int off = (int)(voff[h] + (uint32_t)(cc * col_span) * 8u);
-            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, AF_X_AUX));
             pf[(cc * kPfSlots + h) * 2] = v[0];
             pf[(cc * kPfSlots + h) * 2 + 1] = v[1];
         }
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 if (acc0[0] == 1.2345e-30f) yc[o0] = acc0[1];        // keeps the arithmetic alive, never taken in practice
             } else if constexpr (BS) {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc0), yrs, (int)((mb32 + (uint32_t)o0) * 4u), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc0), yrs, (int)((mb32 + (uint32_t)o0) * 4u), 0, AF_Y_AUX);
             } else if (whole) {
                 *reinterpret_cast<f32x4*>(yc + o0) = acc0;
                 if (kPair) *reinterpret_cast<f32x4*>(yc + o1) = acc1;
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if constexpr (AF_STREAM_ABL & 1) return;
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 v = __builtin_bit_cast(
-            f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff + (uint32_t)(2 * i * g.S) * 4u), 0, 0));
+            f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff + (uint32_t)(2 * i * g.S) * 4u), 0, AF_X_AUX));
         // (everything in the VECTOR offset: the scalar offset operand is added behind the hardware's range check)
         pf[2 * i] = v[0];
         pf[2 * i + 1] = v[1];
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // 32 bits are enough: the tile grid reaches less than one tile past either end of the wanted outputs and
             // launch_stream bounds n_out, so nothing wraps INTO the range the hardware accepts
             const uint32_t off = (m_lo + row * (uint32_t)(16 * g.nb) + 4u * c4) * 4u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, (int)(valid ? off : kOob), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, (int)(valid ? off : kOob), 0, AF_Y_AUX);
         }
     };
 
@@ -833,22 +840,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if constexpr (FMT == 0) {                                   // s = h * 16 + cc
             const int cc = s % kCols, h = s / kCols;
             pf[cc * kPfSlots + h] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, 0));
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, AF_X_AUX));
         } else if constexpr (FMT == 1) {                            // s = cc
             // (cast the whole vector: hipcc 7.2 reads element 0 for __builtin_bit_cast(float, v[i]))
             const f32x4 v = __builtin_bit_cast(
-                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 8u), 0, 0));
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 8u), 0, AF_X_AUX));
 #pragma unroll
             for (int i = 0; i < 4; ++i) pf[s * 4 + i] = v[i];
         } else if constexpr (FMT == 2) {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const f32x2 v = __builtin_bit_cast(
-                f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 4u), 0, 0));
+                f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 4u), 0, AF_X_AUX));
             pf[s * 2] = v[0];
             pf[s * 2 + 1] = v[1];
         } else {
             pf[s] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 2u), 0, 0));
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 2u), 0, AF_X_AUX));
         }
     };
     // the frame pair of column cc as two mono samples
