@@ -31,6 +31,10 @@ struct af_features {
     DevBuf d_mono;                   // channels > 2: the downmixed batch the fused kernel reads
     DevBuf d_units;                  // v2::UnitDesc per 16-frame unit (hop 256 only)
     bool units_ok = false;
+    // filterbanks the banded MFMA plan does not cover (few, wide filters: 20 mels at 48 kHz ...): the kernels write
+    // |X|^2 rows into d_power and dense_mel_kernel contracts them with W (two launches instead of one)
+    bool dense_mel = false;
+    DevBuf d_W, d_band, d_power;     // W [n_mels][513]; first / last + 1 non-zero bin per filter; [total_frames][513]
     // the batch tables are rewritten by set_batch*: the last launch that reads them must be done first
     hipEvent_t last_run = nullptr;
     bool run_pending = false;
@@ -318,7 +322,11 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     AF_HIP(hipMemcpy(p->d_tables.p, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     // hop-256 kernel: one 32-byte record per 16-frame unit
     p->units_ok = false;
-    if (p->plan8.n_waves == v2::kW && aligned4 && p->total_units > 0 && p->total_units < (1ll << 26)) {
+    if (p->dense_mel && p->cfg.output != AF_OUT_POWER)
+        AF_TRY(p->d_power.reserve(((size_t)p->total_frames * kBins + 16) * sizeof(float)));
+    // (dense_mel: the hop-256 kernel only writes power rows, which needs no filterbank plan)
+    const bool v2_ok = p->plan8.n_waves == v2::kW || (p->dense_mel && p->cfg.hop == (uint32_t)v2::kHop);
+    if (v2_ok && aligned4 && p->total_units > 0 && p->total_units < (1ll << 26)) {
         std::vector<v2::UnitDesc> units((size_t)p->total_units + 1);   // + one zero record: the kernel reads a unit ahead
         const bool sep = p->cfg.channel_mode == AF_CH_SEPARATE;
         size_t k = 0;
@@ -401,12 +409,22 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     std::vector<float> wfrag;
     std::vector<int> meta;
     af_status st = build_plan(p->W, (int)cfg->n_mels, kWaves, kMaxSlotsW, 4, p->plan, wfrag, meta);
+    if (st == AF_ERR_UNSUPPORTED) {
+        // a group of filters must fit the K-steps of ONE wave; few wide filters do not (20 mels over 0 .. 24 kHz):
+        // power rows + the dense contraction instead
+        p->dense_mel = true;
+        std::memset(&p->plan, 0, sizeof(p->plan));
+        wfrag.assign(4, 0.0f);
+        meta.assign(4, 0);
+        last_error_slot().clear();
+        st = AF_OK;
+    }
     if (st != AF_OK) { delete p; return st; }
     // hop-256 kernel: the same groups dealt to 8 waves, at most 8 slots each; a filterbank that
     // does not fit leaves plan8.n_waves == 0 and the general kernel serves hop 256 as well
     std::vector<float> wfrag8;
     std::vector<int> meta8;
-    if (cfg->hop == (uint32_t)v2::kHop) {
+    if (cfg->hop == (uint32_t)v2::kHop && !p->dense_mel) {
         // 6 slots per wave where the filterbank allows it (the instance with the smaller register budget)
         if (build_plan(p->W, (int)cfg->n_mels, v2::kW, 6, 2, p->plan8, wfrag8, meta8, v2::kBinMajor) != AF_OK &&
             build_plan(p->W, (int)cfg->n_mels, v2::kW, 8, 2, p->plan8, wfrag8, meta8, v2::kBinMajor) != AF_OK) {
@@ -496,6 +514,22 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     p->d_tabs2 = reinterpret_cast<const float*>(base + off_tabs2);
     p->d_wfrag8 = reinterpret_cast<const float*>(base + off_wf8);
     p->d_meta8 = reinterpret_cast<const int*>(base + off_meta8);
+    if (p->dense_mel) {
+        std::vector<int> band(2 * cfg->n_mels, 0);
+        for (uint32_t m = 0; m < cfg->n_mels; ++m) {
+            int lo = kBins, hi = 0;
+            for (int k = 0; k < kBins; ++k)
+                if (p->W[(size_t)m * kBins + k] != 0.0f) { lo = std::min(lo, k); hi = k + 1; }
+            band[2 * m] = lo < hi ? lo : 0;
+            band[2 * m + 1] = lo < hi ? hi : 0;
+        }
+        st = p->d_W.reserve(p->W.size() * sizeof(float));
+        if (st == AF_OK) st = p->d_band.reserve(band.size() * sizeof(int));
+        if (st == AF_OK && (hipMemcpy(p->d_W.p, p->W.data(), p->W.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemcpy(p->d_band.p, band.data(), band.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
+            st = fail(AF_ERR_HIP, "uploading the filterbank failed");
+        if (st != AF_OK) { delete p; return st; }
+    }
     *out = p;
     return AF_OK;
 }
@@ -575,6 +609,33 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
     return AF_OK;
 }
 
+// mel[f][m] = sum_k W[m][k] P[f][k] over the filter's own bins, 8 power rows per workgroup through LDS: the contraction
+// for filterbanks the banded MFMA plan does not cover (dense_mel); f32 FMA chain in bin order
+__global__ __launch_bounds__(256) void dense_mel_kernel(const float* __restrict__ power, float* __restrict__ mel,
+                                                        const float* __restrict__ W, const int* __restrict__ band,
+                                                        int n_mels, int64_t n_frames, int log_mel)
+{
+    constexpr int F = 8;
+    __shared__ float rows[F][kBins + 3];
+    for (int64_t f0 = (int64_t)blockIdx.x * F; f0 < n_frames; f0 += (int64_t)gridDim.x * F) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < F * kBins; i += blockDim.x) {
+            const int f = i / kBins, k = i - f * kBins;
+            rows[f][k] = f0 + f < n_frames ? power[(f0 + f) * kBins + k] : 0.0f;
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < F * n_mels; o += blockDim.x) {
+            const int f = o / n_mels, m = o - f * n_mels;
+            if (f0 + f >= n_frames) continue;
+            const float* w = W + (size_t)m * kBins;
+            float acc = 0.0f;
+            for (int k = band[2 * m]; k < band[2 * m + 1]; ++k) acc = __builtin_fmaf(w[k], rows[f][k], acc);
+            if (log_mel) acc = __log10f(fmaxf(acc, 1e-10f));
+            mel[(f0 + f) * n_mels + m] = acc;
+        }
+    }
+}
+
 // units [u_begin, u_begin + u_count) of the batch (u_count < 0: all of it), which read PCM frames
 // [f_begin, f_end) (f_end < 0: the whole batch)
 static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel_dev, void* stream,
@@ -590,6 +651,20 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
                                  (uint16_t)ch, p->d_mono.as<float>() + f_begin, stream));
         pcm_dev = p->d_mono.p;
     }
+    // dense_mel: the kernels write power rows, the contraction with W follows as its own launch
+    const bool dense = p->dense_mel && p->cfg.output != AF_OUT_POWER;
+    if (dense) AF_REQUIRE(u_begin == 0 && u_count == p->total_units, "dense filterbank path: whole batches only");
+    float* const mel_out = mel_dev;
+    if (dense) mel_dev = p->d_power.as<float>();
+    const auto finish = [&]() -> af_status {
+        if (!dense || p->total_frames == 0) return AF_OK;
+        const int64_t blocks = (p->total_frames + 7) / 8;
+        const unsigned grid = (unsigned)std::min<int64_t>(blocks, (int64_t)p->n_cus * 16);
+        hipLaunchKernelGGL(dense_mel_kernel, dim3(grid), dim3(256), 0, as_stream(stream), p->d_power.as<float>(), mel_out,
+                           p->d_W.as<float>(), p->d_band.as<int>(), (int)p->cfg.n_mels, p->total_frames, (int)p->cfg.log_mel);
+        AF_HIP(hipGetLastError());
+        return AF_OK;
+    };
     Params prm{};
     prm.pcm = pcm_dev;
     prm.mel = mel_dev;
@@ -608,7 +683,7 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     prm.n_clips = (int)p->n_clips;
     prm.hop = (int)p->cfg.hop;
     prm.stamps = p->d_stamps.as<unsigned long long>();
-    prm.out_power = p->cfg.output == AF_OUT_POWER;
+    prm.out_power = p->cfg.output == AF_OUT_POWER || dense;
     prm.log_mel = (int)p->cfg.log_mel;
     prm.separate = p->cfg.channel_mode == AF_CH_SEPARATE;
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
@@ -631,8 +706,9 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         int64_t grid2 = (int64_t)p->n_cus * 2;
         if (wg_knob == 1) grid2 = (int64_t)p->n_cus;
         if (grid2 > u_count) grid2 = u_count;
-        return v2::launch(q, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
-                          (int)grid2, as_stream(stream));
+        AF_TRY(v2::launch(q, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
+                          (int)grid2, as_stream(stream)));
+        return finish();
     }
     const size_t smem = features_smem_bytes(prm.hop);
     AF_REQUIRE(smem <= 160 * 1024, "hop %d needs %zu bytes of LDS", prm.hop, smem);
@@ -643,8 +719,9 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     if (wg_knob >= 1 && wg_knob <= 8) per_cu = wg_knob;
     int64_t grid = (int64_t)p->n_cus * per_cu;
     if (grid > u_count) grid = u_count;
-    return launch_features(prm, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16,
-                           (int)grid, smem, as_stream(stream));
+    AF_TRY(launch_features(prm, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16,
+                           (int)grid, smem, as_stream(stream)));
+    return finish();
 }
 
 af_status af_features_run(af_features* p, const void* pcm, size_t pcm_len, float* mel, size_t mel_cap)
@@ -673,7 +750,7 @@ af_status af_features_run(af_features* p, const void* pcm, size_t pcm_len, float
     hipPointerAttribute_t pa;
     const bool pinned = hipPointerGetAttributes(&pa, pcm) == hipSuccess && pa.type == hipMemoryTypeHost;
     if (!pinned) (void)hipGetLastError();
-    if (pinned && p->contiguous && n >= 2 && in_bytes >= ((size_t)64 << 20)) {
+    if (pinned && p->contiguous && n >= 2 && in_bytes >= ((size_t)64 << 20) && !p->dense_mel) {
         const int64_t target = (int64_t)(((size_t)32 << 20) / bpf);
         size_t c0 = 0;
         while (c0 < n) {
@@ -947,6 +1024,15 @@ af_status af_mel_apply_device(af_mel* m, const float* power_dev, size_t n_frames
     AF_REQUIRE(m, "af_mel_apply_device: null handle");
     if (n_frames == 0) return AF_OK;
     AF_REQUIRE(power_dev && mel_dev, "af_mel_apply_device: null buffer");
+    if (m->f->dense_mel) {                      // a filterbank the banded plan does not cover: the dense contraction
+        const int64_t blocks = ((int64_t)n_frames + 7) / 8;
+        const unsigned grid = (unsigned)std::min<int64_t>(blocks, (int64_t)m->f->n_cus * 16);
+        hipLaunchKernelGGL(dense_mel_kernel, dim3(grid), dim3(256), 0, as_stream(stream), power_dev, mel_dev,
+                           m->f->d_W.as<float>(), m->f->d_band.as<int>(), (int)m->f->cfg.n_mels, (int64_t)n_frames,
+                           (int)m->f->cfg.log_mel);
+        AF_HIP(hipGetLastError());
+        return AF_OK;
+    }
     MelApplyParams prm{};
     prm.power = power_dev;
     prm.mel = mel_dev;

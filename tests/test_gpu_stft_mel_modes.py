@@ -134,3 +134,33 @@ def test_stft_then_mel_equals_fused(af):
     pipe = af.FeaturePipeline(sample_rate=16000, channels=1)
     pipe.set_batch_uniform(1, 48000)
     assert frame_rel_err(mel2, pipe.run(x).astype(np.float64)) < 1e-6
+
+
+@pytest.mark.parametrize("sr,ch,n_mels,hop,log", [(48000, 2, 20, 256, False), (48000, 1, 8, 160, False), (96000, 1, 13, 256, True),
+                                                  (48000, 2, 2, 256, False), (44100, 2, 16, 256, False), (48000, 1, 1, 512, False)])
+def test_wide_filterbanks_take_the_dense_contraction(af, po, sr, ch, n_mels, hop, log):
+    """Few, wide filters (20 mels over 0 .. 24 kHz ...) do not fit the banded MFMA plan -- a group of filters must fit the
+    K-steps of one wave --: the handle then runs the power kernel and a dense contraction with W instead of failing
+    (round 2's AF_ERR_UNSUPPORTED).  Ragged batch, both kernels (hop 256 / general), log-mel, the stand-alone filterbank."""
+    lens = [30000, 1024, 1023, 17000]
+    clips = [synth_clip(40 + i, n, ch, sr) for i, n in enumerate(lens)]
+    pipe = af.FeaturePipeline(sample_rate=sr, channels=ch, hop=hop, n_mels=n_mels, log_mel=log)
+    total = pipe.set_batch(np.concatenate([[0], np.cumsum(lens)]))
+    got = pipe.run(np.concatenate([x.reshape(-1) for x in clips]))
+    assert got.shape == (total, n_mels)
+    W = po.mel_weights(float(sr), n_mels=n_mels)
+    assert np.array_equal(pipe.mel_weights(), W.astype(np.float32))
+    row = 0
+    for x, n in zip(clips, lens):
+        nf = pipe.n_frames(n)
+        if nf:
+            ref = po.features(x, ch, float(sr), hop=hop, n_mels=n_mels)
+            g = got[row:row + nf].astype(np.float64)
+            assert frame_rel_err(10.0 ** g if log else g, np.maximum(ref, 1e-10) if log else ref) < TOL
+        row += nf
+    assert row == total
+    # the stand-alone filterbank on given power rows
+    rng = np.random.default_rng(n_mels)
+    P = (rng.random((37, 513)) ** 4).astype(np.float32) * 10.0
+    fb = af.MelFilterbank(sample_rate=sr, n_mels=n_mels)
+    assert frame_rel_err(fb.apply(P), po.mel_apply(P, W)) < TOL
