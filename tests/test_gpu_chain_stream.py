@@ -417,6 +417,43 @@ def test_chain_ragged_strip_many_clips(af):
     assert rows[-1] == mel.shape[0]
 
 
+def test_chain_ragged_random_configurations(af, po):
+    """Seeded sweep over rate pairs (fused, ten-wave, streamed, VALU-fallback ratios, no resampler), FIR lengths up to
+    several banded passes, formats and clip lengths: every clip of the ragged batch equals itself alone, bit for bit, and
+    the first one the oracle within tolerance."""
+    rng = np.random.default_rng(2024)
+    rates = [(48000, 16000), (44100, 16000), (32000, 16000), (48000, 44100), (22050, 16000), (11025, 16000), (8000, 16000),
+             (16000, 16000), (44100, 48000), (96000, 16000), (44100, 8000)]
+    for case in range(22):
+        fi, fo = rates[int(rng.integers(len(rates)))]
+        ch, fmt = int(rng.integers(1, 3)), int(rng.integers(0, 2))
+        K = int(rng.choice([0, 1, 17, 64, 129, 130, 177, 178, 400, 1000]))
+        taps = lowpass_taps(K, fc=0.4 * min(fo, fi), sr=float(fo)) if K else None
+        n_clips = int(rng.integers(1, 7))
+        lens = [int(v) for v in rng.integers(0, 60000, n_clips)]
+        clips = [synth_clip(1000 + 10 * case + i, n, ch, fi) for i, n in enumerate(lens)]
+        if fmt:
+            clips = [_as_i16(x) for x in clips]
+        chain = af.ChainPipeline(input_rate=fi, channels=ch, output_rate=fo, fir_taps=taps, sample_format=fmt)
+        total = chain.set_batch(np.concatenate([[0], np.cumsum(lens)]))
+        mel = chain.run(np.concatenate([x.reshape(-1) for x in clips]) if sum(lens) else np.zeros(0, clips[0].dtype))
+        assert mel.shape == (total, 80), (case, fi, fo, ch, fmt, K, lens)
+        alone = af.ChainPipeline(input_rate=fi, channels=ch, output_rate=fo, fir_taps=taps, sample_format=fmt)
+        row, checked = 0, False
+        for x, n in zip(clips, lens):
+            nf = chain.n_frames(n)
+            if nf:
+                alone.set_batch_uniform(1, n)
+                one = alone.run(x.reshape(-1))
+                assert np.array_equal(mel[row:row + nf], one), (case, fi, fo, ch, fmt, K, lens)
+                if not checked:
+                    xf = x.astype(np.float32) / 32768.0 if fmt else x
+                    assert frame_rel_err(one, oracle_chain(po, xf, ch, fi, fo, taps)) < 3e-5, (case, fi, fo, ch, fmt, K)
+                    checked = True
+            row += nf
+        assert row == total
+
+
 def test_chain_ragged_strip_more_clips_than_a_grid_dimension(af):
     """66 000 short clips (the gather's grid.y is 16 bits: two launches of it), most of them too short for a row."""
     torch = pytest.importorskip("torch")
