@@ -17,7 +17,8 @@ struct af_features {
     af_features_config cfg{};
     int device = 0;
     int n_cus = 256;
-    std::vector<float> W;            // [n_mels][513] f32, as used on the device
+    std::vector<float> W;            // [n_mels][513] f32, as used on the device (n_fft < 1024: on every (1024 / n_fft)-th bin)
+    std::vector<float> Wn;           // [n_mels][n_fft / 2 + 1]: the filterbank as the API reports it
     Plan plan{};                     // groups dealt to the 4 waves of the general kernel
     Plan plan8{};                    // ... and to the 8 waves of the hop-256 kernel (n_waves == 0: not usable)
     DevBuf d_const;                  // wintab | twtab | wfrag | meta | v2 tables | wfrag8 | meta8
@@ -35,6 +36,7 @@ struct af_features {
     // |X|^2 rows into d_power and dense_mel_kernel contracts them with W (two launches instead of one)
     bool dense_mel = false;
     DevBuf d_W, d_band, d_power;     // W [n_mels][513]; first / last + 1 non-zero bin per filter; [total_frames][513]
+    DevBuf d_Wn, d_bandn;            // n_fft < 1024: the filterbank on its own grid (af_mel_apply on n_fft / 2 + 1 wide rows)
     // the batch tables are rewritten by set_batch*: the last launch that reads them must be done first
     hipEvent_t last_run = nullptr;
     bool run_pending = false;
@@ -88,7 +90,7 @@ double mel_to_hz(double m, bool slaney)
 }
 
 // docs/OPS.md "Mel filterbank": triangular; optional Slaney area normalisation 2/(e[m+2]-e[m])
-void build_mel(const af_features_config& c, double f_max, std::vector<float>& W)
+void build_mel(const af_features_config& c, double f_max, std::vector<float>& W, std::vector<float>& Wn)
 {
     const int nm = (int)c.n_mels;
     const bool sl = c.mel_scale == AF_MEL_SLANEY;
@@ -96,15 +98,20 @@ void build_mel(const af_features_config& c, double f_max, std::vector<float>& W)
     const double m_lo = hz_to_mel(c.f_min, sl), m_hi = hz_to_mel(f_max, sl);
     for (int i = 0; i < nm + 2; ++i)
         edges[i] = mel_to_hz(m_lo + (m_hi - m_lo) * (double)i / (double)(nm + 1), sl);
+    // n_fft < 1024 (512, 256): the kernels transform the n_fft-sample frame zero-padded to 1024 points, whose bins
+    // 0, s, 2 s, ... (s = 1024 / n_fft) ARE the n_fft-point DFT; the filterbank lives on those bins, zero elsewhere
+    const int n_fft = (int)c.n_fft, bins_n = n_fft / 2 + 1, stride = kNfft / n_fft;
+    Wn.assign((size_t)nm * bins_n, 0.0f);
     W.assign((size_t)nm * kBins, 0.0f);
     for (int m = 0; m < nm; ++m) {
         const double lo = edges[m], ce = edges[m + 1], hi = edges[m + 2];
-        for (int k = 0; k < kBins; ++k) {
-            const double f = (double)k * (double)c.sample_rate / (double)kNfft;
+        for (int k = 0; k < bins_n; ++k) {
+            const double f = (double)k * (double)c.sample_rate / (double)n_fft;
             const double up = (f - lo) / (ce - lo), dn = (hi - f) / (hi - ce);
             double v = up < dn ? up : dn;
             if (c.mel_norm == AF_MEL_NORM_SLANEY) v *= 2.0 / (hi - lo);
-            W[(size_t)m * kBins + k] = v > 0.0 ? (float)v : 0.0f;
+            Wn[(size_t)m * bins_n + k] = v > 0.0 ? (float)v : 0.0f;
+            W[(size_t)m * kBins + (size_t)k * stride] = Wn[(size_t)m * bins_n + k];
         }
     }
 }
@@ -322,7 +329,7 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     AF_HIP(hipMemcpy(p->d_tables.p, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     // hop-256 kernel: one 32-byte record per 16-frame unit
     p->units_ok = false;
-    if (p->dense_mel && p->cfg.output != AF_OUT_POWER)
+    if ((p->dense_mel && p->cfg.output != AF_OUT_POWER) || (p->cfg.output == AF_OUT_POWER && p->cfg.n_fft != (uint32_t)kNfft))
         AF_TRY(p->d_power.reserve(((size_t)p->total_frames * kBins + 16) * sizeof(float)));
     // (dense_mel: the hop-256 kernel only writes power rows, which needs no filterbank plan)
     const bool v2_ok = p->plan8.n_waves == v2::kW || (p->dense_mel && p->cfg.hop == (uint32_t)v2::kHop);
@@ -379,7 +386,8 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
 {
     AF_REQUIRE(cfg && out, "af_features_create: null argument");
     *out = nullptr;
-    AF_REQUIRE(cfg->n_fft == (uint32_t)kNfft, "n_fft must be %d (got %u)", kNfft, cfg->n_fft);
+    AF_REQUIRE(cfg->n_fft == 1024u || cfg->n_fft == 512u || cfg->n_fft == 256u, "n_fft must be 1024, 512 or 256 (got %u)",
+               cfg->n_fft);
     AF_REQUIRE(cfg->channels >= 1 && cfg->channels <= 16, "channels must be in [1, 16] (got %u)", cfg->channels);
     if (cfg->channels > 2 && cfg->sample_format != AF_PCM_F32)
         return fail(AF_ERR_UNSUPPORTED, "more than two channels are supported for f32 PCM only");
@@ -405,7 +413,7 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     if (hipGetDevice(&p->device) != hipSuccess) p->device = 0;
     p->n_cus = device_cu_count(p->device);
 
-    build_mel(*cfg, f_max, p->W);
+    build_mel(*cfg, f_max, p->W, p->Wn);
     std::vector<float> wfrag;
     std::vector<int> meta;
     af_status st = build_plan(p->W, (int)cfg->n_mels, kWaves, kMaxSlotsW, 4, p->plan, wfrag, meta);
@@ -435,6 +443,11 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
         }
     }
 
+    // periodic Hann over the frame's n_fft samples; the rest of the 1024-point transform is zero padding
+    const int frame_len = (int)cfg->n_fft;
+    const auto hann = [frame_len](int i) {
+        return i < frame_len ? 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)frame_len) : 0.0;
+    };
     // constant block: wintab [32][kWinRow] | twtab [32][kTwRow] | wfrag | meta
     // (the two tables are copied verbatim into LDS by every workgroup; rows are
     // padded so that 16 lanes reading 16 rows with ds_read_b128 hit 16 bank groups)
@@ -442,7 +455,7 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     for (int n2 = 0; n2 < 32; ++n2)
         for (int n1 = 0; n1 < 32; ++n1) {
             const int i = 32 * n1 + n2;
-            const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)kNfft);
+            const double w = hann(i);
             wintab[n2 * kWinRow + n1] = 0.5f * (float)w;   // the 1/2 of the two-real-signals split, exact
         }
     std::vector<float> twtab(32 * kTwRow, 0.0f);
@@ -465,7 +478,7 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
             const int n2 = (l >> 4) + 4 * (l & 15);
             for (int n1 = 0; n1 < 16; ++n1) {
                 const int i = 64 * n1 + n2;
-                const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)kNfft);
+                const double w = hann(i);
                 win2[l * v2::kWinRow2 + n1] = 0.5f * (float)w;
                 if (n1 == 0) continue;                                           // n1 plays k1; rows start at k1 = 1
                 const double a = 2.0 * kPi * (double)(n1 * n2) / (double)kNfft;
@@ -514,22 +527,25 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     p->d_tabs2 = reinterpret_cast<const float*>(base + off_tabs2);
     p->d_wfrag8 = reinterpret_cast<const float*>(base + off_wf8);
     p->d_meta8 = reinterpret_cast<const int*>(base + off_meta8);
-    if (p->dense_mel) {
+    const auto upload_bank = [&](const std::vector<float>& w, int row_len, DevBuf& d_w, DevBuf& d_b) -> af_status {
         std::vector<int> band(2 * cfg->n_mels, 0);
         for (uint32_t m = 0; m < cfg->n_mels; ++m) {
-            int lo = kBins, hi = 0;
-            for (int k = 0; k < kBins; ++k)
-                if (p->W[(size_t)m * kBins + k] != 0.0f) { lo = std::min(lo, k); hi = k + 1; }
+            int lo = row_len, hi = 0;
+            for (int k = 0; k < row_len; ++k)
+                if (w[(size_t)m * row_len + k] != 0.0f) { lo = std::min(lo, k); hi = k + 1; }
             band[2 * m] = lo < hi ? lo : 0;
             band[2 * m + 1] = lo < hi ? hi : 0;
         }
-        st = p->d_W.reserve(p->W.size() * sizeof(float));
-        if (st == AF_OK) st = p->d_band.reserve(band.size() * sizeof(int));
-        if (st == AF_OK && (hipMemcpy(p->d_W.p, p->W.data(), p->W.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-                            hipMemcpy(p->d_band.p, band.data(), band.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
-            st = fail(AF_ERR_HIP, "uploading the filterbank failed");
-        if (st != AF_OK) { delete p; return st; }
-    }
+        AF_TRY(d_w.reserve(w.size() * sizeof(float)));
+        AF_TRY(d_b.reserve(band.size() * sizeof(int)));
+        if (hipMemcpy(d_w.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_b.p, band.data(), band.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(AF_ERR_HIP, "uploading the filterbank failed");
+        return AF_OK;
+    };
+    if (p->dense_mel) st = upload_bank(p->W, kBins, p->d_W, p->d_band);
+    if (st == AF_OK && cfg->n_fft != (uint32_t)kNfft) st = upload_bank(p->Wn, (int)cfg->n_fft / 2 + 1, p->d_Wn, p->d_bandn);
+    if (st != AF_OK) { delete p; return st; }
     *out = p;
     return AF_OK;
 }
@@ -545,7 +561,7 @@ size_t af_features_n_frames(const af_features* p, size_t n_pcm_frames)
 size_t af_features_row_len(const af_features* p)
 {
     if (!p) return 0;
-    return p->cfg.output == AF_OUT_POWER ? (size_t)kBins : (size_t)p->cfg.n_mels;
+    return p->cfg.output == AF_OUT_POWER ? (size_t)(p->cfg.n_fft / 2 + 1) : (size_t)p->cfg.n_mels;
 }
 
 af_status af_features_set_batch(af_features* p, const int64_t* clip_offsets, size_t n_clips,
@@ -613,26 +629,38 @@ af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel
 // for filterbanks the banded MFMA plan does not cover (dense_mel); f32 FMA chain in bin order
 __global__ __launch_bounds__(256) void dense_mel_kernel(const float* __restrict__ power, float* __restrict__ mel,
                                                         const float* __restrict__ W, const int* __restrict__ band,
-                                                        int n_mels, int64_t n_frames, int log_mel)
+                                                        int n_mels, int64_t n_frames, int log_mel, int row_len)
 {
     constexpr int F = 8;
     __shared__ float rows[F][kBins + 3];
     for (int64_t f0 = (int64_t)blockIdx.x * F; f0 < n_frames; f0 += (int64_t)gridDim.x * F) {
         __syncthreads();
-        for (int i = threadIdx.x; i < F * kBins; i += blockDim.x) {
-            const int f = i / kBins, k = i - f * kBins;
-            rows[f][k] = f0 + f < n_frames ? power[(f0 + f) * kBins + k] : 0.0f;
+        for (int i = threadIdx.x; i < F * row_len; i += blockDim.x) {
+            const int f = i / row_len, k = i - f * row_len;
+            rows[f][k] = f0 + f < n_frames ? power[(f0 + f) * row_len + k] : 0.0f;
         }
         __syncthreads();
         for (int o = threadIdx.x; o < F * n_mels; o += blockDim.x) {
             const int f = o / n_mels, m = o - f * n_mels;
             if (f0 + f >= n_frames) continue;
-            const float* w = W + (size_t)m * kBins;
+            const float* w = W + (size_t)m * row_len;
             float acc = 0.0f;
             for (int k = band[2 * m]; k < band[2 * m + 1]; ++k) acc = __builtin_fmaf(w[k], rows[f][k], acc);
             if (log_mel) acc = __log10f(fmaxf(acc, 1e-10f));
             mel[(f0 + f) * n_mels + m] = acc;
         }
+    }
+}
+
+// n_fft < 1024, power output: bins 0, s, 2 s ... of the 1024-point rows are the n_fft-point spectrum
+__global__ void decimate_power_kernel(const float* __restrict__ power, float* __restrict__ out, int stride, int bins_n,
+                                      int64_t n_frames)
+{
+    const int64_t total = n_frames * bins_n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / bins_n;
+        const int k = (int)(i - f * bins_n);
+        out[i] = power[f * kBins + (int64_t)k * stride];
     }
 }
 
@@ -653,15 +681,26 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     }
     // dense_mel: the kernels write power rows, the contraction with W follows as its own launch
     const bool dense = p->dense_mel && p->cfg.output != AF_OUT_POWER;
-    if (dense) AF_REQUIRE(u_begin == 0 && u_count == p->total_units, "dense filterbank path: whole batches only");
+    // n_fft < 1024 with power output: 1024-point rows first, then every (1024 / n_fft)-th bin
+    const bool thin = p->cfg.output == AF_OUT_POWER && p->cfg.n_fft != (uint32_t)kNfft;
+    if (dense || thin) AF_REQUIRE(u_begin == 0 && u_count == p->total_units, "two-launch feature path: whole batches only");
     float* const mel_out = mel_dev;
-    if (dense) mel_dev = p->d_power.as<float>();
+    if (dense || thin) mel_dev = p->d_power.as<float>();
     const auto finish = [&]() -> af_status {
-        if (!dense || p->total_frames == 0) return AF_OK;
+        if (!(dense || thin) || p->total_frames == 0) return AF_OK;
+        if (thin) {
+            const int bins_n = (int)p->cfg.n_fft / 2 + 1;
+            const int64_t total = p->total_frames * bins_n;
+            const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)p->n_cus * 32);
+            hipLaunchKernelGGL(decimate_power_kernel, dim3(grid), dim3(256), 0, as_stream(stream), p->d_power.as<float>(),
+                               mel_out, kNfft / (int)p->cfg.n_fft, bins_n, p->total_frames);
+            AF_HIP(hipGetLastError());
+            return AF_OK;
+        }
         const int64_t blocks = (p->total_frames + 7) / 8;
         const unsigned grid = (unsigned)std::min<int64_t>(blocks, (int64_t)p->n_cus * 16);
         hipLaunchKernelGGL(dense_mel_kernel, dim3(grid), dim3(256), 0, as_stream(stream), p->d_power.as<float>(), mel_out,
-                           p->d_W.as<float>(), p->d_band.as<int>(), (int)p->cfg.n_mels, p->total_frames, (int)p->cfg.log_mel);
+                           p->d_W.as<float>(), p->d_band.as<int>(), (int)p->cfg.n_mels, p->total_frames, (int)p->cfg.log_mel, kBins);
         AF_HIP(hipGetLastError());
         return AF_OK;
     };
@@ -750,7 +789,8 @@ af_status af_features_run(af_features* p, const void* pcm, size_t pcm_len, float
     hipPointerAttribute_t pa;
     const bool pinned = hipPointerGetAttributes(&pa, pcm) == hipSuccess && pa.type == hipMemoryTypeHost;
     if (!pinned) (void)hipGetLastError();
-    if (pinned && p->contiguous && n >= 2 && in_bytes >= ((size_t)64 << 20) && !p->dense_mel) {
+    const bool two_launches = p->dense_mel || (p->cfg.output == AF_OUT_POWER && p->cfg.n_fft != (uint32_t)kNfft);
+    if (pinned && p->contiguous && n >= 2 && in_bytes >= ((size_t)64 << 20) && !two_launches) {
         const int64_t target = (int64_t)(((size_t)32 << 20) / bpf);
         size_t c0 = 0;
         while (c0 < n) {
@@ -836,9 +876,9 @@ af_status af_pipeline_run(const af_batch_desc* batch, const void* pcm, size_t pc
 af_status af_features_mel_weights(const af_features* p, float* W, size_t cap)
 {
     AF_REQUIRE(p && W, "af_features_mel_weights: null argument");
-    if (cap < p->W.size())
-        return fail(AF_ERR_BUFFER_TOO_SMALL, "need %zu floats", p->W.size());
-    std::memcpy(W, p->W.data(), p->W.size() * sizeof(float));
+    if (cap < p->Wn.size())
+        return fail(AF_ERR_BUFFER_TOO_SMALL, "need %zu floats", p->Wn.size());
+    std::memcpy(W, p->Wn.data(), p->Wn.size() * sizeof(float));
     return AF_OK;
 }
 
@@ -936,7 +976,7 @@ size_t af_stft_n_frames(const af_stft* s, size_t n_pcm_frames)
 {
     return s ? af_features_n_frames(s->f, n_pcm_frames) : 0;
 }
-size_t af_stft_n_bins(const af_stft* s) { return s ? (size_t)kBins : 0; }
+size_t af_stft_n_bins(const af_stft* s) { return s ? af_features_row_len(s->f) : 0; }
 
 af_status af_stft_set_batch_uniform(af_stft* s, size_t n_clips, size_t frames_per_clip,
                                     size_t* total_frames_out)
@@ -1024,12 +1064,16 @@ af_status af_mel_apply_device(af_mel* m, const float* power_dev, size_t n_frames
     AF_REQUIRE(m, "af_mel_apply_device: null handle");
     if (n_frames == 0) return AF_OK;
     AF_REQUIRE(power_dev && mel_dev, "af_mel_apply_device: null buffer");
-    if (m->f->dense_mel) {                      // a filterbank the banded plan does not cover: the dense contraction
+    if (m->f->dense_mel || m->f->cfg.n_fft != (uint32_t)kNfft) {
+        // a filterbank the banded plan does not cover, or power rows of n_fft / 2 + 1 < 513 bins: the dense contraction
+        // (on the rows' own grid: d_Wn)
+        const bool narrow = m->f->cfg.n_fft != (uint32_t)kNfft;
         const int64_t blocks = ((int64_t)n_frames + 7) / 8;
         const unsigned grid = (unsigned)std::min<int64_t>(blocks, (int64_t)m->f->n_cus * 16);
         hipLaunchKernelGGL(dense_mel_kernel, dim3(grid), dim3(256), 0, as_stream(stream), power_dev, mel_dev,
-                           m->f->d_W.as<float>(), m->f->d_band.as<int>(), (int)m->f->cfg.n_mels, (int64_t)n_frames,
-                           (int)m->f->cfg.log_mel);
+                           narrow ? m->f->d_Wn.as<float>() : m->f->d_W.as<float>(),
+                           narrow ? m->f->d_bandn.as<int>() : m->f->d_band.as<int>(), (int)m->f->cfg.n_mels,
+                           (int64_t)n_frames, (int)m->f->cfg.log_mel, narrow ? (int)m->f->cfg.n_fft / 2 + 1 : kBins);
         AF_HIP(hipGetLastError());
         return AF_OK;
     }

@@ -164,3 +164,62 @@ def test_wide_filterbanks_take_the_dense_contraction(af, po, sr, ch, n_mels, hop
     P = (rng.random((37, 513)) ** 4).astype(np.float32) * 10.0
     fb = af.MelFilterbank(sample_rate=sr, n_mels=n_mels)
     assert frame_rel_err(fb.apply(P), po.mel_apply(P, W)) < TOL
+
+
+@pytest.mark.parametrize("n_fft,hop,sr,ch,n_mels", [(512, 128, 16000, 1, 80), (512, 160, 16000, 2, 40), (256, 64, 8000, 1, 40),
+                                                    (512, 256, 48000, 2, 80), (256, 256, 16000, 1, 23)])
+def test_shorter_transforms(af, po, n_fft, hop, sr, ch, n_mels):
+    """n_fft 512 / 256: the kernels transform the n_fft-sample frame zero-padded to 1024 points, whose every (1024 / n_fft)-th
+    bin IS the n_fft-point DFT; frame counts, window, filterbank and rows are those of the n_fft-point definition
+    (docs/OPS.md), against the oracle's n_fft-point transform.  Ragged batch incl. clips of n_fft and n_fft - 1 samples."""
+    lens = [20000, n_fft, n_fft - 1, 7777]
+    clips = [synth_clip(60 + i, n, ch, sr) for i, n in enumerate(lens)]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    flat = np.concatenate([x.reshape(-1) for x in clips])
+    pipe = af.FeaturePipeline(sample_rate=sr, channels=ch, n_fft=n_fft, hop=hop, n_mels=n_mels)
+    total = pipe.set_batch(offs)
+    assert total == sum(po.stft_n_frames(n, n_fft, hop) for n in lens)
+    got = pipe.run(flat)
+    W = po.mel_weights(float(sr), n_fft=n_fft, n_mels=n_mels)
+    assert np.array_equal(pipe.mel_weights(), W.astype(np.float32))
+    pw = af.FeaturePipeline(sample_rate=sr, channels=ch, n_fft=n_fft, hop=hop, n_mels=n_mels, output=af._ffi.AF_OUT_POWER)
+    assert pw.set_batch(offs) == total and pw.row_len() == n_fft // 2 + 1
+    power = pw.run(flat)
+    row = 0
+    for x, n in zip(clips, lens):
+        nf = pipe.n_frames(n)
+        if nf:
+            mono = po.to_mono(x, ch)
+            P = po.stft_power(mono, n_fft, hop)
+            assert frame_rel_err(power[row:row + nf], P) < TOL
+            assert frame_rel_err(got[row:row + nf], po.mel_apply(P, W)) < TOL
+        row += nf
+    assert row == total
+    # the stand-alone stages on the same grid
+    P = af.Stft(n_fft=n_fft, hop=hop, channels=ch).power(clips[0])
+    assert P.shape[1] == n_fft // 2 + 1 and frame_rel_err(P, po.stft_power(po.to_mono(clips[0], ch), n_fft, hop)) < TOL
+    fb = af.MelFilterbank(sample_rate=sr, n_fft=n_fft, n_mels=n_mels)
+    assert frame_rel_err(fb.apply(P), po.mel_apply(P.astype(np.float64), W)) < TOL
+
+
+def test_shorter_transform_streams_like_one_shot(af):
+    """af_stream_* with n_fft = 512 (carry n_fft - hop = 384 frames): pushes + flush == one-shot, bit for bit; and a bank of
+    20 mels at 48 kHz (the dense contraction inside the replayed graph)."""
+    for kw, sr, ch in [(dict(n_fft=512, hop=128, n_mels=40, sample_rate=16000, channels=1), 16000, 1),
+                       (dict(n_mels=20, sample_rate=48000, channels=2), 48000, 2)]:
+        hop = kw.get("hop", 256)
+        n = 16 * hop * 9 + 3333
+        x = synth_clip(70, n, ch, sr)
+        xf = x.reshape(n, ch)
+        st = af.FeatureStream(step_frames=16 * hop * 2, **kw)
+        rng = np.random.default_rng(6)
+        rows, pos = [], 0
+        while pos < n:
+            k = int(rng.integers(1, 9000))
+            rows.append(st.push(xf[pos:pos + k]))
+            pos += k
+        rows.append(st.flush())
+        got = np.concatenate(rows)
+        one = af.FeaturePipeline(**kw)
+        one.set_batch_uniform(1, n)
+        assert np.array_equal(got, one.run(x.reshape(-1)))
