@@ -287,12 +287,14 @@ struct MelSpectrogram {
 // Stft::new(n_fft, hop) [B]: power spectrogram rows [frame][n_fft/2+1]
 class Stft {
 public:
-    explicit Stft(uint32_t hop = 256, uint32_t channels = 1)
+    // n_fft 1024 (default), 512 or 256: the Stft::new(n_fft, hop) shape of SURVEY.md section 8 A6
+    explicit Stft(uint32_t hop = 256, uint32_t channels = 1, uint32_t n_fft = 1024)
     {
         af_stft_config c;
         af_stft_default_config(&c);
         c.hop = hop;
         c.channels = channels;
+        c.n_fft = n_fft;
         detail::check(af_stft_create(&c, &h_));
     }
     Stft(const Stft&) = delete;

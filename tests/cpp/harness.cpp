@@ -131,6 +131,13 @@ int main()
         CHECK(arg == 64);
         // periodic Hann: sum w^2 = 3N/8; a bin-centred tone of amplitude A has |X|^2 = (A N / 4)^2
         CHECK(std::fabs(P[64] / (0.5 * 1024 / 4) / (0.5 * 1024 / 4) - 1.0) < 1e-3);
+        // n_fft 512: 1 kHz = bin 32 of 257, same amplitude law with N = 512
+        Stft st512(128, 1, 512);
+        CHECK(st512.n_frames(x.size()) == 1 + (16000 - 512) / 128 && st512.n_bins() == 257);
+        auto P5 = st512.power(x);
+        size_t arg5 = 0;
+        for (size_t k = 1; k < 257; ++k) if (P5[k] > P5[arg5]) arg5 = k;
+        CHECK(arg5 == 32 && std::fabs(P5[32] / (0.5 * 512 / 4) / (0.5 * 512 / 4) - 1.0) < 1e-3);
         MelFilterbank fb(16000, 80);
         auto W = fb.weights();
         CHECK(W.size() == 80 * 513);
