@@ -111,4 +111,9 @@ struct DevBuf {
     T* as() const { return static_cast<T*>(p); }
 };
 
+// features_api.hip: the feature kernel on the units of clips [clip_begin, clip_end) of the handle's batch (rows land at
+// their places in mel_dev), with wg_per_cu workgroups per CU (1 | 2) -- the chain's pipelined form
+af_status features_run_clips(af_features* p, const void* pcm_dev, float* mel_dev, hipStream_t stream, size_t clip_begin,
+                             size_t clip_end, int wg_per_cu);
+
 }  // namespace af

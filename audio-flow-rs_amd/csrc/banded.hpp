@@ -132,6 +132,7 @@ struct FusedArgs {
     int64_t n_clips = 0;
     const FusedTile* tiles = nullptr;   // device; ragged batch (then x_len .. n_clips above are ignored)
     int64_t n_tiles = 0;
+    int wg_per_cu = 2;         // 1: leave half of every CU to another kernel (the chain's pipelined form)
 };
 // z[clip][m - m0] = FIR(resample(to_mono(x[clip])))[m]
 af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* afrag_b, const FusedArgs& args,

@@ -1465,7 +1465,9 @@ af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* af
     g.ys_off = kCols * f.seg_stride_a;
     g.inv_colz = 1.0f / (float)(16 * f.P2);
     int64_t grid = g.n_tiles;
-    const int64_t cap = 2 * (int64_t)device_cu_count(current_device());
+    // (diagnostics: af_debug_set("features.wg_per_cu", 1) also holds this launch to one workgroup per CU)
+    const int64_t cap = (debug_knob(kKnobFeaturesWgPerCu) == 1 || q.wg_per_cu == 1 ? 1 : 2) *
+                        (int64_t)device_cu_count(current_device());
     if (grid > cap) grid = cap;
     if (f.a.NK == 24) return launch_resfir_f<24>(f.fmt, f.NKB, g, (unsigned)grid, f.smem, stream);
     return launch_resfir_f<28>(f.fmt, f.NKB, g, (unsigned)grid, f.smem, stream);

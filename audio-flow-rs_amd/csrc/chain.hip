@@ -37,6 +37,19 @@ struct af_chain {
     const float* afrag_res = nullptr;
     DevBuf d_afrag_fir;
     int opt_unfused = -1;            // af_chain_set_option("unfused"); -1: the process-wide af_debug_set switch
+    // the pipelined form of the two-launch chain (uniform batches): see run_pipelined
+    int opt_pipeline = 0;            // af_chain_set_option("pipeline", chunks); 0: off (the default)
+    hipStream_t s_a = nullptr, s_b = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_chunk;
+    ~af_chain()
+    {
+        for (hipEvent_t e : ev_chunk) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (s_a) (void)hipStreamDestroy(s_a);
+        if (s_b) (void)hipStreamDestroy(s_b);
+    }
     // the batch
     bool ragged = false;
     size_t n_clips = 0, n_in = 0, n_res = 0;         // uniform: frames per clip in / resampled
@@ -226,6 +239,66 @@ af_status strip_run(af_chain* c, const void* pcm_dev, hipStream_t s, const float
     return AF_OK;
 }
 
+// ---- the two launches side by side (af_chain_set_option("pipeline", chunks); off by default) --------------------
+// The fused resampler + FIR launch is at its memory side: with ONE workgroup per CU it is as fast as with two (0.77 ms
+// either way on config 4's shard).  The feature kernel is at its arithmetic side and needs little memory traffic.  Each
+// needs 128 registers per lane and 72-78 KB of LDS per workgroup, so one workgroup of EACH fits a CU together.  The batch
+// is cut into chunks of clips; stream A runs the first launch chunk after chunk at one workgroup per CU, stream B follows
+// one chunk behind with the feature kernel, also at one workgroup per CU, behind an event per chunk.  Same kernels, same
+// data, same bits; the caller's stream forks into the two and joins them again (event record / wait: capturable).
+// MEASURED (scripts/gpu_bench_chain_pipeline.py, kernel trace gpurun_out/r03/pipe_kt): the launches do run side by side,
+// but a chunk of the first launch then takes 152 instead of 126 us and a chunk of the feature kernel 150-165 instead of
+// 72 us -- sharing the SIMDs' issue slots and the matrix pipe costs what the overlap buys: 1.16-1.19 ms against 1.13 one
+// after the other, and with the feature kernel's waves at a higher issue priority 1.21-1.24.  Kept as an option only.
+int pipeline_chunks(const af_chain* c)
+{
+    if (c->ragged || c->opt_pipeline == 0) return 0;
+    if (c->opt_pipeline > 0) return (int)std::min<size_t>((size_t)c->opt_pipeline, c->n_clips);
+    return 0;                                                       // (see MEASURED above)
+}
+
+af_status pipeline_resources(af_chain* c, int chunks)
+{
+    if (!c->s_a) AF_HIP(hipStreamCreateWithFlags(&c->s_a, hipStreamNonBlocking));
+    if (!c->s_b) AF_HIP(hipStreamCreateWithFlags(&c->s_b, hipStreamNonBlocking));
+    if (!c->ev_fork) AF_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if (!c->ev_join) AF_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    while ((int)c->ev_chunk.size() < chunks) {
+        hipEvent_t e = nullptr;
+        AF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_chunk.push_back(e);
+    }
+    return AF_OK;
+}
+
+af_status run_pipelined(af_chain* c, const void* pcm_dev, float* mel_dev, hipStream_t stream, int chunks)
+{
+    AF_REQUIRE(c->s_a && c->s_b && (int)c->ev_chunk.size() >= chunks, "af_chain: pipeline resources missing (set_batch builds them)");
+    AF_HIP(hipEventRecord(c->ev_fork, stream));
+    AF_HIP(hipStreamWaitEvent(c->s_a, c->ev_fork, 0));
+    AF_HIP(hipStreamWaitEvent(c->s_b, c->ev_fork, 0));
+    const size_t n = c->n_clips;
+    for (int k = 0; k < chunks; ++k) {
+        const size_t c0 = n * (size_t)k / (size_t)chunks, c1 = n * (size_t)(k + 1) / (size_t)chunks;
+        if (c1 == c0) continue;
+        banded::FusedArgs q;
+        q.x = static_cast<const char*>(pcm_dev) + c0 * c->n_in * c->bpf;
+        q.z = c->d_fir.as<float>() + c0 * c->n_res;
+        q.x_len = q.x_stride = (int64_t)c->n_in;
+        q.z_stride = q.n_res = q.n_out = (int64_t)c->n_res;
+        q.n_clips = (int64_t)(c1 - c0);
+        q.wg_per_cu = 1;
+        AF_TRY(banded::launch_fused(c->fused, c->afrag_res, c->d_afrag_fir.as<float>(), q, c->s_a));
+        AF_HIP(hipEventRecord(c->ev_chunk[k], c->s_a));
+        AF_HIP(hipStreamWaitEvent(c->s_b, c->ev_chunk[k], 0));
+        AF_TRY(features_run_clips(c->feat, c->d_fir.as<float>(), mel_dev, c->s_b, c0, c1, 1));
+    }
+    // stream B's last launch is behind every launch of stream A
+    AF_HIP(hipEventRecord(c->ev_join, c->s_b));
+    AF_HIP(hipStreamWaitEvent(stream, c->ev_join, 0));
+    return AF_OK;
+}
+
 bool fused_applies(const af_chain* c)
 {
     if (!c->fused.ok || want_unfused(c)) return false;
@@ -304,6 +377,12 @@ af_status af_chain_set_option(af_chain* c, const char* key, int value)
         c->opt_unfused = value < 0 ? -1 : value != 0;
         return AF_OK;
     }
+    if (std::strcmp(key, "pipeline") == 0) {             // chunks of the pipelined two-launch form; <= 0: off
+        AF_REQUIRE(value <= 256, "af_chain_set_option: at most 256 pipeline chunks");
+        c->opt_pipeline = value < 0 ? 0 : value;
+        if (value > 0) AF_TRY(pipeline_resources(c, value));
+        return AF_OK;
+    }
     return fail(AF_ERR_INVALID_ARG, "af_chain_set_option: unknown option '%s'", key);
 }
 
@@ -332,6 +411,7 @@ af_status af_chain_set_batch_uniform(af_chain* c, size_t n_clips, size_t frames_
     if (c->cfg.n_fir_taps) AF_TRY(c->d_fir.reserve((size_t)c->total_z * sizeof(float)));
     size_t total = 0;
     AF_TRY(af_features_set_batch_uniform(c->feat, n_clips, c->n_res, &total));
+    if (const int chunks = pipeline_chunks(c)) AF_TRY(pipeline_resources(c, chunks));
     c->total_frames = total;
     if (total_frames_out) *total_frames_out = total;
     return AF_OK;
@@ -398,6 +478,7 @@ af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, 
     const bool resample = c->cfg.input_rate != c->cfg.output_rate;
     const bool i16 = c->cfg.sample_format == AF_PCM_I16;
     if (fused_applies(c)) {
+        if (const int chunks = pipeline_chunks(c)) return run_pipelined(c, pcm_dev, mel_dev, as_stream(stream), chunks);
         banded::FusedArgs q;
         q.x = pcm_dev;
         q.z = c->d_fir.as<float>();
@@ -457,7 +538,7 @@ int af_chain_n_launches(const af_chain* c)
 {
     if (!c) return 0;
     const bool resample = c->cfg.input_rate != c->cfg.output_rate;
-    if (fused_applies(c)) return 2;
+    if (fused_applies(c)) return pipeline_chunks(c) ? 2 * pipeline_chunks(c) : 2;
     int fir_parts = 0;
     if (c->cfg.n_fir_taps) {
         const banded::FirParts fp = banded::make_fir_parts((int)c->cfg.n_fir_taps);

@@ -607,22 +607,29 @@ af_status af_features_set_batch_spans(af_features* p, const int64_t* starts, con
 }
 
 static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel_dev, void* stream,
-                                 int64_t u_begin = 0, int64_t u_count = -1, int64_t f_begin = 0, int64_t f_end = -1);
+                                 int64_t u_begin = 0, int64_t u_count = -1, int64_t f_begin = 0, int64_t f_end = -1,
+                                 int wg_override = -1);
+
+// remember the launch: set_batch* must not rewrite the tables under it (not inside a stream capture: the replayed
+// graph owns its own ordering)
+static af_status note_launch(af_features* p, hipStream_t stream)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+    if (cs == hipStreamCaptureStatusNone) {
+        if (!p->last_run) AF_HIP(hipEventCreateWithFlags(&p->last_run, hipEventDisableTiming));
+        AF_HIP(hipEventRecord(p->last_run, stream));
+        p->run_pending = true;
+    }
+    return AF_OK;
+}
 
 af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel_dev, void* stream)
 {
     AF_REQUIRE(p, "af_features_run_device: null handle");
     AF_TRY(run_device_impl(p, pcm_dev, mel_dev, stream));
     if (p->total_units == 0) return AF_OK;
-    // remember the launch (not inside a stream capture: the replayed graph owns its own ordering)
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(as_stream(stream), &cs) != hipSuccess) (void)hipGetLastError();
-    if (cs == hipStreamCaptureStatusNone) {
-        if (!p->last_run) AF_HIP(hipEventCreateWithFlags(&p->last_run, hipEventDisableTiming));
-        AF_HIP(hipEventRecord(p->last_run, as_stream(stream)));
-        p->run_pending = true;
-    }
-    return AF_OK;
+    return note_launch(p, as_stream(stream));
 }
 
 // mel[f][m] = sum_k W[m][k] P[f][k] over the filter's own bins, 8 power rows per workgroup through LDS: the contraction
@@ -667,7 +674,7 @@ __global__ void decimate_power_kernel(const float* __restrict__ power, float* __
 // units [u_begin, u_begin + u_count) of the batch (u_count < 0: all of it), which read PCM frames
 // [f_begin, f_end) (f_end < 0: the whole batch)
 static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel_dev, void* stream,
-                                 int64_t u_begin, int64_t u_count, int64_t f_begin, int64_t f_end)
+                                 int64_t u_begin, int64_t u_count, int64_t f_begin, int64_t f_end, int wg_override)
 {
     if (u_count < 0) u_count = p->total_units - u_begin;
     if (p->total_units == 0 || u_count <= 0) return AF_OK;
@@ -726,7 +733,8 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     prm.log_mel = (int)p->cfg.log_mel;
     prm.separate = p->cfg.channel_mode == AF_CH_SEPARATE;
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
-    const int wg_knob = p->opt_wg_per_cu >= 0 ? p->opt_wg_per_cu : debug_knob(kKnobFeaturesWgPerCu);
+    const int wg_knob = wg_override > 0 ? wg_override
+                        : p->opt_wg_per_cu >= 0 ? p->opt_wg_per_cu : debug_knob(kKnobFeaturesWgPerCu);
     const int general = p->opt_kernel >= 0 ? p->opt_kernel : debug_knob(kKnobFeaturesKernel);
     if (p->units_ok && p->offsets_aligned4 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 == 0 && !general) {
         // hop 256, dword-aligned clips: the 8-wave kernel, two workgroups per CU
@@ -1107,3 +1115,17 @@ af_status af_mel_apply(af_mel* m, const float* power, size_t n_frames, float* me
 }
 
 }  // extern "C"
+
+
+// The chain's pipelined form (chain.hip): the units of clips [clip_begin, clip_end) only, on the given stream, with one
+// or two workgroups per CU.  Rows land at their places in mel_dev; the caller orders the launches.
+af_status af::features_run_clips(af_features* p, const void* pcm_dev, float* mel_dev, hipStream_t stream, size_t clip_begin,
+                                 size_t clip_end, int wg_per_cu)
+{
+    AF_REQUIRE(p && clip_begin <= clip_end && clip_end <= p->n_clips, "features_run_clips: bad clip range");
+    AF_REQUIRE(!p->dense_mel && p->cfg.channels <= 2, "features_run_clips: one-launch configurations only");
+    const int64_t u0 = p->h_unit_off[clip_begin], u1 = p->h_unit_off[clip_end];
+    if (u1 <= u0) return AF_OK;
+    AF_TRY(run_device_impl(p, pcm_dev, mel_dev, stream, u0, u1 - u0, 0, -1, wg_per_cu));
+    return note_launch(p, stream);
+}

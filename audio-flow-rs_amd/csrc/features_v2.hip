@@ -45,6 +45,10 @@
 #ifndef AF_V2_TW_EARLY
 #define AF_V2_TW_EARLY 0
 #endif
+// issue priority of the kernel's waves outside their raised sections (experiment: 1 when it shares CUs with another kernel)
+#ifndef AF_V2_BASE_PRIO
+#define AF_V2_BASE_PRIO 0
+#endif
 
 namespace af {
 namespace feat {
@@ -560,7 +564,8 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             // The issue arbiter prefers the older wave: waves 4..7 of a workgroup share their SIMDs with waves
             // 0..3 and would run the two FFT parts ~25 % slower (10.5 k against 8.5 k cycles), everyone then
             // waiting for them at B2.  One priority step for the younger half evens that out (-2.3 %).
-            if (w >= 4) __builtin_amdgcn_s_setprio(1);
+            if (w >= 4) __builtin_amdgcn_s_setprio(1 + AF_V2_BASE_PRIO);
+            else if (AF_V2_BASE_PRIO) __builtin_amdgcn_s_setprio(AF_V2_BASE_PRIO);
             float s1[20], win[16];
             stage1_load(tile, w, lane, wtab, s1, win);
             fft_pair_1(s1, win, wb, wv, lane, tw1, ur, ui);
@@ -585,14 +590,14 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                 for (int q = 0; q < NSLOT * kSlotSteps; ++q) wf[q] = 0.0f;
             }
             fft_pair_2(wb, wv, lane, ltw, ur, ui);
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(AF_V2_BASE_PRIO);
         }
         AF_STAMP2(3);
 
         __syncthreads();                             // B2: power rows ready, tile reads done
         // the tile update and the mel phase hold up the next unit's FFT and issue few instructions:
         // let them go ahead of the other workgroup's FFT stream
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(AF_V2_BASE_PRIO ? 3 : 2);
         AF_STAMP2(4);
         // Everything this wave has in flight is old by now (prefetch: a whole FFT ago; fragments: half of one; the
         // previous unit's mel stores: a unit ago) and all of it is needed right below.  One wait the compiler sees,
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                 }
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(AF_V2_BASE_PRIO);
         AF_STAMP2(5);
         ++u;
         fresh = !has_next;

@@ -424,7 +424,10 @@ af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, 
 /* host buffers; pcm_len counts samples (frames x channels) */
 af_status af_chain_run(af_chain* c, const void* pcm, size_t pcm_len, float* mel, size_t mel_cap);
 /* per-handle diagnostics (unlike af_debug_set they touch no other handle):
- *   "unfused"  1: resampler and FIR as separate launches; 0: fused where covered; -1: follow af_debug_set */
+ *   "unfused"  1: resampler and FIR as separate launches; 0: fused where covered; -1: follow af_debug_set
+ *   "pipeline" k > 0: equal-length batches run the two launches of the fused form side by side on two internal
+ *              streams, in k chunks of clips (same rows; measured slower than one after the other on MI355X,
+ *              DESIGN.md section 9 -- hence 0, off, by default) */
 af_status af_chain_set_option(af_chain* c, const char* key, int value);
 /* kernels af_chain_run_device enqueues per call for the configuration and batch described (2 when the
  * fused resampler + FIR launch applies; e.g. 3 for config 4 without it: resampler, FIR, STFT / mel) */

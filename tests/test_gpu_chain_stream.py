@@ -417,6 +417,24 @@ def test_chain_ragged_strip_many_clips(af):
     assert rows[-1] == mel.shape[0]
 
 
+def test_chain_pipelined_form_same_bits(af):
+    """af_chain_set_option("pipeline", k): the two launches side by side on two streams, chunk by chunk (measured slower than
+    one after the other on this chip, hence opt-in) -- same rows bit for bit, also when the chunks do not divide the batch."""
+    taps = lowpass_taps()
+    n_clips, n = 37, 30011
+    x = np.concatenate([synth_clip(1500 + i, n, 2, 48000) for i in range(n_clips)])
+    chain = af.ChainPipeline(fir_taps=taps)
+    chain.set_batch_uniform(n_clips, n)
+    ref = chain.run(x)
+    assert chain.n_launches() == 2
+    for k in (1, 3, 8, 37, 64):
+        chain.set_option("pipeline", k)
+        assert chain.n_launches() == 2 * min(k, n_clips)
+        assert np.array_equal(chain.run(x), ref)
+    chain.set_option("pipeline", 0)
+    assert chain.n_launches() == 2 and np.array_equal(chain.run(x), ref)
+
+
 def test_chain_ragged_random_configurations(af, po):
     """Seeded sweep over rate pairs (fused, ten-wave, streamed, VALU-fallback ratios, no resampler), FIR lengths up to
     several banded passes, formats and clip lengths: every clip of the ragged batch equals itself alone, bit for bit, and
