@@ -105,6 +105,58 @@ struct Params {
 af_status launch(const Params& p, int channels, bool i16, bool separate, int grid, hipStream_t stream);
 }  // namespace v2
 
+// ---- hop-256 kernel, DFT on the matrix cores (features_v3.hip) ---------------------------------
+// The 1024-point transform of 16 frames at once as two stages of 32-point DFTs written as matrix products
+// (n = 32 n1 + n2, k = k1 + 32 k2): stage 1 contracts n1 with a per-n2 matrix that carries the Hann window AND the
+// twiddle W1024^(n2 k1); stage 2 contracts n2 with the plain 32-point DFT matrix.  Operands are f16 pairs
+// (x = hi + 2^-11 lo'), three v_mfma_f32_16x16x32_f16 per product (hi hi, hi lo', lo' hi), f32 accumulation.
+namespace v3 {
+constexpr int kW = 8;                     // waves per workgroup, ONE workgroup per CU (256 VGPRs per lane)
+constexpr int kT = 64 * kW;
+constexpr int kHop = v2::kHop;
+constexpr int kTile = v2::kTile;          // 4864 mono samples = 152 blocks of 32
+constexpr int kTail = v2::kTail;          // 768
+constexpr int kBlk = kTile / 32;          // 152
+constexpr int kQuads = kBlk / 4;          // 38 groups of four blocks
+constexpr int kTRow = 2 * kBlk;           // bytes per row of the f16 signal image T[n2][blk] (304: 16-lane b64 stores conflict-free)
+constexpr int kYRow = 288;                // bytes per (k1 slot, frame): Yr hi | Yi hi | Yr lo' | Yi lo' (64 B each) + 32 pad
+constexpr int kYSlot = 16 * kYRow;        // one k1 slot: 16 frames
+constexpr int kProw = 520;                // dwords per power row (== 8 mod 64: the mel phase's ds_read_b128 pattern)
+constexpr int kHaloRow = 112;             // bytes per row of the f32 copy of the tile's last 768 samples [n2][24]
+// LDS map (bytes)
+constexpr int kOffY = 0;
+constexpr int kOffThi = kOffY + 16 * kYSlot;                // 73 728
+constexpr int kOffTlo = kOffThi + 32 * kTRow;
+constexpr int kOffHalo = kOffTlo + 32 * kTRow;              // two buffers
+constexpr int kOffP = kOffHalo + 2 * 32 * kHaloRow;
+constexpr int kOffWmax = kOffP + 16 * kProw * 4;
+constexpr int kOffMeta = kOffWmax + 64;
+constexpr int kLdsBytes = kOffMeta + kW * kMaxSlotsW * 4;
+static_assert(kLdsBytes <= 160 * 1024 && kOffThi % 16 == 0 && kOffTlo % 16 == 0 && kOffHalo % 16 == 0 && kOffP % 16 == 0,
+              "LDS map");
+// fragment tables (uint4 = 8 f16 per lane): a1 [32 n2][2 row blocks][hi, lo'][64]; a2 [4 row blocks][hi, lo'][64];
+// a2s (k1 = 16, its twiddle W64^n2 folded in) [2 row blocks][hi, lo'][64]
+constexpr int kA1Vec = 32 * 2 * 2 * 64;
+constexpr int kA2Vec = 4 * 2 * 64;
+constexpr int kA2sVec = 2 * 2 * 64;
+constexpr int kTabVec = kA1Vec + kA2Vec + kA2sVec;
+
+struct Params {
+    const void* pcm;
+    float* out;               // mel rows [total_frames][n_mels]
+    const uint4* tabs;        // a1 | a2 | a2s
+    const float* wfrag;       // the hop-256 mel plan's fragments [8][kMaxSlotsW][64][4] (f32, as features_v2)
+    const int* meta;          // [8][kMaxSlotsW]
+    const v2::UnitDesc* units;
+    Plan plan;
+    int64_t total_units;
+    int log_mel;
+};
+// host: the three fragment tables for a window (values of the 1024-point frame, zero behind n_fft)
+void build_tables(const double* window1024, uint4* tabs);
+af_status launch(const Params& p, int channels, bool i16, bool separate, int grid, hipStream_t stream);
+}  // namespace v3
+
 struct Params {
     const void* pcm;          // interleaved PCM (f32 or i16)
     float* mel;               // [total_frames][n_mels]  (or [total_frames][513] power rows)

@@ -32,6 +32,8 @@ struct af_features {
     DevBuf d_mono;                   // channels > 2: the downmixed batch the fused kernel reads
     DevBuf d_units;                  // v2::UnitDesc per 16-frame unit (hop 256 only)
     bool units_ok = false;
+    DevBuf d_tabs3;                  // features_v3.hip: f16-pair fragment tables of the two DFT stages (hop 256, mel output)
+    bool v3_ok = false;
     // filterbanks the banded MFMA plan does not cover (few, wide filters: 20 mels at 48 kHz ...): the kernels write
     // |X|^2 rows into d_power and dense_mel_kernel contracts them with W (two launches instead of one)
     bool dense_mel = false;
@@ -543,6 +545,18 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
             return fail(AF_ERR_HIP, "uploading the filterbank failed");
         return AF_OK;
     };
+    // hop-256 kernel with the DFT on the matrix cores (features_v3.hip): mel output through the 8-wave banded plan
+    if (cfg->hop == (uint32_t)v2::kHop && p->plan8.n_waves == v2::kW && !p->dense_mel && cfg->output == AF_OUT_MEL) {
+        std::vector<double> win(kNfft);
+        for (int i = 0; i < kNfft; ++i) win[i] = hann(i);
+        std::vector<uint4> tabs3(v3::kTabVec);
+        v3::build_tables(win.data(), tabs3.data());
+        st = p->d_tabs3.reserve(tabs3.size() * sizeof(uint4));
+        if (st == AF_OK && hipMemcpy(p->d_tabs3.p, tabs3.data(), tabs3.size() * sizeof(uint4), hipMemcpyHostToDevice) != hipSuccess)
+            st = fail(AF_ERR_HIP, "uploading the DFT fragment tables failed");
+        if (st != AF_OK) { delete p; return st; }
+        p->v3_ok = true;
+    }
     if (p->dense_mel) st = upload_bank(p->W, kBins, p->d_W, p->d_band);
     if (st == AF_OK && cfg->n_fft != (uint32_t)kNfft) st = upload_bank(p->Wn, (int)cfg->n_fft / 2 + 1, p->d_Wn, p->d_bandn);
     if (st != AF_OK) { delete p; return st; }
@@ -735,8 +749,31 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
     const int wg_knob = wg_override > 0 ? wg_override
                         : p->opt_wg_per_cu >= 0 ? p->opt_wg_per_cu : debug_knob(kKnobFeaturesWgPerCu);
-    const int general = p->opt_kernel >= 0 ? p->opt_kernel : debug_knob(kKnobFeaturesKernel);
-    if (p->units_ok && p->offsets_aligned4 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 == 0 && !general) {
+    // which fused kernel: 0 = the best that applies (hop 256: features_v3, then features_v2), 1 = the general kernel,
+    // 2 = features_v2 (the register-FFT kernel of rounds 2-3), 3 = features_v3 or an error
+    const int ksel = p->opt_kernel >= 0 ? p->opt_kernel : debug_knob(kKnobFeaturesKernel);
+    const bool hop256_ok = p->units_ok && p->offsets_aligned4 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 == 0;
+    const bool v3_applies = hop256_ok && p->v3_ok && !prm.out_power;
+    if (ksel == 3 && !v3_applies)
+        return fail(AF_ERR_UNSUPPORTED, "features: the matrix-core DFT kernel serves hop 256 with mel output through the banded plan only");
+    if (v3_applies && ksel == 3) {                       // (opt-in until it is the faster one)
+        v3::Params q{};
+        q.pcm = pcm_dev;
+        q.out = mel_dev;
+        q.tabs = p->d_tabs3.as<uint4>();
+        q.wfrag = p->d_wfrag8;
+        q.meta = p->d_meta8;
+        q.units = p->d_units.as<v2::UnitDesc>() + u_begin;
+        q.plan = p->plan8;
+        q.total_units = u_count;
+        q.log_mel = prm.log_mel;
+        int64_t grid3 = (int64_t)p->n_cus;               // one 8-wave workgroup per CU (256 registers per lane, 131 KB of LDS)
+        if (grid3 > u_count) grid3 = u_count;
+        AF_TRY(v3::launch(q, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
+                          (int)grid3, as_stream(stream)));
+        return finish();
+    }
+    if (hop256_ok && ksel != 1) {
         // hop 256, dword-aligned clips: the 8-wave kernel, two workgroups per CU
         v2::Params q{};
         q.pcm = pcm_dev;
@@ -890,7 +927,7 @@ af_status af_features_mel_weights(const af_features* p, float* W, size_t cap)
     return AF_OK;
 }
 
-const char* af_features_kernel_name(void) { return "af_features_v2_kernel"; }   // the BASELINE configuration (hop 256); other hops: af_features_kernel
+const char* af_features_kernel_name(void) { return "af_features_v2_kernel"; }   // the BASELINE configuration (hop 256, mel output); power output: af_features_v2_kernel; other hops: af_features_kernel
 
 // diagnostics, host only: the mel plans -- info[81] = {groups, K-steps, slots of wave 0..3} of the
 // general kernel, then {waves (0: not in use), groups, K-steps, slots of wave 0..7} of the hop-256 kernel,

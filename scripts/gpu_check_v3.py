@@ -1,0 +1,103 @@
+"""Check of the matrix-core DFT kernel (features_v3.hip) on the GPU: ragged batches in all four PCM formats against
+the float64 oracle and against features_v2 (af_features_set_option kernel = 2), dynamic-range cases, log-mel /
+separate channels / other filterbanks, then config-2 timing of both kernels in one process."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import audio_flow_rs_amd as af
+from oracle import pyoracle as po
+from util import synth_clip, frame_rel_err
+
+lib = af.library()
+
+def run(clips, ch, fmt=0, kernel=3, **kw):
+    pipe = af.FeaturePipeline(sample_rate=kw.pop("sample_rate", 48000), channels=ch, hop=256, sample_format=fmt, **kw)
+    assert lib.af_features_set_option(pipe._h, b"kernel", kernel) == 0
+    offs = np.zeros(len(clips) + 1, np.int64)
+    for i, c in enumerate(clips): offs[i + 1] = offs[i] + c.size // ch
+    pipe.set_batch(offs)
+    return pipe.run(np.concatenate(clips))
+
+def per_frame(got, ref):
+    g = np.asarray(got, np.float64)
+    return np.linalg.norm(g - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-300)
+
+worst = 0.0
+lens = [0, 1016, 1024, 1024 + 256 * 15, 1024 + 256 * 16, 1024 + 256 * 16 - 8, 7776, 50000, 8, 1024 + 256 * 47, 123456]
+for ch in (2, 1):
+    for fmt in (0, 1):
+        clips = [synth_clip(i, n, ch, 48000) for i, n in enumerate(lens)]
+        if fmt: clips = [np.round(c * 32767.0).astype(np.int16) for c in clips]
+        mel = run(clips, ch, fmt, 3)
+        mel2 = run(clips, ch, fmt, 2)
+        row = 0
+        for n, x in zip(lens, clips):
+            xf = x.astype(np.float32) / np.float32(32768.0) if fmt else x
+            ref = po.features(xf, ch, 48000.0)
+            nf = ref.shape[0]
+            e = frame_rel_err(mel[row:row + nf], ref) if nf else 0.0
+            e2 = frame_rel_err(mel2[row:row + nf], ref) if nf else 0.0
+            worst = max(worst, e)
+            if e > 1e-5:
+                fe = per_frame(mel[row:row + nf], ref)
+                bad = np.nonzero(fe > 1e-5)[0]
+                print("   bad frames:", bad.tolist()[:64], "got", np.asarray(mel[row + bad[0]][:6]), "ref", ref[bad[0]][:6], flush=True)
+            print(f"ch={ch} fmt={fmt} n={n:7d} frames={nf:4d} v3 vs oracle {e:.2e}   (v2 {e2:.2e})", flush=True)
+            row += nf
+        assert row == mel.shape[0] and np.all(np.isfinite(mel))
+print("worst vs oracle", worst, flush=True)
+
+# dynamic range inside one 16-frame unit, tiny and large signals
+rng = np.random.default_rng(5)
+n = 1024 + 256 * 63
+cases = {
+    "x 1e-6": 1e-6 * rng.standard_normal(n),
+    "x 1e+4": 1e4 * rng.standard_normal(n),
+    "80 dB step": np.concatenate([rng.standard_normal(n // 2), 1e-4 * rng.standard_normal(n - n // 2)]),
+    "120 dB step": np.concatenate([rng.standard_normal(n // 2), 1e-6 * rng.standard_normal(n - n // 2)]),
+    "160 dB step": np.concatenate([rng.standard_normal(n // 2), 1e-8 * rng.standard_normal(n - n // 2)]),
+    "silence then tone": np.concatenate([np.zeros(n // 2), np.sin(0.05 * np.arange(n - n // 2))]),
+    "dc": np.full(n, 0.7),
+    "zeros": np.zeros(n),
+}
+for name, x in cases.items():
+    x = x.astype(np.float32)
+    ref = po.features(x, 1, 48000.0)
+    fe3 = per_frame(run([x], 1, 0, 3), ref) if np.any(ref) else np.abs(run([x], 1, 0, 3)).max(axis=1)
+    fe2 = per_frame(run([x], 1, 0, 2), ref) if np.any(ref) else np.abs(run([x], 1, 0, 2)).max(axis=1)
+    ok = np.isfinite(fe3)
+    print(f"{name:18s} v3 max {np.nanmax(fe3):.2e} median {np.nanmedian(fe3):.2e}   v2 max {np.nanmax(fe2):.2e}", flush=True)
+
+x = [synth_clip(40 + i, 20000 + 4096 * i, 2, 48000) for i in range(3)]
+for kw in (dict(log_mel=1), dict(channel_mode=1), dict(n_mels=40), dict(n_mels=128, sample_rate=44100), dict(n_fft=512), dict(n_fft=256),
+           dict(mel_scale=1, mel_norm=1)):
+    try:
+        a, b = run(x, 2, 0, 3, **dict(kw)), run(x, 2, 0, 2, **dict(kw))
+        print(kw, a.shape, "max rel diff v3 vs v2", float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)),
+              "per frame", frame_rel_err(a, np.asarray(b, np.float64)), flush=True)
+    except Exception as ex:
+        print(kw, "FAILED", ex, flush=True)
+assert worst < 1e-5
+
+if "--time" in sys.argv:
+    import torch
+    n_clips, nfr = 256, 1440000
+    dev = torch.device("cuda:0")
+    pcm = (torch.rand(n_clips, nfr, 2, device=dev) * 2 - 1) * 0.3
+    stream = torch.cuda.current_stream().cuda_stream
+    for kernel in (3, 2, 3, 2):
+        pipe = af.FeaturePipeline(sample_rate=48000, channels=2)
+        assert lib.af_features_set_option(pipe._h, b"kernel", kernel) == 0
+        tot = pipe.set_batch_uniform(n_clips, nfr)
+        mel = torch.empty(tot, 80, device=dev)
+        for _ in range(40): pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        K = 40
+        e0.record()
+        for _ in range(K): pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / K
+        b = n_clips * nfr * 8 + tot * 320
+        print(f"kernel {kernel}: {ms:.4f} ms  frac of 8 TB/s {b / ms / 1e6 / 8000:.3f}  finite {bool(torch.isfinite(mel).all())}", flush=True)
