@@ -85,7 +85,8 @@ struct UnitDesc {
     int64_t out0;        // first output row
     int32_t n_avail;     // PCM frames from pcm0 to the end of the clip (clamped to 2^30)
     int32_t n_rows;      // valid output rows (1..16)
-    int32_t flags;       // bit 0: the next unit continues this clip (its tile = this one shifted by 16 hops)
+    int32_t flags;       // bit 0: the next unit continues this clip (its tile = this one shifted by 16 hops);
+                         // bits 8..15: how many units follow in this clip (clamped to 255; features_v3 prefetches by it)
     int32_t sel;         // -1: downmix; 0 / 1: that channel alone (AF_CH_SEPARATE)
 };
 
@@ -119,9 +120,15 @@ constexpr int kTail = v2::kTail;          // 768
 constexpr int kBlk = kTile / 32;          // 152
 constexpr int kQuads = kBlk / 4;          // 38 groups of four blocks
 constexpr int kTRow = 2 * kBlk;           // bytes per row of the f16 signal image T[n2][blk] (304: 16-lane b64 stores conflict-free)
-constexpr int kYRow = 288;                // bytes per (k1 slot, frame): Yr hi | Yi hi | Yr lo' | Yi lo' (64 B each) + 32 pad
+// Y: bytes per (k1 slot, frame): Yr hi | Yi hi | Yr lo' | Yi lo' (64 B each) + 32 pad; inside a part the 16-byte piece g
+// sits at position g ^ (f >> 2).  With 288 = 18 x 16 the ds_read_b128 of stage 2 are conflict-free and the ds_write_b64
+// of stage 1 two-way (scripts/proto/lds_layout_search.py; without the swizzle the stores were four-way: 16 LDS cycles each)
+constexpr int kYRow = 288;
 constexpr int kYSlot = 16 * kYRow;        // one k1 slot: 16 frames
-constexpr int kProw = 520;                // dwords per power row (== 8 mod 64: the mel phase's ds_read_b128 pattern)
+// power rows, BIN-major: PT[bin][frame], 16 dwords per bin.  Stage 2 stores one bin of 16 frames per lane group
+// (two-way at most: free for ds_write_b32; frame-major rows of 520 dwords were eight-way), the mel phase reads its B
+// operands as ds_read_b32 (lanes (frame, kq) on bins b + kq: consecutive bins alternate between the bank halves)
+constexpr int kPBins = 520;
 constexpr int kHaloRow = 112;             // bytes per row of the f32 copy of the tile's last 768 samples [n2][24]
 // LDS map (bytes)
 constexpr int kOffY = 0;
@@ -129,10 +136,12 @@ constexpr int kOffThi = kOffY + 16 * kYSlot;                // 73 728
 constexpr int kOffTlo = kOffThi + 32 * kTRow;
 constexpr int kOffHalo = kOffTlo + 32 * kTRow;              // two buffers
 constexpr int kOffP = kOffHalo + 2 * 32 * kHaloRow;
-constexpr int kOffWmax = kOffP + 16 * kProw * 4;
+constexpr int kOffWmax = kOffP + 16 * kPBins * 4;
 constexpr int kOffMeta = kOffWmax + 64;
-constexpr int kLdsBytes = kOffMeta + kW * kMaxSlotsW * 4;
-static_assert(kLdsBytes <= 160 * 1024 && kOffThi % 16 == 0 && kOffTlo % 16 == 0 && kOffHalo % 16 == 0 && kOffP % 16 == 0,
+constexpr int kOffA2s = kOffMeta + kW * kMaxSlotsW * 4;      // the k1 = 16 matrix (one wave reads it): [2 row blocks][hi, lo'][64] uint4
+constexpr int kLdsBytes = kOffA2s + 2 * 2 * 64 * 16;
+static_assert(kLdsBytes <= 160 * 1024 && kOffThi % 16 == 0 && kOffTlo % 16 == 0 && kOffHalo % 16 == 0 && kOffP % 16 == 0 &&
+                  kOffA2s % 16 == 0,
               "LDS map");
 // fragment tables (uint4 = 8 f16 per lane): a1 [32 n2][2 row blocks][hi, lo'][64]; a2 [4 row blocks][hi, lo'][64];
 // a2s (k1 = 16, its twiddle W64^n2 folded in) [2 row blocks][hi, lo'][64]
@@ -145,12 +154,14 @@ struct Params {
     const void* pcm;
     float* out;               // mel rows [total_frames][n_mels]
     const uint4* tabs;        // a1 | a2 | a2s
-    const float* wfrag;       // the hop-256 mel plan's fragments [8][kMaxSlotsW][64][4] (f32, as features_v2)
-    const int* meta;          // [8][kMaxSlotsW]
+    const float* wfrag;       // mel plan fragments [8][kMaxSlotsW][64][4] (f32; step i of a slot covers bins bin0 + 4 i + kq)
+    const int* meta;          // [8][kMaxSlotsW]: first bin of every slot
     const v2::UnitDesc* units;
     Plan plan;
     int64_t total_units;
     int log_mel;
+    unsigned long long* stamps;   // diagnostics only: [4 waves][8] summed phase cycles, or null
+    int stamp_wave0;              // ... of waves stamp_wave0 .. stamp_wave0 + 3
 };
 // host: the three fragment tables for a window (values of the 1024-point frame, zero behind n_fft)
 void build_tables(const double* window1024, uint4* tabs);

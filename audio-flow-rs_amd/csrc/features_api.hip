@@ -32,8 +32,11 @@ struct af_features {
     DevBuf d_mono;                   // channels > 2: the downmixed batch the fused kernel reads
     DevBuf d_units;                  // v2::UnitDesc per 16-frame unit (hop 256 only)
     bool units_ok = false;
-    DevBuf d_tabs3;                  // features_v3.hip: f16-pair fragment tables of the two DFT stages (hop 256, mel output)
-    bool v3_ok = false;
+    DevBuf d_tabs3;                  // features_v3.hip: f16-pair fragment tables of the two DFT stages (hop 256, mel output),
+    bool v3_ok = false;              // then its mel plan's fragments and slot table (steps of a slot 4 bins apart)
+    Plan plan8b{};
+    const float* d_wfrag8b = nullptr;
+    const int* d_meta8b = nullptr;
     // filterbanks the banded MFMA plan does not cover (few, wide filters: 20 mels at 48 kHz ...): the kernels write
     // |X|^2 rows into d_power and dense_mel_kernel contracts them with W (two launches instead of one)
     bool dense_mel = false;
@@ -335,8 +338,8 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
         AF_TRY(p->d_power.reserve(((size_t)p->total_frames * kBins + 16) * sizeof(float)));
     // (dense_mel: the hop-256 kernel only writes power rows, which needs no filterbank plan)
     const bool v2_ok = p->plan8.n_waves == v2::kW || (p->dense_mel && p->cfg.hop == (uint32_t)v2::kHop);
-    if (v2_ok && aligned4 && p->total_units > 0 && p->total_units < (1ll << 26)) {
-        std::vector<v2::UnitDesc> units((size_t)p->total_units + 1);   // + one zero record: the kernel reads a unit ahead
+    if ((v2_ok || p->v3_ok) && aligned4 && p->total_units > 0 && p->total_units < (1ll << 26)) {
+        std::vector<v2::UnitDesc> units((size_t)p->total_units + 4);   // + zero records: the kernels read a unit ahead
         const bool sep = p->cfg.channel_mode == AF_CH_SEPARATE;
         size_t k = 0;
         for (size_t c = 0; c < n; ++c) {
@@ -350,7 +353,7 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
                 const int64_t left = t_len[c] - first;
                 d.n_avail = (int32_t)std::min<int64_t>(left, (int64_t)1 << 30);
                 d.n_rows = (int32_t)std::min<int64_t>(nf - i * kFramesPerIter, kFramesPerIter);
-                d.flags = i + 1 < nu ? 1 : 0;
+                d.flags = (i + 1 < nu ? 1 : 0) | ((int32_t)std::min<int64_t>(nu - 1 - i, 255) << 8);
                 d.sel = sep ? (int32_t)(c & 1) : -1;
             }
         }
@@ -545,17 +548,36 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
             return fail(AF_ERR_HIP, "uploading the filterbank failed");
         return AF_OK;
     };
-    // hop-256 kernel with the DFT on the matrix cores (features_v3.hip): mel output through the 8-wave banded plan
-    if (cfg->hop == (uint32_t)v2::kHop && p->plan8.n_waves == v2::kW && !p->dense_mel && cfg->output == AF_OUT_MEL) {
-        std::vector<double> win(kNfft);
-        for (int i = 0; i < kNfft; ++i) win[i] = hann(i);
-        std::vector<uint4> tabs3(v3::kTabVec);
-        v3::build_tables(win.data(), tabs3.data());
-        st = p->d_tabs3.reserve(tabs3.size() * sizeof(uint4));
-        if (st == AF_OK && hipMemcpy(p->d_tabs3.p, tabs3.data(), tabs3.size() * sizeof(uint4), hipMemcpyHostToDevice) != hipSuccess)
-            st = fail(AF_ERR_HIP, "uploading the DFT fragment tables failed");
-        if (st != AF_OK) { delete p; return st; }
-        p->v3_ok = true;
+    // hop-256 kernel with the DFT on the matrix cores (features_v3.hip): mel output through an 8-wave banded plan whose
+    // slots walk bins 4 apart per step (its power rows are bin-major)
+    if (cfg->hop == (uint32_t)v2::kHop && !p->dense_mel && cfg->output == AF_OUT_MEL) {
+        std::vector<float> wfrag8b;
+        std::vector<int> meta8b;
+        // groups of whole filter quads first (one 16-byte store per group and lane: the kernel's QUADS instances), then the
+        // finer cut
+        if (build_plan(p->W, (int)cfg->n_mels, v3::kW, 6, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
+            build_plan(p->W, (int)cfg->n_mels, v3::kW, 8, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
+            build_plan(p->W, (int)cfg->n_mels, v3::kW, 6, 2, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
+            build_plan(p->W, (int)cfg->n_mels, v3::kW, 8, 2, p->plan8b, wfrag8b, meta8b, false) != AF_OK) {
+            std::memset(&p->plan8b, 0, sizeof(p->plan8b));
+            last_error_slot().clear();
+        } else {
+            std::vector<double> win(kNfft);
+            for (int i = 0; i < kNfft; ++i) win[i] = hann(i);
+            std::vector<uint4> tabs3(v3::kTabVec);
+            v3::build_tables(win.data(), tabs3.data());
+            const size_t o_wf = tabs3.size() * sizeof(uint4), o_meta = o_wf + wfrag8b.size() * sizeof(float);
+            st = p->d_tabs3.reserve(o_meta + meta8b.size() * sizeof(int));
+            char* b3 = p->d_tabs3.as<char>();
+            if (st == AF_OK && (hipMemcpy(b3, tabs3.data(), o_wf, hipMemcpyHostToDevice) != hipSuccess ||
+                                hipMemcpy(b3 + o_wf, wfrag8b.data(), wfrag8b.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+                                hipMemcpy(b3 + o_meta, meta8b.data(), meta8b.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
+                st = fail(AF_ERR_HIP, "uploading the DFT fragment tables failed");
+            if (st != AF_OK) { delete p; return st; }
+            p->d_wfrag8b = reinterpret_cast<const float*>(b3 + o_wf);
+            p->d_meta8b = reinterpret_cast<const int*>(b3 + o_meta);
+            p->v3_ok = true;
+        }
     }
     if (p->dense_mel) st = upload_bank(p->W, kBins, p->d_W, p->d_band);
     if (st == AF_OK && cfg->n_fft != (uint32_t)kNfft) st = upload_bank(p->Wn, (int)cfg->n_fft / 2 + 1, p->d_Wn, p->d_bandn);
@@ -761,19 +783,21 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         q.pcm = pcm_dev;
         q.out = mel_dev;
         q.tabs = p->d_tabs3.as<uint4>();
-        q.wfrag = p->d_wfrag8;
-        q.meta = p->d_meta8;
+        q.wfrag = p->d_wfrag8b;
+        q.meta = p->d_meta8b;
         q.units = p->d_units.as<v2::UnitDesc>() + u_begin;
-        q.plan = p->plan8;
+        q.plan = p->plan8b;
         q.total_units = u_count;
         q.log_mel = prm.log_mel;
+        q.stamps = prm.stamps;
+        q.stamp_wave0 = (prm.stamps && std::getenv("AF_V3_STAMP_W0")) ? std::atoi(std::getenv("AF_V3_STAMP_W0")) : 0;   // diagnostics
         int64_t grid3 = (int64_t)p->n_cus;               // one 8-wave workgroup per CU (256 registers per lane, 131 KB of LDS)
         if (grid3 > u_count) grid3 = u_count;
         AF_TRY(v3::launch(q, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
                           (int)grid3, as_stream(stream)));
         return finish();
     }
-    if (hop256_ok && ksel != 1) {
+    if (hop256_ok && ksel != 1 && (p->plan8.n_waves == v2::kW || p->dense_mel)) {
         // hop 256, dword-aligned clips: the 8-wave kernel, two workgroups per CU
         v2::Params q{};
         q.pcm = pcm_dev;

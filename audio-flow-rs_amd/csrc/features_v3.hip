@@ -36,6 +36,15 @@
 //   mel       the banded f32 contraction of features_v2.hip on v_mfma_f32_16x16x4_f32 (same plan, same fragments)
 #include "features_dev.hpp"
 
+// AF_V3_ABL (diagnostic builds only, scripts/ablate/): bit mask of work compiled OUT of the kernel to see what it costs.
+// The results are then wrong; every guard that bounds a global access stays in.
+//   1 stage-1 MFMAs   2 stage-1 conversion + Y stores   4 maxima + tile update   8 stage-2 MFMAs   16 stage-2 power + P stores
+//   32 mel MFMAs   64 mel stores   128 PCM prefetch   256 mel operand reads   512 barriers 1..3   1024 the whole mel block
+//   2048 the prefetch instructions themselves   4096 the stage-1 operand reads
+#ifndef AF_V3_ABL
+#define AF_V3_ABL 0
+#endif
+
 namespace af {
 namespace feat {
 namespace v3 {
@@ -45,14 +54,18 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 using v2::UnitDesc;
 
-// ---- PCM samples: one raw load per frame, converted to mono where it is used ------------------------------------------
+// ---- PCM samples: one raw load per frame through a range-checked buffer resource (what lies behind the clip's end
+// reads as 0, no branch), converted to mono where it is used --------------------------------------------------------
 template <int CH, bool I16>
 struct Smp;
 template <>
 struct Smp<2, false> {
     typedef uint2 raw_t;
     static constexpr int kBpf = 8;
-    __device__ static __forceinline__ raw_t zero() { return uint2{0u, 0u}; }
+    __device__ static __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, int off)
+    {
+        return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    }
     __device__ static __forceinline__ float mono(raw_t r, int sel)
     {
         const float a = __uint_as_float(r.x), b = __uint_as_float(r.y);
@@ -63,14 +76,20 @@ template <>
 struct Smp<1, false> {
     typedef unsigned raw_t;
     static constexpr int kBpf = 4;
-    __device__ static __forceinline__ raw_t zero() { return 0u; }
+    __device__ static __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, int off)
+    {
+        return __builtin_bit_cast(unsigned, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    }
     __device__ static __forceinline__ float mono(raw_t r, int) { return __uint_as_float(r); }
 };
 template <>
 struct Smp<2, true> {
     typedef unsigned raw_t;
     static constexpr int kBpf = 4;
-    __device__ static __forceinline__ raw_t zero() { return 0u; }
+    __device__ static __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, int off)
+    {
+        return __builtin_bit_cast(unsigned, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    }
     __device__ static __forceinline__ float mono(raw_t r, int sel)
     {
         const float a = (float)(int16_t)(r & 0xffffu) * (1.0f / 32768.0f);
@@ -82,7 +101,10 @@ template <>
 struct Smp<1, true> {
     typedef unsigned short raw_t;
     static constexpr int kBpf = 2;
-    __device__ static __forceinline__ raw_t zero() { return 0; }
+    __device__ static __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, int off)
+    {
+        return __builtin_bit_cast(unsigned short, __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+    }
     __device__ static __forceinline__ float mono(raw_t r, int) { return (float)(int16_t)r * (1.0f / 32768.0f); }
 };
 
@@ -142,6 +164,7 @@ __device__ __forceinline__ void split4(const float (&m)[4], const Scale& sc, uin
 }
 
 typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ UnitDesc load_desc(const UnitDesc* units, unsigned u)
 {
     // through the scalar cache, as a load the compiler tracks (features_v2.hip load_desc)
@@ -161,12 +184,35 @@ __device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f3
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// stage-2 product (ablation 8: no MFMA, the operands stay alive)
+__device__ __forceinline__ f32x4 mfma16s2(const f16x8& a, const f16x8& b, const f32x4& c)
+{
+    if constexpr (AF_V3_ABL & 8) {
+        const f32x4 bb = __builtin_bit_cast(f32x4, b);
+        return f32x4{c[0] + bb[0], c[1] + bb[1], c[2] + bb[2], c[3] + bb[3]};
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+}
 __device__ __forceinline__ f16x8 lds_frag(const unsigned char* p)
 {
     return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(p));
 }
 
-template <int CH, bool I16, bool SEP, int NSLOT>
+// Diagnostics (Params::stamps != null only): per-phase cycle sums of waves 0..3.
+#define AF_STAMP3(i)                                                        \
+    do {                                                                    \
+        if constexpr (STAMPS) {                                             \
+            __builtin_amdgcn_sched_barrier(0);                              \
+            const unsigned long long _t = __builtin_amdgcn_s_memtime();     \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+            acc_t[i] += _t - t_prev;                                        \
+            t_prev = _t;                                                    \
+            __builtin_amdgcn_sched_barrier(0);                              \
+        }                                                                   \
+    } while (0)
+
+template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS, bool QUADS>
 __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
 {
     using S = Smp<CH, I16>;
@@ -179,6 +225,7 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
     float* const P = reinterpret_cast<float*>(smem + kOffP);
     unsigned* const wmax = reinterpret_cast<unsigned*>(smem + kOffWmax);
     int* const lmeta = reinterpret_cast<int*>(smem + kOffMeta);
+    unsigned char* const A2s = smem + kOffA2s;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,8 +236,9 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
     const unsigned u_end = (unsigned)(p.total_units * (bid + 1) / G);
     if (u >= u_end) return;
 
-    // ---- constant fragments, resident for the whole launch ----
-    f16x8 a1h[4][2], a1l[4][2], a2h[4], a2l[4], a2sh[2], a2sl[2];
+    // ---- constant fragments, resident for the whole launch: stage 1 (this wave's four n2), stage 2, this wave's mel slots
+    f16x8 a1h[4][2], a1l[4][2], a2h[4], a2l[4];
+    float wf[NSLOT * kSlotSteps];
     {
         const uint4* t1 = p.tabs;
 #pragma unroll
@@ -207,16 +255,19 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
             a2h[rb] = __builtin_bit_cast(f16x8, t2[(rb * 2 + 0) * 64 + lane]);
             a2l[rb] = __builtin_bit_cast(f16x8, t2[(rb * 2 + 1) * 64 + lane]);
         }
-        const uint4* t3 = p.tabs + kA1Vec + kA2Vec;
+        const float4* wbase = reinterpret_cast<const float4*>(p.wfrag) + (size_t)w * kMaxSlotsW * 64;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            a2sh[rb] = __builtin_bit_cast(f16x8, t3[(rb * 2 + 0) * 64 + lane]);
-            a2sl[rb] = __builtin_bit_cast(f16x8, t3[(rb * 2 + 1) * 64 + lane]);
+        for (int q = 0; q < NSLOT; ++q) {
+            const float4 v = wbase[lane + q * 64];
+            wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
         }
+        // the k1 = 16 matrix -> LDS (only the wave with the special item reads it)
+        const uint4* t3 = p.tabs + kA1Vec + kA2Vec;
+        if (tid < kA2sVec) reinterpret_cast<uint4*>(A2s)[tid] = t3[tid];
     }
     for (int i = tid; i < kW * kMaxSlotsW; i += kT) lmeta[i] = p.meta[i];
-    // bins 513..519 of every power row stay zero (a mel slot may reach bin 515)
-    if (tid < 16 * 7) P[(tid / 7) * kProw + 513 + tid % 7] = 0.0f;
+    // bins 513..519 stay zero (padding steps of a mel slot may touch them with zero weights)
+    if (tid < 16 * 7) P[513 * 16 + tid] = 0.0f;
     // a wait the compiler sees for the loads above (features_v2.hip: loop-invariant loads carried as "pending")
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
 #pragma unroll
@@ -226,7 +277,7 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) asm volatile("" : "+v"(a2h[rb]), "+v"(a2l[rb]));
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) asm volatile("" : "+v"(a2sh[rb]), "+v"(a2sl[rb]));
+    for (int q = 0; q < NSLOT * kSlotSteps; ++q) asm volatile("" : "+v"(wf[q]));
 
     // this wave's share of the mel plan
     int slot_end_w[NSLOT];
@@ -234,71 +285,92 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
     for (int q = 0; q < NSLOT; ++q) slot_end_w[q] = p.plan.slot_end[w][q];
     const int n_slots_w = p.plan.wave_nslots[w];
     const int n_mels = p.plan.n_mels;
-    const bool vec_ok = (n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(p.out) % 16 == 0);
-    const float* pbase = P + f * kProw + 4 * g;
+    const float* pbase = P + 16 * g + f;                 // PT[bin = kq][frame]
     const unsigned row_off = (unsigned)f * (unsigned)n_mels + 4u * (unsigned)g;
 
-    // lane constants of the tile update: sample pair p = tid + 512 r  ->  n2 = p & 31, q = p >> 5
-    const int tn2 = tid & 31, tq = tid >> 5;                       // q of r = 0; r = 1: tq + 16; r = 2 (fresh): tq + 32
+    // lane constants of the tile update: sample pair p = tid + 512 r  ->  n2 = p & 31, q = p >> 5 (r = 0; + 16 per r).
+    // Tile position of sample j of quad Q: 32 (4 Q + j) + n2.
+    const int tn2 = tid & 31, tq = tid >> 5;
+    const int lane_pos = 128 * tq + tn2;                 // position of (quad tq, j = 0)
 
-    const auto sample_pos = [&](int quad, int j) { return 32 * (4 * quad + j) + tn2; };
-    const auto load_raw = [&](int64_t frame) -> raw_t {
-        return *reinterpret_cast<const raw_t*>(static_cast<const char*>(p.pcm) + frame * S::kBpf);
+    // PCM frames [frame0, frame0 + n) as a buffer: n <= 0 gives an empty range (every load returns 0, nothing is fetched)
+    // (every component through readfirstlane: the unit record may live in vector registers, and a resource the compiler
+    // cannot prove uniform turns each load into a waterfall loop -- behind which it waits for vmcnt(0) everywhere)
+    const auto clip_rsrc = [&](int64_t frame0, int n) {
+        n = n < 0 ? 0 : n > (1 << 20) ? (1 << 20) : n;
+        const unsigned long long a = reinterpret_cast<unsigned long long>(p.pcm) + (unsigned long long)frame0 * S::kBpf;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane(n * S::kBpf), 0x00020000);
     };
+    // the new samples of tile (unit of d + k): tile positions [768, 4864) = PCM frames d.pcm0 + 4096 k + position
+    const auto issue_piece = [&](raw_t (&dst)[2][4], const UnitDesc& d, int k, bool need) {
+        const __amdgpu_buffer_rsrc_t rs = clip_rsrc(d.pcm0 + 4096 * k, (need && !(AF_V3_ABL & 128)) ? d.n_avail - 4096 * k : 0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[r][j] = S::load(rs, (lane_pos + 768 + 2048 * r + 32 * j) * S::kBpf);
+    };
+
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memtime() : 0;
 
     bool fresh = true;
     UnitDesc ud_next = load_desc(p.units, u);
     float c_cur = 1.0f;            // 16 / s of the tile in LDS
     unsigned tail_prev = 0;        // bits of max |x| over the tile's last 768 samples
     int hb = 0;                    // halo buffer that holds those samples as f32
-    raw_t pf[2][4];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pf[r][j] = S::zero();
+    // Two prefetch sets: while the piece for the next unit is consumed, the one after it stays in flight (one workgroup
+    // per CU: a unit lasts about 2 us, a loaded HBM round trip up to 4).  The loop body exists twice, once per set.
+    raw_t pf[2][2][4];
 
-    // the new samples of tile (d.unit + k): tile positions [768, 4864) = PCM frames d.pcm0 + 4096 k + position
-    const auto issue_prefetch = [&](const UnitDesc& d, int k) {
-        const int64_t f0 = d.pcm0 + 4096 * k;
-        const int n_left = d.n_avail - 4096 * k;
-        if (n_left >= kTile) {                           // wave-uniform: the piece lies inside the clip
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pf[r][j] = load_raw(f0 + sample_pos(6 + tq + 16 * r, j));
-        } else {
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int s = sample_pos(6 + tq + 16 * r, j);
-                    pf[r][j] = s < n_left ? load_raw(f0 + s) : S::zero();
-                }
-        }
-    };
-
-    while (u < u_end) {
-        const UnitDesc ud = ud_next;
-        ud_next = load_desc(p.units, u + 1);             // (the table ends with one spare record)
+    const auto unit = [&](auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
+        UnitDesc ud = ud_next;
+        ud_next = load_desc(p.units, u + 1);             // (the table ends with spare records)
+        // (a workgroup with an odd number of units runs one more pass, on a record that stores nothing: see the loop below)
+        const bool live = u < u_end;
+        if (!live) { ud.n_rows = 0; ud.n_avail = 0; ud.flags = 0; }
         const int sel = SEP ? ud.sel : -1;
-        const bool has_next = (u + 1 < u_end) && (ud.flags & 1);
+        const int run = (ud.flags >> 8) & 255;           // units that follow in this clip
+        const bool has_next = (u + 1 < u_end) && run >= 1;
+        AF_STAMP3(0);
 
         if (fresh) {
             // ---- a clip starts: the whole tile from global memory ----
             __syncthreads();                             // nobody still reads T, P, the halo or wmax
+            const __amdgpu_buffer_rsrc_t rs = clip_rsrc(ud.pcm0, ud.n_avail);
+            raw_t raw[3][4];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw[r][j] = S::load(rs, (lane_pos + 2048 * r + 32 * j) * S::kBpf);
+            // the next two pieces go out now, each into its set -- with as many (empty-range) stores between them as a unit
+            // issues, so that the first piece has the same number of younger operations behind it as in the steady state
+            issue_piece(pf[PAR], ud, 1, has_next);
+            {
+                const __amdgpu_buffer_rsrc_t nowhere = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < (QUADS ? NSLOT : 4 * NSLOT); ++q) {
+                    // (distinct offsets: identical stores would be merged into one)
+                    if constexpr (QUADS) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, nowhere, 0x7ffff000 + 16 * q, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32(0u, nowhere, 0x7ffff000 + 16 * q, 0, 0);
+                }
+            }
+            issue_piece(pf[PAR ^ 1], ud, 2, (u + 2 < u_end) && run >= 2);
             float m[3][4];
             float mx = 0.0f, mt = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int quad = tq + 16 * r;
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int s = sample_pos(quad, j);
-                    m[r][j] = (quad < kQuads && s < ud.n_avail) ? S::mono(load_raw(ud.pcm0 + s), sel) : 0.0f;
+                    // (r = 2: quads 32..37 exist for tq < 6 only; the others read past the tile and are not used)
+                    m[r][j] = S::mono(raw[r][j], sel);
+                    if (r == 2 && tq >= kQuads - 32) m[r][j] = 0.0f;
                     mx = fmaxf(mx, fabsf(m[r][j]));
-                    if (r == 2) mt = fmaxf(mt, fabsf(m[r][j]));            // quads 32..37: the last 768 samples
+                    if (r == 2) mt = fmaxf(mt, fabsf(m[r][j]));            // the last 768 samples
                 }
-            }
             const unsigned wm = wave_max_bits(mx), wt = wave_max_bits(mt);
             if (lane == 0) { wmax[2 * w] = wm; wmax[2 * w + 1] = wt; }
             __syncthreads();
@@ -325,13 +397,30 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
                             float4{m[r][0], m[r][1], m[r][2], m[r][3]};
                 }
             }
-            if (has_next) issue_prefetch(ud, 1);
             __syncthreads();                             // T ready
         }
+        AF_STAMP3(1);
 
+        // ---- the prefetched piece (set PAR): mono samples and their maxima, published before barrier 1 ----
+        float mn[2][4];
+        if (has_next && !(AF_V3_ABL & 4)) {
+            float mx = 0.0f, mt = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mn[r][j] = S::mono(pf[PAR][r][j], sel);
+                    mx = fmaxf(mx, fabsf(mn[r][j]));
+                    if (r == 1) mt = fmaxf(mt, fabsf(mn[r][j]));
+                }
+            const unsigned wm = wave_max_bits(mx);
+            // quads 32..37 (the next tile's last 768 samples) are r = 1 of threads 320..511 = waves 5..7
+            const unsigned wt = w >= 5 ? wave_max_bits(mt) : 0u;
+            if (lane == 0) { wmax[2 * w] = wm; wmax[2 * w + 1] = wt; }
+        }
         // ---- stage 1: this wave's four n2 ----
-        f32x4 y[4][2];
         {
+            f32x4 y[4][2];
             const int bro = 16 * (f + g);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -341,15 +430,30 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) {
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 p1 = mfma16(a1h[t][rb], bh, z);
-                    f32x4 p2 = mfma16(a1h[t][rb], bl, z);
-                    p2 = mfma16(a1l[t][rb], bh, p2);
+                    f32x4 p1, p2;
+                    if constexpr (!(AF_V3_ABL & 1)) {
+                        p1 = mfma16(a1h[t][rb], bh, z);
+                        p2 = mfma16(a1h[t][rb], bl, z);
+                        p2 = mfma16(a1l[t][rb], bh, p2);
+                    } else {
+                        p1 = __builtin_bit_cast(f32x4, __builtin_bit_cast(uint4, bh)) ;
+                        p2 = __builtin_bit_cast(f32x4, __builtin_bit_cast(uint4, bl));
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) y[t][rb][i] = __builtin_fmaf(p2[i], 1.0f / 2048.0f, p1[i]);
                 }
             }
             // -> f16 pairs -> Y[k1 = 4g + i][f][row block rb: Yr | Yi][hi | lo'][n2 = 4w .. 4w+3]
-            unsigned char* yw = Ybase + (4 * g) * kYSlot + f * kYRow + 8 * w;
+            if constexpr (AF_V3_ABL & 2) {
+                float sink = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) sink += y[t][rb][0] + y[t][rb][1] + y[t][rb][2] + y[t][rb][3];
+                if (sink == 1.2345e-30f) wmax[lane] = 1u;
+            } else {
+            // (the 16-byte piece n2 / 8 = w >> 1 of a part sits at position (w >> 1) ^ (f >> 2))
+            unsigned char* yw = Ybase + (4 * g) * kYSlot + f * kYRow + 16 * ((w >> 1) ^ (f >> 2)) + 8 * (w & 1);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -368,36 +472,113 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
                     *reinterpret_cast<uint2*>(yw + i * kYSlot + rb * 64) = uint2{h[0], h[1]};
                     *reinterpret_cast<uint2*>(yw + i * kYSlot + rb * 64 + 128) = uint2{l[0], l[1]};
                 }
+            }
         }
+        AF_STAMP3(2);
 
-        // ---- the prefetched piece: mono samples and their maxima, published before barrier 1 ----
-        float mn[2][4];
-        if (has_next) {
-            float mx = 0.0f, mt = 0.0f;
+        AF_STAMP3(3);
+        if constexpr (!(AF_V3_ABL & 512)) __syncthreads();   // B1: Y ready, maxima published, T free
+        AF_STAMP3(4);
+
+        AF_STAMP3(5);
+
+        // ---- stage 2: two k1 per wave -> power rows ----
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+        for (int it = 0; it < 2; ++it) {
+            const int slot = (2 * w + 1 + it) & 15;      // k1; 0: the special item (k1 = 0 and k1 = 16)
+            const unsigned char* yb = Ybase + slot * kYSlot + f * kYRow + 16 * (g ^ (f >> 2));
+            const f16x8 yrh = lds_frag(yb), yih = lds_frag(yb + 64), yrl = lds_frag(yb + 128), yil = lds_frag(yb + 192);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            // row 4g + i of row block rb is k2 = 8 rb + 4 (g >> 1) + (g & 1) + 2 (i >> 1), cos (i even) or -sin (i odd):
+            // the two lane groups of a 32-lane store half differ in the parity of k2, i.e. by 32 banks
+            const int k2g = 4 * (g >> 1) + (g & 1);
+            float* prow = P + f;                         // PT[bin][f]: bin b is prow[16 b]
+            if (slot != 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    mn[r][j] = S::mono(pf[r][j], sel);
-                    mx = fmaxf(mx, fabsf(mn[r][j]));
-                    if (r == 1) mt = fmaxf(mt, fabsf(mn[r][j]));
+                for (int rb = 0; rb < 4; ++rb) {
+                    const f32x4 a0p1 = mfma16s2(a2h[rb], yrh, z);
+                    const f32x4 a1p1 = mfma16s2(a2h[rb], yih, z);
+                    f32x4 a0p2 = mfma16s2(a2h[rb], yrl, z);
+                    f32x4 a1p2 = mfma16s2(a2h[rb], yil, z);
+                    a0p2 = mfma16s2(a2l[rb], yrh, a0p2);
+                    a1p2 = mfma16s2(a2l[rb], yih, a1p2);
+                    float pw[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float re = __builtin_fmaf(a0p2[2 * h] - a1p2[2 * h + 1], 1.0f / 2048.0f, a0p1[2 * h] - a1p1[2 * h + 1]);
+                        const float im = __builtin_fmaf(a1p2[2 * h] + a0p2[2 * h + 1], 1.0f / 2048.0f, a1p1[2 * h] + a0p1[2 * h + 1]);
+                        pw[h] = __builtin_fmaf(re, re, im * im);
+                    }
+                    const int k2 = 8 * rb + k2g;         // and k2 + 2
+                    if (rb < 2) {
+                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (slot + 32 * k2)] = pw[0];
+                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (slot + 32 * k2 + 64)] = pw[1];
+                    } else {                             // bin 1024 - k
+                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (1024 - slot - 32 * k2)] = pw[0];
+                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (1024 - slot - 32 * k2 - 64)] = pw[1];
+                    }
                 }
-            const unsigned wm = wave_max_bits(mx);
-            // quads 32..37 (the next tile's last 768 samples) are r = 1 of threads 320..511 = waves 5..7
-            const unsigned wt = w >= 5 ? wave_max_bits(mt) : 0u;
-            if (lane == 0) { wmax[2 * w] = wm; wmax[2 * w + 1] = wt; }
+            } else {
+                // k1 = 0: X[32 k2] = A2 Y0 (real input), k2 = 0..16
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) {
+                    const f32x4 p1 = mfma16s2(a2h[rb], yrh, z);
+                    f32x4 p2 = mfma16s2(a2h[rb], yrl, z);
+                    p2 = mfma16s2(a2l[rb], yrh, p2);
+                    float pw[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float re = __builtin_fmaf(p2[2 * h], 1.0f / 2048.0f, p1[2 * h]);
+                        const float im = __builtin_fmaf(p2[2 * h + 1], 1.0f / 2048.0f, p1[2 * h + 1]);
+                        pw[h] = __builtin_fmaf(re, re, im * im);
+                    }
+                    const int k2 = 8 * rb + k2g;
+                    if (rb < 2) {
+                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (32 * k2)] = pw[0];
+                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (32 * k2 + 64)] = pw[1];
+                    } else if (g == 0) {
+                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * 512] = pw[0];          // k2 = 16: bin 512
+                    }
+                }
+                // k1 = 16: X[16 + 32 k2] = A2s Y16, k2 = 0..15 (the matrix comes from LDS: one wave uses it)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const f16x8 sh = lds_frag(A2s + ((rb * 2 + 0) * 64 + lane) * 16);
+                    const f16x8 sl = lds_frag(A2s + ((rb * 2 + 1) * 64 + lane) * 16);
+                    const f32x4 p1 = mfma16s2(sh, yih, z);
+                    f32x4 p2 = mfma16s2(sh, yil, z);
+                    p2 = mfma16s2(sl, yih, p2);
+                    float pw[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float re = __builtin_fmaf(p2[2 * h], 1.0f / 2048.0f, p1[2 * h]);
+                        const float im = __builtin_fmaf(p2[2 * h + 1], 1.0f / 2048.0f, p1[2 * h + 1]);
+                        pw[h] = __builtin_fmaf(re, re, im * im);
+                    }
+                    const int k2 = 8 * rb + k2g;
+                    if constexpr (!(AF_V3_ABL & 16)) prow[16 * (16 + 32 * k2)] = pw[0];
+                    if constexpr (!(AF_V3_ABL & 16)) prow[16 * (16 + 32 * k2 + 64)] = pw[1];
+                }
+            }
         }
-        __syncthreads();                                 // B1: Y ready, maxima published, T free
+        AF_STAMP3(6);
+        if constexpr (!(AF_V3_ABL & 512)) __syncthreads();   // B2: power rows ready; Y free
+        AF_STAMP3(4);
 
+        // ---- mel: banded W (A, registers) x P^T (B, bins x 16 frames) on v_mfma_f32_16x16x4_f32 (features_v2.hip), with the
+        // tile update for the next unit (vector work) beside its f32 MFMAs ----
         float c_next = c_cur;
         unsigned tail_next = tail_prev;
-        if (has_next) {
+        if (has_next && !(AF_V3_ABL & 4)) {
             // ---- tile update: the next unit's tile = the last 768 samples (f32 copy in the halo buffer) + the new piece ----
             unsigned mall = tail_prev, mtl = 0;
 #pragma unroll
-            for (int ww = 0; ww < kW; ++ww) {
-                mall = wmax[2 * ww] > mall ? wmax[2 * ww] : mall;
-                mtl = wmax[2 * ww + 1] > mtl ? wmax[2 * ww + 1] : mtl;
+            for (int ww = 0; ww < kW; ww += 2) {
+                const uint4 v = reinterpret_cast<const uint4*>(wmax)[ww / 2];
+                mall = v.x > mall ? v.x : mall;
+                mall = v.z > mall ? v.z : mall;
+                mtl = v.y > mtl ? v.y : mtl;
+                mtl = v.w > mtl ? v.w : mtl;
             }
             const Scale sc = make_scale(mall);
             c_next = sc.c;
@@ -421,153 +602,103 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
                     *reinterpret_cast<float4*>(Halo + (hb ^ 1) * (32 * kHaloRow) + tn2 * kHaloRow + (quad - 32) * 16) =
                         float4{mn[r][0], mn[r][1], mn[r][2], mn[r][3]};
             }
-            // the piece after that, one unit ahead
-            if ((u + 2 < u_end) && (ud_next.flags & 1)) issue_prefetch(ud, 2);
         }
-
-        // ---- stage 2: two k1 per wave -> power rows ----
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int slot = (2 * w + 1 + it) & 15;      // k1; 0: the special item (k1 = 0 and k1 = 16)
-            const unsigned char* yb = Ybase + slot * kYSlot + f * kYRow + 16 * g;
-            const f16x8 yrh = lds_frag(yb), yih = lds_frag(yb + 64), yrl = lds_frag(yb + 128), yil = lds_frag(yb + 192);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            // row 4g + i of row block rb is k2 = 8 rb + 4 (g >> 1) + (g & 1) + 2 (i >> 1), cos (i even) or -sin (i odd):
-            // the two lane groups of a 32-lane store half differ in the parity of k2, i.e. by 32 banks
-            const int k2g = 4 * (g >> 1) + (g & 1);
-            float* prow = P + f * kProw;
-            if (slot != 0) {
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    const f32x4 a0p1 = mfma16(a2h[rb], yrh, z);
-                    const f32x4 a1p1 = mfma16(a2h[rb], yih, z);
-                    f32x4 a0p2 = mfma16(a2h[rb], yrl, z);
-                    f32x4 a1p2 = mfma16(a2h[rb], yil, z);
-                    a0p2 = mfma16(a2l[rb], yrh, a0p2);
-                    a1p2 = mfma16(a2l[rb], yih, a1p2);
-                    float pw[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float re = __builtin_fmaf(a0p2[2 * h] - a1p2[2 * h + 1], 1.0f / 2048.0f, a0p1[2 * h] - a1p1[2 * h + 1]);
-                        const float im = __builtin_fmaf(a1p2[2 * h] + a0p2[2 * h + 1], 1.0f / 2048.0f, a1p1[2 * h] + a0p1[2 * h + 1]);
-                        pw[h] = __builtin_fmaf(re, re, im * im);
-                    }
-                    const int k2 = 8 * rb + k2g;         // and k2 + 2
-                    if (rb < 2) {
-                        prow[slot + 32 * k2] = pw[0];
-                        prow[slot + 32 * k2 + 64] = pw[1];
-                    } else {                             // bin 1024 - k
-                        prow[1024 - slot - 32 * k2] = pw[0];
-                        prow[1024 - slot - 32 * k2 - 64] = pw[1];
-                    }
-                }
-            } else {
-                // k1 = 0: X[32 k2] = A2 Y0 (real input), k2 = 0..16
-#pragma unroll
-                for (int rb = 0; rb < 3; ++rb) {
-                    const f32x4 p1 = mfma16(a2h[rb], yrh, z);
-                    f32x4 p2 = mfma16(a2h[rb], yrl, z);
-                    p2 = mfma16(a2l[rb], yrh, p2);
-                    float pw[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float re = __builtin_fmaf(p2[2 * h], 1.0f / 2048.0f, p1[2 * h]);
-                        const float im = __builtin_fmaf(p2[2 * h + 1], 1.0f / 2048.0f, p1[2 * h + 1]);
-                        pw[h] = __builtin_fmaf(re, re, im * im);
-                    }
-                    const int k2 = 8 * rb + k2g;
-                    if (rb < 2) {
-                        prow[32 * k2] = pw[0];
-                        prow[32 * k2 + 64] = pw[1];
-                    } else if (g == 0) {
-                        prow[512] = pw[0];               // k2 = 16: bin 512
-                    }
-                }
-                // k1 = 16: X[16 + 32 k2] = A2s Y16, k2 = 0..15
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const f32x4 p1 = mfma16(a2sh[rb], yih, z);
-                    f32x4 p2 = mfma16(a2sh[rb], yil, z);
-                    p2 = mfma16(a2sl[rb], yih, p2);
-                    float pw[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float re = __builtin_fmaf(p2[2 * h], 1.0f / 2048.0f, p1[2 * h]);
-                        const float im = __builtin_fmaf(p2[2 * h + 1], 1.0f / 2048.0f, p1[2 * h + 1]);
-                        pw[h] = __builtin_fmaf(re, re, im * im);
-                    }
-                    const int k2 = 8 * rb + k2g;
-                    prow[16 + 32 * k2] = pw[0];
-                    prow[16 + 32 * k2 + 64] = pw[1];
-                }
-            }
-        }
-        __syncthreads();                                 // B2: power rows ready; next tile ready; Y free
-
-        // ---- mel: banded W (A, registers) x P^T (B, bins x 16 frames) on v_mfma_f32_16x16x4_f32 (features_v2.hip) ----
-        {
-            float wf[NSLOT * kSlotSteps], bop[NSLOT * kSlotSteps];
-            const float4* wbase = reinterpret_cast<const float4*>(p.wfrag) + (size_t)w * kMaxSlotsW * 64;
+        if constexpr (!(AF_V3_ABL & 1024)) {
+            float bop[NSLOT * kSlotSteps];
             const int* lm = lmeta + w * kMaxSlotsW;
 #pragma unroll
             for (int q = 0; q < NSLOT; ++q) {
-                const float4 v = wbase[lane + q * 64];
-                wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
-                const float4 bv = *reinterpret_cast<const float4*>(pbase + lm[q]);
-                bop[4 * q] = bv.x; bop[4 * q + 1] = bv.y; bop[4 * q + 2] = bv.z; bop[4 * q + 3] = bv.w;
+                const float* bq = pbase + 16 * lm[q];    // step i of the slot: bins bin0 + 4 i + kq
+#pragma unroll
+                for (int i = 0; i < kSlotSteps; ++i) bop[4 * q + i] = (AF_V3_ABL & 256) ? (float)(lane + i + q) : bq[64 * i];
             }
-            float* obase = p.out + ud.out0 * n_mels;     // wave-uniform
-            const bool fvalid = f < ud.n_rows;
+            // The rows of this unit as a buffer: rows behind n_rows are out of range, what must not be written gets an
+            // out-of-range offset -- every wave issues exactly NSLOT (QUADS) or 4 NSLOT store instructions per unit, no branch
+            // around any of them.  The count matters: vector memory operations retire in order, the wait for a prefetched
+            // piece is "all but the youngest N", and with a count the compiler cannot see it waited for the stores issued
+            // just before -- a full store round trip in every unit (-0.2 ms when the stores were compiled out).
+            const int rows_bytes = __builtin_amdgcn_readfirstlane(ud.n_rows * n_mels * 4);
+            const unsigned long long oa = reinterpret_cast<unsigned long long>(p.out) + (unsigned long long)(ud.out0 * n_mels) * 4ull;
+            const unsigned olo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)oa);
+            const unsigned ohi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(oa >> 32));
+            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void*>(((unsigned long long)ohi << 32) | olo), 0, (AF_V3_ABL & 64) ? 0 : rows_bytes, 0x00020000);
             const int i0 = 4 * g;
-            const float c2 = c_cur * c_cur;              // in range: c in [2^-122, 2^118] only for absurd inputs
+            constexpr unsigned kOob = 0x7fffffffu;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < NSLOT; ++q) {
+                // (slots this wave does not use are skipped -- a wave-uniform branch without any memory operation inside;
+                // the stores below stay unconditional)
                 if (q < n_slots_w) {
 #pragma unroll
                     for (int st = q * kSlotSteps; st < (q + 1) * kSlotSteps; st += 2) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], bop[st], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st + 1], bop[st + 1], acc1, 0, 0, 0);
-                    }
-                    const int e = slot_end_w[q];         // wave-uniform (kernarg)
-                    if (e != 0) {
-                        f32x4 r = acc0 + acc1;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) r[i] = (r[i] * c_cur) * c_cur;      // the tile's scale leaves here
-                        (void)c2;
-                        if (p.log_mel) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) r[i] = __log10f(fmaxf(r[i], 1e-10f));
-                        }
-                        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-                        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                        const int mm = e & 255, cnt = (e >> 8) & 31;
-                        float* o = obase + mm + row_off;
-                        if (vec_ok && ((cnt | mm) & 3) == 0) {
-                            if (fvalid && i0 < cnt) *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
-                        } else if (fvalid) {
-                            if (i0 < cnt) o[0] = r[0];
-                            if (i0 + 1 < cnt) o[1] = r[1];
-                            if (i0 + 2 < cnt) o[2] = r[2];
-                            if (i0 + 3 < cnt) o[3] = r[3];
+                        if constexpr (!(AF_V3_ABL & 32)) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], bop[st], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st + 1], bop[st + 1], acc1, 0, 0, 0);
+                        } else {
+                            acc0[0] += wf[st] * bop[st];
+                            acc1[0] += wf[st + 1] * bop[st + 1];
                         }
                     }
                 }
+                const int e = slot_end_w[q];             // wave-uniform (kernarg); 0: the group continues
+                const bool end = e != 0;
+                const int mm = e & 255, cnt = (e >> 8) & 31;
+                f32x4 r = acc0 + acc1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = (r[i] * c_cur) * c_cur;          // the tile's scale leaves here
+                if (p.log_mel) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = __log10f(fmaxf(r[i], 1e-10f));
+                }
+                const unsigned off = (row_off + (unsigned)mm) * 4u;
+                if constexpr (QUADS) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), ors, (int)((end && i0 < cnt) ? off : kOob), 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r[i]), ors, (int)((end && i0 + i < cnt) ? off + 4u * i : kOob), 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0[i] = end ? 0.0f : acc0[i];
+                    acc1[i] = end ? 0.0f : acc1[i];
+                }
             }
         }
+        // ---- the piece three units ahead goes into the set just consumed: the LAST vector memory operations of the
+        // iteration and unconditional (an empty range when there is nothing to fetch), so that "all but the youngest 8"
+        // is what the next consumer has to wait for on every path ----
+        if constexpr (!(AF_V3_ABL & 2048)) issue_piece(pf[PAR], ud, 3, has_next && (u + 3 < u_end) && run >= 3);
+        AF_STAMP3(7);
+        if (has_next && !(AF_V3_ABL & 512)) __syncthreads();   // B3: the next tile is ready (a clip start brings its own barriers)
+        AF_STAMP3(4);
 
         c_cur = c_next;
         tail_prev = tail_next;
         if (has_next) hb ^= 1;
         fresh = !has_next;
         ++u;
+    };
+
+    // Two passes per trip, no exit between them: a `break` in the middle leaves a (never taken) edge in the control-flow
+    // graph on which the set issued at the end of the first pass is the youngest thing in flight when that pass starts
+    // again, and the compiler then waits for vmcnt(0) at every consumption.  An odd unit count is padded with one dead pass.
+    while (u < u_end) {
+        unit(std::integral_constant<int, 0>{});
+        unit(std::integral_constant<int, 1>{});
+    }
+    if constexpr (STAMPS) {
+        if (lane == 0 && w >= p.stamp_wave0 && w < p.stamp_wave0 + 4)
+            for (int i = 0; i < 8; ++i) atomicAdd(p.stamps + (w - p.stamp_wave0) * 8 + i, acc_t[i]);
     }
 }
 
-template <int CH, bool I16, bool SEP, int NSLOT>
+template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS, bool QUADS>
 static af_status launch_k(const Params& p, int grid, hipStream_t stream)
 {
-    auto kern = af_features_v3_kernel<CH, I16, SEP, NSLOT>;
+    auto kern = af_features_v3_kernel<CH, I16, SEP, NSLOT, STAMPS, QUADS>;
     static LdsAttrFlags attr_set;
     AF_HIP(allow_big_lds(kern, kLdsBytes, attr_set));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kT), kLdsBytes, stream, p);
@@ -579,13 +710,26 @@ template <int CH, bool I16>
 static af_status launch_fmt(const Params& p, bool separate, int grid, hipStream_t stream)
 {
     int most = 0;
-    for (int w = 0; w < kW; ++w) most = p.plan.wave_nslots[w] > most ? p.plan.wave_nslots[w] : most;
+    // QUADS: every group of the plan starts and ends on a multiple of four filters and the rows are 16-byte aligned:
+    // one 16-byte store per slot (16-byte buffer stores need 16-byte-aligned addresses); otherwise four 4-byte stores
+    bool quads = p.plan.n_mels % 4 == 0 && reinterpret_cast<uintptr_t>(p.out) % 16 == 0;
+    for (int w = 0; w < kW; ++w) {
+        most = p.plan.wave_nslots[w] > most ? p.plan.wave_nslots[w] : most;
+        for (int q = 0; q < kMaxSlotsW; ++q) {
+            const int e = p.plan.slot_end[w][q];
+            if (e != 0 && (((e & 255) | ((e >> 8) & 31)) & 3) != 0) quads = false;
+        }
+    }
     if (most > 8) return fail(AF_ERR_UNSUPPORTED, "features v3: %d mel slots on one wave (limit 8)", most);
     if constexpr (CH == 2) {
-        if (separate) return launch_k<CH, I16, true, 8>(p, grid, stream);
+        if (separate) return quads ? launch_k<CH, I16, true, 8, false, true>(p, grid, stream) : launch_k<CH, I16, true, 8, false, false>(p, grid, stream);
     }
-    if (most <= 6) return launch_k<CH, I16, false, 6>(p, grid, stream);
-    return launch_k<CH, I16, false, 8>(p, grid, stream);
+    if constexpr (CH == 2 && !I16) {
+        if (p.stamps && quads) return launch_k<CH, I16, false, 8, true, true>(p, grid, stream);
+    }
+    if (!quads) return launch_k<CH, I16, false, 8, false, false>(p, grid, stream);
+    if (most <= 6) return launch_k<CH, I16, false, 6, false, true>(p, grid, stream);
+    return launch_k<CH, I16, false, 8, false, true>(p, grid, stream);
 }
 
 af_status launch(const Params& p, int channels, bool i16, bool separate, int grid, hipStream_t stream)

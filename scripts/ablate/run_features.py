@@ -11,6 +11,7 @@ ffi = importlib.util.module_from_spec(spec); spec.loader.exec_module(ffi)
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20); ap.add_argument("--warm", type=int, default=30)
 ap.add_argument("--clips", type=int, default=256); ap.add_argument("libs", nargs="+")
+ap.add_argument("--kernel", type=int, default=-1, help="af_features_set_option kernel (1 general, 2 features_v2, 3 features_v3)")
 a = ap.parse_args()
 n = 1440000
 dev = torch.device("cuda:0")
@@ -20,10 +21,11 @@ for path in a.libs:
     # RTLD_LOCAL: every build resolves its own symbols (RTLD_GLOBAL would bind later builds to the first one's)
     lib = C.CDLL(os.path.abspath(path), mode=os.RTLD_LOCAL | os.RTLD_NOW)
     for name in ("af_features_default_config", "af_features_create", "af_features_set_batch_uniform",
-                 "af_features_run_device", "af_features_destroy", "af_last_error"):
+                 "af_features_run_device", "af_features_destroy", "af_last_error", "af_features_set_option"):
         fn = getattr(lib, name); fn.restype, fn.argtypes = ffi.SIGNATURES[name]
     cfg = ffi.FeaturesConfig(); lib.af_features_default_config(C.byref(cfg))
     h = C.c_void_p(); assert lib.af_features_create(C.byref(cfg), C.byref(h)) == 0
+    if a.kernel >= 0: assert lib.af_features_set_option(h, b"kernel", a.kernel) == 0
     tot = C.c_size_t(); assert lib.af_features_set_batch_uniform(h, a.clips, n, C.byref(tot)) == 0
     mel = torch.empty(tot.value, 80, device=dev)
     for _ in range(a.warm): assert lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), s) == 0

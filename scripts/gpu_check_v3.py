@@ -101,3 +101,18 @@ if "--time" in sys.argv:
         ms = e0.elapsed_time(e1) / K
         b = n_clips * nfr * 8 + tot * 320
         print(f"kernel {kernel}: {ms:.4f} ms  frac of 8 TB/s {b / ms / 1e6 / 8000:.3f}  finite {bool(torch.isfinite(mel).all())}", flush=True)
+    # in-kernel phase stamps of the matrix-core kernel (waves 0..3)
+    lib.af_features_debug_stamps.restype = C.c_int32; lib.af_features_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    pipe = af.FeaturePipeline(sample_rate=48000, channels=2)
+    assert lib.af_features_set_option(pipe._h, b"kernel", 3) == 0
+    tot = pipe.set_batch_uniform(n_clips, nfr)
+    assert lib.af_features_debug_stamps(pipe._h, 1, None) == 0
+    for _ in range(3): pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+    torch.cuda.synchronize()
+    out = np.zeros(32, np.uint64)
+    assert lib.af_features_debug_stamps(pipe._h, 0, out.ctypes.data) == 0
+    per = out.reshape(4, 8).astype(np.float64) / (3 * tot / 16)
+    names = ["desc", "fresh", "stage 1", "publish max", "barrier waits", "tile update", "stage 2", "mel + issue"]
+    print("cycles per unit, waves 0..3:")
+    for i, nm in enumerate(names): print(f"  {nm:15s}", " ".join(f"{per[w, i]:8.0f}" for w in range(4)))
+    print("  total          ", " ".join(f"{per[w].sum():8.0f}" for w in range(4)))

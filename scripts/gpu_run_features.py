@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("ffi", os.path.join(ROOT, "audio-flow-rs_amd", "_ffi.py"))
 ffi = importlib.util.module_from_spec(spec); spec.loader.exec_module(ffi)
 lib = ffi.load(os.environ.get("AF_LIB"))
+if os.environ.get("AF_KERNEL"):        # 1: general kernel, 2: features_v2, 3: features_v3 (af_debug_set "features.kernel")
+    lib.af_debug_set.argtypes = [C.c_char_p, C.c_int]; lib.af_debug_set(b"features.kernel", int(os.environ["AF_KERNEL"]))
 n_clips = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 n = 1440000
