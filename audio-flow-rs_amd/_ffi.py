@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaudioflow_dsp.so")
+# AF_LIB: another build of the SAME library (sanitizer / ablation builds of scripts/); the product is the in-tree file
+LIB_PATH = os.environ.get("AF_LIB") or os.path.join(_HERE, "libaudioflow_dsp.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 AF_OK = 0
@@ -195,6 +196,7 @@ SIGNATURES = {
     "af_chain_stream_rows_per_step": (_sz, [_vp]),
     "af_chain_stream_row_len": (_sz, [_vp]),
     "af_chain_stream_total_rows": (_sz, [_vp, C.c_uint64]),
+    "af_chain_stream_flush_rows": (_sz, [_vp]),
     "af_chain_stream_max_rows": (_sz, [_vp, _sz]),
     "af_chain_stream_push": (_st, [_vp, _vp, _sz, _vp, _sz, _szp]),
     "af_chain_stream_flush": (_st, [_vp, _vp, _sz, _szp]),

@@ -836,7 +836,8 @@ class ChainStream:
         return rows[:n.value]
 
     def flush(self) -> np.ndarray:
-        rows = np.empty((self.rows_per_step, self.row_len), np.float32)
+        # (the flush can owe one row more than a step when the resampler's look-ahead spans a hop)
+        rows = np.empty((max(int(self._lib.af_chain_stream_flush_rows(self._h)), 1), self.row_len), np.float32)
         n = C.c_size_t()
         _check(self._lib.af_chain_stream_flush(self._h, _ptr(rows), rows.size, C.byref(n)))
         return rows[:n.value].copy()

@@ -113,6 +113,8 @@ struct DevBuf {
 
 // features_api.hip: the feature kernel on the units of clips [clip_begin, clip_end) of the handle's batch (rows land at
 // their places in mel_dev), with wg_per_cu workgroups per CU (1 | 2) -- the chain's pipelined form
+// whether the handle's batches run as ONE launch of a fused kernel (no dense filterbank contraction, no to_mono pass)
+bool features_one_launch(const af_features* p);
 af_status features_run_clips(af_features* p, const void* pcm_dev, float* mel_dev, hipStream_t stream, size_t clip_begin,
                              size_t clip_end, int wg_per_cu);
 

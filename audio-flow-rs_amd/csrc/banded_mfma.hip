@@ -821,12 +821,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float pf[kRegs];
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[kPfSlots];
+    uint32_t x_frames = 0;           // FMT 3: frames of the clip whose tile is staged next (see staged_pair)
     auto prep_tile = [&](uint32_t tile, bool live) {
         const TileCtx c = tile_ctx(tile);
         // x index of the first staged sample of the tile: q(y0) + lo_off - shift, y0 = t z_per_tile - H2,
         // relative to the buffer's first frame
         const int64_t base = (c.t_abs * (int64_t)(16 * g.P2) - g.H2 / 16) * g.S + g.lo_off - g.shift - g.x_abs0;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.xp), 0, (int)c.x_bytes, 0x00020000);
+        // mono i16 is staged as one dword per frame pair and the range check works per dword: for an odd frame count
+        // the last dword (frames n - 1 and n) would be read or dropped whole.  The range is rounded up to whole dwords
+        // (the extra 2 bytes share an aligned dword with the clip's last sample) and staged_pair zeroes the half that
+        // lies behind the clip.
+        if constexpr (FMT == 3) x_frames = c.x_bytes >> 1;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.xp), 0, (int)(FMT == 3 ? (c.x_bytes + 2u) & ~3u : c.x_bytes),
+                                                 0x00020000);
         if constexpr (PAIR) {
             const uint32_t v0 = ((uint32_t)base + 2u * (uint32_t)(tid + opaque_zero())) * (uint32_t)BPF;
             voff[0] = live && first ? v0 : kOob;
@@ -870,7 +877,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             m1 = (lo16(pf[cc * 2 + 1]) + hi16(pf[cc * 2 + 1])) * 0.5f;
         } else {
             m0 = lo16(pf[cc]);
-            m1 = hi16(pf[cc]);
+            // byte offset of the pair's second sample, with the wrap-around of the load's own offset arithmetic (a
+            // column of a segment that starts before the clip can lie inside it; an offset before the clip is huge)
+            const uint32_t b1 = voff[0] + (uint32_t)(cc * col_span) * 2u + 2u;
+            m1 = b1 < 2u * x_frames ? hi16(pf[cc]) : 0.0f;
         }
     };
 

@@ -252,7 +252,9 @@ af_status strip_run(af_chain* c, const void* pcm_dev, hipStream_t s, const float
 // after the other, and with the feature kernel's waves at a higher issue priority 1.21-1.24.  Kept as an option only.
 int pipeline_chunks(const af_chain* c)
 {
-    if (c->ragged || c->opt_pipeline == 0) return 0;
+    // (the pipelined form runs the feature kernel clip range by clip range: one-launch feature configurations only --
+    // filterbanks on the dense fallback take two launches over whole batches)
+    if (c->ragged || c->opt_pipeline == 0 || !features_one_launch(c->feat)) return 0;
     if (c->opt_pipeline > 0) return (int)std::min<size_t>((size_t)c->opt_pipeline, c->n_clips);
     return 0;                                                       // (see MEASURED above)
 }
@@ -278,9 +280,13 @@ af_status run_pipelined(af_chain* c, const void* pcm_dev, float* mel_dev, hipStr
     AF_HIP(hipStreamWaitEvent(c->s_a, c->ev_fork, 0));
     AF_HIP(hipStreamWaitEvent(c->s_b, c->ev_fork, 0));
     const size_t n = c->n_clips;
-    for (int k = 0; k < chunks; ++k) {
+    // The caller's stream has been forked: whatever happens below, it is joined again before this returns (work the
+    // caller enqueues next must stay ordered behind both side streams, and a stream capture in progress must see the
+    // fork closed) -- the first error is kept and returned after the join.
+    af_status st = AF_OK;
+    const auto chunk = [&](int k) -> af_status {
         const size_t c0 = n * (size_t)k / (size_t)chunks, c1 = n * (size_t)(k + 1) / (size_t)chunks;
-        if (c1 == c0) continue;
+        if (c1 == c0) return AF_OK;
         banded::FusedArgs q;
         q.x = static_cast<const char*>(pcm_dev) + c0 * c->n_in * c->bpf;
         q.z = c->d_fir.as<float>() + c0 * c->n_res;
@@ -291,17 +297,25 @@ af_status run_pipelined(af_chain* c, const void* pcm_dev, float* mel_dev, hipStr
         AF_TRY(banded::launch_fused(c->fused, c->afrag_res, c->d_afrag_fir.as<float>(), q, c->s_a));
         AF_HIP(hipEventRecord(c->ev_chunk[k], c->s_a));
         AF_HIP(hipStreamWaitEvent(c->s_b, c->ev_chunk[k], 0));
-        AF_TRY(features_run_clips(c->feat, c->d_fir.as<float>(), mel_dev, c->s_b, c0, c1, 1));
-    }
-    // stream B's last launch is behind every launch of stream A
-    AF_HIP(hipEventRecord(c->ev_join, c->s_b));
-    AF_HIP(hipStreamWaitEvent(stream, c->ev_join, 0));
+        return features_run_clips(c->feat, c->d_fir.as<float>(), mel_dev, c->s_b, c0, c1, 1);
+    };
+    for (int k = 0; k < chunks && st == AF_OK; ++k) st = chunk(k);
+    // stream B waits for everything stream A has been given (after an error its last chunk event may not exist), the
+    // caller's stream for stream B
+    hipError_t je = hipEventRecord(c->ev_join, c->s_a);
+    if (je == hipSuccess) je = hipStreamWaitEvent(c->s_b, c->ev_join, 0);
+    if (je == hipSuccess) je = hipEventRecord(c->ev_join, c->s_b);
+    if (je == hipSuccess) je = hipStreamWaitEvent(stream, c->ev_join, 0);
+    if (st != AF_OK) return st;
+    if (je != hipSuccess) return fail(AF_ERR_HIP, "af_chain: joining the pipeline streams failed: %s", hipGetErrorString(je));
     return AF_OK;
 }
 
 bool fused_applies(const af_chain* c)
 {
     if (!c->fused.ok || want_unfused(c)) return false;
+    // (mono i16 is staged in dwords from the clip base: clips of an odd frame count put every second base on an odd frame)
+    if (!c->ragged && c->fmt == banded::kFmtMonoI16 && (c->n_in & 1) && c->n_clips > 1) return false;
     if (!c->ragged) return banded::fits(c->fused, (int64_t)c->n_in);
     return c->n_tiles > 0 || c->n_clips == 0;        // the tile table exists: every clip fits and is aligned
 }
@@ -897,6 +911,13 @@ af_status af_chain_stream_push(af_chain_stream* s, const void* pcm, size_t n_fra
     s->rows_out += wrote;
     *n_rows = wrote;
     return AF_OK;
+}
+
+size_t af_chain_stream_flush_rows(const af_chain_stream* s)
+{
+    if (!s || s->flushed) return 0;
+    const size_t total = af_chain_stream_total_rows(s, s->frames_in);
+    return total > (size_t)s->rows_out ? total - (size_t)s->rows_out : 0;
 }
 
 af_status af_chain_stream_flush(af_chain_stream* s, float* rows_out, size_t rows_cap, size_t* n_rows)

@@ -1178,6 +1178,8 @@ af_status af_mel_apply(af_mel* m, const float* power, size_t n_frames, float* me
 }  // extern "C"
 
 
+bool af::features_one_launch(const af_features* p) { return p && !p->dense_mel && p->cfg.channels <= 2; }
+
 // The chain's pipelined form (chain.hip): the units of clips [clip_begin, clip_end) only, on the given stream, with one
 // or two workgroups per CU.  Rows land at their places in mel_dev; the caller orders the launches.
 af_status af::features_run_clips(af_features* p, const void* pcm_dev, float* mel_dev, hipStream_t stream, size_t clip_begin,

@@ -540,7 +540,8 @@ public:
     }
     std::vector<float> flush()
     {
-        std::vector<float> rows(af_chain_stream_rows_per_step(h_) * row_len());
+        // (the flush can owe one row more than a step: af_chain_stream_flush_rows is the bound)
+        std::vector<float> rows(std::max<size_t>(af_chain_stream_flush_rows(h_), 1) * row_len());
         size_t n = 0;
         detail::check(af_chain_stream_flush(h_, rows.data(), rows.size(), &n));
         rows.resize(n * row_len());

@@ -52,7 +52,9 @@ const char* af_version(void);
 int         af_device_count(void);
 /* Diagnostics only (no reference counterpart): process-wide switches used by the tests and the
  * profiling scripts; value 0 restores the product behaviour.
- *   "features.kernel"     1: the general fused STFT+mel kernel also where the hop-256 kernel applies
+ *   "features.kernel"     1: the general fused STFT+mel kernel also where the hop-256 kernel applies; 2: the hop-256
+ *                         register-FFT kernel (the default there); 3: the hop-256 matrix-core DFT kernel (mel output
+ *                         through the banded plan only: AF_ERR_UNSUPPORTED elsewhere; docs/OPS.md "STFT")
  *   "features.wg_per_cu"  workgroups per CU of the fused kernels
  *   "banded.off"          1: resampler / FIR on the thread-per-output kernels instead of MFMA
  *   "chain.unfused"       1: af_chain_* runs resampler and FIR as two launches instead of one
@@ -459,6 +461,10 @@ size_t    af_chain_stream_total_rows(const af_chain_stream* s, uint64_t n_frames
 size_t    af_chain_stream_max_rows(const af_chain_stream* s, size_t n_frames);      /* of the next push of n_frames */
 af_status af_chain_stream_push(af_chain_stream* s, const void* pcm, size_t n_frames, float* rows_out,
                                size_t rows_cap, size_t* n_rows);
+/* rows the next af_chain_stream_flush() hands out (total_rows(frames pushed) minus the rows returned so far): can exceed
+ * rows_per_step by one when the resampler's look-ahead spans a hop -- size the flush buffer with this, not with
+ * rows_per_step (reference analogue: the final partial chunk of BatchResampler::flush, resampler.rs:150-166) */
+size_t    af_chain_stream_flush_rows(const af_chain_stream* s);
 af_status af_chain_stream_flush(af_chain_stream* s, float* rows_out, size_t rows_cap, size_t* n_rows);
 af_status af_chain_stream_reset(af_chain_stream* s);
 /* Time sharding of ONE long recording across GPUs (BASELINE config 5): every rank owns a

@@ -148,6 +148,7 @@ extern "C" {
     pub fn af_chain_stream_rows_per_step(s: *const af_chain_stream) -> usize;
     pub fn af_chain_stream_row_len(s: *const af_chain_stream) -> usize;
     pub fn af_chain_stream_total_rows(s: *const af_chain_stream, n_frames: u64) -> usize;
+    pub fn af_chain_stream_flush_rows(s: *const af_chain_stream) -> usize;
     pub fn af_chain_stream_max_rows(s: *const af_chain_stream, n_frames: usize) -> usize;
     pub fn af_chain_stream_push(s: *mut af_chain_stream, pcm: *const c_void, n_frames: usize, rows_out: *mut f32, rows_cap: usize, n_rows: *mut usize) -> af_status;
     pub fn af_chain_stream_flush(s: *mut af_chain_stream, rows_out: *mut f32, rows_cap: usize, n_rows: *mut usize) -> af_status;

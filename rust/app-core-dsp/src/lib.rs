@@ -558,7 +558,8 @@ impl<T: PcmSample> ChainStream<T> {
         Ok(rows)
     }
     pub fn flush(&mut self) -> Result<Vec<f32>, AudioError> {
-        let mut rows = vec![0.0f32; unsafe { ffi::af_chain_stream_rows_per_step(self.h) } * self.row_len()];
+        // (the flush can owe one row more than a step: af_chain_stream_flush_rows is the bound)
+        let mut rows = vec![0.0f32; unsafe { ffi::af_chain_stream_flush_rows(self.h) }.max(1) * self.row_len()];
         let mut n = 0usize;
         check(unsafe { ffi::af_chain_stream_flush(self.h, rows.as_mut_ptr(), rows.len(), &mut n) })?;
         rows.truncate(n * self.row_len());

@@ -2,6 +2,7 @@
 # LDS cycles / bank conflicts of the hop-256 kernel by access group (run on the GPU box after scripts/ablate/build.sh
 # built libaf_abl{0,1,2,...,1024}.so): one timing pass, one PMC pass.
 set -e
+: "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O="$GRAFT_REPO_ROOT/gpurun_out/r03/abl"; mkdir -p "$O"
 M="0 1 2 4 8 16 32 64 128 256 512 1024"

@@ -2,10 +2,11 @@
 # Timing + LDS counters of the feature kernel for the given library builds (default: the product library):
 #   bash scripts/ablate/one.sh TAG [LIB ...]
 set -e
+: "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG="$1"; shift
 LIBS="$@"; [ -z "$LIBS" ] && LIBS="audio-flow-rs_amd/libaudioflow_dsp.so"
-O="$GRAFT_REPO_ROOT/gpurun_out/r03/$TAG"; mkdir -p "$O"
+O="$GRAFT_REPO_ROOT/gpurun_out/${AF_ROUND:-r04}/$TAG"; mkdir -p "$O"
 NAMES=""; for l in $LIBS; do NAMES="$NAMES $(basename $l .so)"; done
 python3 scripts/ablate/run_features.py $LIBS > "$O/time.txt" 2> "$O/time.err" || { cat "$O/time.err" | tail -5; bash scripts/ablate/check_fault.sh "$O/time.err"; exit 4; }
 bash scripts/ablate/check_fault.sh "$O/time.err" "$O/time.txt"

@@ -2,6 +2,7 @@
 # Config 4's chain under rocprofv3 (run on the GPU box through gpurun):
 #   scripts/profile_chain.sh <tag>  -> gpurun_out/<tag>/{kernel_stats,pmc_*}.txt
 set -e
+: "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 T=${1:-chain}
 O="$GRAFT_REPO_ROOT/gpurun_out/$T"

@@ -3,6 +3,7 @@
 #   kernel trace + stats of the default bench, then separate PMC passes (FETCH_SIZE / WRITE_SIZE /
 #   SQ counters) restricted to the fused feature kernel, the calibration kernel and the ops bench.
 set -e
+: "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O="$GRAFT_REPO_ROOT/gpurun_out/r02p"
 rm -rf "$O" && mkdir -p "$O"

@@ -5,6 +5,7 @@
 #   counters) for the fused feature kernel, the calibration kernel, config 4's chain, the resampler kernels and
 #   the ops bench.  Counters are never combined with a trace.
 set -e
+: "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O="$GRAFT_REPO_ROOT/gpurun_out/r03p"
 rm -rf "$O" && mkdir -p "$O"

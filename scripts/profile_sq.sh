@@ -2,6 +2,7 @@
 # SQ / LDS counter passes of the fused feature kernel at config 2 (run on the GPU box through gpurun):
 #   scripts/profile_sq.sh <tag>    -> gpurun_out/<tag>/{sq,sq2,sq3}.txt
 set -e
+: "${GRAFT_REPO_ROOT:?run this on the GPU box through gpurun}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 T=${1:-sq}
 O="$GRAFT_REPO_ROOT/gpurun_out/$T"

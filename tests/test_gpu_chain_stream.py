@@ -362,6 +362,60 @@ def test_chain_ragged_and_i16_fused_equals_unfused_and_oracle(af, po, ch, fmt):
     assert np.array_equal(uni.run(x4), fused[r0:r0 + nfs[4]])
 
 
+def test_chain_mono_i16_odd_lengths(af, po):
+    """Mono i16 clips of an ODD frame count (round-3 advisor: the fused launch stages mono i16 as one dword per frame
+    pair and the buffer's range check works per dword, so the last sample of an odd clip was either lost or joined by
+    the 2 bytes behind the clip).  Lengths chosen so that the last STFT frame of the 16 kHz signal ends on the clip's
+    final samples: fused == stage-by-stage bit for bit, both within tolerance of the oracle, for a single odd clip, a
+    ragged batch whose last clip is odd, and a uniform batch of odd clips (which leaves the fused launch)."""
+    taps = lowpass_taps()
+    # 16 kHz length 1024 + 256 k  <=>  48 kHz length 3 * that; -1 / -2 / +1 make it odd around the frame boundary
+    for n in (3 * (1024 + 256 * 40) + 1, 3 * (1024 + 256 * 17) - 1, 3 * (1024 + 256 * 5) + 3):
+        assert n & 1
+        x = _as_i16(synth_clip(910 + n % 7, n, 1, 48000))
+        chain = af.ChainPipeline(input_rate=48000, channels=1, output_rate=16000, fir_taps=taps, sample_format=1)
+        chain.set_batch_uniform(1, n)
+        assert chain.n_launches() == 2
+        fused = chain.run(x)
+        chain.set_option("unfused", 1)
+        staged = chain.run(x)
+        chain.set_option("unfused", -1)
+        assert np.array_equal(fused, staged), n
+        xf = x.astype(np.float32) / np.float32(32768.0)
+        assert frame_rel_err(fused, oracle_chain(po, xf, 1, 48000, 16000, taps)) < 2e-5
+        # behind the clip sits a loud sample that must not leak into its last frame
+        pad = np.concatenate([x, np.array([32767], np.int16)])
+        chain.set_batch(np.array([0, n], np.int64))
+        assert np.array_equal(chain.run(pad), fused), n
+    # ragged: even clips, the last one odd (its base stays even, the fused launch applies)
+    lens = [40000, 11520 * 2, 3 * (1024 + 256 * 9) + 1]
+    clips = [_as_i16(synth_clip(920 + i, m, 1, 48000)) for i, m in enumerate(lens)]
+    chain = af.ChainPipeline(input_rate=48000, channels=1, output_rate=16000, fir_taps=taps, sample_format=1)
+    chain.set_batch(np.concatenate([[0], np.cumsum(lens)]))
+    assert chain.n_launches() == 2
+    fused = chain.run(np.concatenate(clips))
+    chain.set_option("unfused", 1)
+    assert np.array_equal(chain.run(np.concatenate(clips)), fused)
+    chain.set_option("unfused", -1)
+    row = 0
+    for xc, m in zip(clips, lens):
+        nf = chain.n_frames(m)
+        assert frame_rel_err(fused[row:row + nf], oracle_chain(po, xc.astype(np.float32) / np.float32(32768.0), 1, 48000, 16000, taps)) < 2e-5
+        row += nf
+    # uniform batch of odd clips: every second base is odd -> stage by stage, same rows as each clip alone
+    n = 3 * (1024 + 256 * 7) + 1
+    clips = [_as_i16(synth_clip(930 + i, n, 1, 48000)) for i in range(3)]
+    uni = af.ChainPipeline(input_rate=48000, channels=1, output_rate=16000, fir_taps=taps, sample_format=1)
+    uni.set_batch_uniform(3, n)
+    assert uni.n_launches() > 2
+    got = uni.run(np.concatenate(clips))
+    one = af.ChainPipeline(input_rate=48000, channels=1, output_rate=16000, fir_taps=taps, sample_format=1)
+    one.set_batch_uniform(1, n)
+    nf = one.n_frames(n)
+    for i, xc in enumerate(clips):
+        assert np.array_equal(got[i * nf:(i + 1) * nf], one.run(xc))
+
+
 @pytest.mark.parametrize("fi,fo,ch,fmt,with_fir", [(44100, 16000, 2, 0, True), (44100, 16000, 1, 1, True),
                                                    (48000, 44100, 2, 1, True), (44100, 16000, 2, 0, False),
                                                    (16000, 16000, 2, 0, True), (16000, 16000, 1, 0, False),
