@@ -130,18 +130,20 @@ constexpr int kYSlot = 16 * kYRow;        // one k1 slot: 16 frames
 // operands as ds_read_b32 (lanes (frame, kq) on bins b + kq: consecutive bins alternate between the bank halves)
 constexpr int kPBins = 520;
 constexpr int kHaloRow = 112;             // bytes per row of the f32 copy of the tile's last 768 samples [n2][24]
-// LDS map (bytes)
+// LDS map (bytes).  Two signal images (hi and lo' planes each): the tile update for the next unit writes one while the
+// slower waves' stage 1 still reads the other.
 constexpr int kOffY = 0;
-constexpr int kOffThi = kOffY + 16 * kYSlot;                // 73 728
-constexpr int kOffTlo = kOffThi + 32 * kTRow;
-constexpr int kOffHalo = kOffTlo + 32 * kTRow;              // two buffers
+constexpr int kTBuf = 32 * kTRow;                           // one plane of one image
+constexpr int kOffThi = kOffY + 16 * kYSlot;                // 73 728: hi planes of image 0, 1
+constexpr int kOffTlo = kOffThi + 2 * kTBuf;                // lo' planes of image 0, 1
+constexpr int kOffHalo = kOffTlo + 2 * kTBuf;               // two buffers
 constexpr int kOffP = kOffHalo + 2 * 32 * kHaloRow;
-constexpr int kOffWmax = kOffP + 16 * kPBins * 4;
-constexpr int kOffMeta = kOffWmax + 64;
-constexpr int kOffA2s = kOffMeta + kW * kMaxSlotsW * 4;      // the k1 = 16 matrix (one wave reads it): [2 row blocks][hi, lo'][64] uint4
+constexpr int kOffWmax = kOffP + 16 * kPBins * 4;           // per wave (max, max of the last 768 samples) of the next tile's piece
+constexpr int kOffWfresh = kOffWmax + 64;                   // the same of a tile read whole at a clip start
+constexpr int kOffA2s = kOffWfresh + 64;                    // the k1 = 16 matrix (one wave reads it): [2 row blocks][hi, lo'][64] uint4
 constexpr int kLdsBytes = kOffA2s + 2 * 2 * 64 * 16;
 static_assert(kLdsBytes <= 160 * 1024 && kOffThi % 16 == 0 && kOffTlo % 16 == 0 && kOffHalo % 16 == 0 && kOffP % 16 == 0 &&
-                  kOffA2s % 16 == 0,
+                  kOffWmax % 16 == 0 && kOffWfresh % 16 == 0 && kOffA2s % 16 == 0,
               "LDS map");
 // fragment tables (uint4 = 8 f16 per lane): a1 [32 n2][2 row blocks][hi, lo'][64]; a2 [4 row blocks][hi, lo'][64];
 // a2s (k1 = 16, its twiddle W64^n2 folded in) [2 row blocks][hi, lo'][64]

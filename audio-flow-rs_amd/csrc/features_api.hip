@@ -556,6 +556,7 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
         // groups of whole filter quads first (one 16-byte store per group and lane: the kernel's QUADS instances), then the
         // finer cut
         if (build_plan(p->W, (int)cfg->n_mels, v3::kW, 6, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
+            build_plan(p->W, (int)cfg->n_mels, v3::kW, 7, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
             build_plan(p->W, (int)cfg->n_mels, v3::kW, 8, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
             build_plan(p->W, (int)cfg->n_mels, v3::kW, 6, 2, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
             build_plan(p->W, (int)cfg->n_mels, v3::kW, 8, 2, p->plan8b, wfrag8b, meta8b, false) != AF_OK) {
@@ -775,7 +776,7 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     // 2 = features_v2 (the register-FFT kernel of rounds 2-3), 3 = features_v3 or an error
     const int ksel = p->opt_kernel >= 0 ? p->opt_kernel : debug_knob(kKnobFeaturesKernel);
     const bool hop256_ok = p->units_ok && p->offsets_aligned4 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 == 0;
-    const bool v3_applies = hop256_ok && p->v3_ok && !prm.out_power;
+    const bool v3_applies = hop256_ok && p->v3_ok && !prm.out_power && !prm.log_mel;
     if (ksel == 3 && !v3_applies)
         return fail(AF_ERR_UNSUPPORTED, "features: the matrix-core DFT kernel serves hop 256 with mel output through the banded plan only");
     if (v3_applies && ksel == 3) {                       // (opt-in until it is the faster one)

@@ -44,6 +44,11 @@
 #ifndef AF_V3_ABL
 #define AF_V3_ABL 0
 #endif
+// experiment knob: 1 = waves 4..7 run stage 1 + tile update before the mel phase, waves 0..3 after it (measured: 1.79 ms
+// against 1.75 in step, gpurun_out/r04/ablate_v3_4.txt)
+#ifndef AF_V3_STAGGER
+#define AF_V3_STAGGER 0
+#endif
 
 namespace af {
 namespace feat {
@@ -129,9 +134,9 @@ __device__ __forceinline__ unsigned wave_max_bits(float x)
 }
 
 // the unit's power-of-two scale from the bit pattern of max |x|:  s = 2^(140 - E) puts the maximum into [2^13, 2^14);
-// c = 16 / s is what one factor of the power rows' scale is (X_acc = X s / 16)
+// c = 64 / s is what one factor of the power rows' scale is (X_acc = X s / 64)
 struct Scale {
-    float s, s2k, c;          // s, 2048 s, 16 / s
+    float s, s2k, c;          // s, 2048 s, 64 / s
 };
 __device__ __forceinline__ Scale make_scale(unsigned max_bits)
 {
@@ -140,7 +145,7 @@ __device__ __forceinline__ Scale make_scale(unsigned max_bits)
     Scale r;
     r.s = __uint_as_float((267u - e) << 23);
     r.s2k = __uint_as_float((278u - e) << 23);
-    r.c = __uint_as_float((e - 9u) << 23);
+    r.c = __uint_as_float((e - 7u) << 23);
     return r;
 }
 
@@ -161,6 +166,16 @@ __device__ __forceinline__ void split4(const float (&m)[4], const Scale& sc, uin
     }
     hi = uint2{h[0], h[1]};
     lo = uint2{l[0], l[1]};
+}
+
+// tid through a register the compiler cannot see through: lane-dependent addresses derived from it are recomputed where
+// they are used instead of being hoisted out of the unit loop (each hoisted one is a register held for the whole launch,
+// and the kernel lives at its register limit)
+__device__ __forceinline__ int opaque_tid(int tid)
+{
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return tid + z;
 }
 
 typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
@@ -200,6 +215,13 @@ __device__ __forceinline__ f16x8 lds_frag(const unsigned char* p)
 }
 
 // Diagnostics (Params::stamps != null only): per-phase cycle sums of waves 0..3.
+// lane-dependent indices, re-derived where they are used (see opaque_tid)
+#define AF_LANE_VARS                                                                          \
+    const int otid = opaque_tid(tid);                                                         \
+    const int lane = otid & 63, f = lane & 15, g = lane >> 4, tn2 = otid & 31, tq = otid >> 5; \
+    const int lane_pos = 128 * tq + tn2;                                                      \
+    (void)lane; (void)f; (void)g; (void)tn2; (void)tq; (void)lane_pos
+
 #define AF_STAMP3(i)                                                        \
     do {                                                                    \
         if constexpr (STAMPS) {                                             \
@@ -224,12 +246,11 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
     unsigned char* const Halo = smem + kOffHalo;
     float* const P = reinterpret_cast<float*>(smem + kOffP);
     unsigned* const wmax = reinterpret_cast<unsigned*>(smem + kOffWmax);
-    int* const lmeta = reinterpret_cast<int*>(smem + kOffMeta);
+    unsigned* const wfresh = reinterpret_cast<unsigned*>(smem + kOffWfresh);
     unsigned char* const A2s = smem + kOffA2s;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int f = lane & 15, g = lane >> 4;
 
     const int64_t G = gridDim.x, bid = blockIdx.x;
     unsigned u = (unsigned)(p.total_units * bid / G);
@@ -240,6 +261,7 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
     f16x8 a1h[4][2], a1l[4][2], a2h[4], a2l[4];
     float wf[NSLOT * kSlotSteps];
     {
+        const int lane = tid & 63;
         const uint4* t1 = p.tabs;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -265,7 +287,10 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
         const uint4* t3 = p.tabs + kA1Vec + kA2Vec;
         if (tid < kA2sVec) reinterpret_cast<uint4*>(A2s)[tid] = t3[tid];
     }
-    for (int i = tid; i < kW * kMaxSlotsW; i += kT) lmeta[i] = p.meta[i];
+    // first bin of every mel slot of this wave (wave-uniform)
+    int lm[NSLOT];
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) lm[q] = __builtin_amdgcn_readfirstlane(p.meta[w * kMaxSlotsW + q]);
     // bins 513..519 stay zero (padding steps of a mel slot may touch them with zero weights)
     if (tid < 16 * 7) P[513 * 16 + tid] = 0.0f;
     // a wait the compiler sees for the loads above (features_v2.hip: loop-invariant loads carried as "pending")
@@ -283,15 +308,10 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
     int slot_end_w[NSLOT];
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) slot_end_w[q] = p.plan.slot_end[w][q];
-    const int n_slots_w = p.plan.wave_nslots[w];
     const int n_mels = p.plan.n_mels;
-    const float* pbase = P + 16 * g + f;                 // PT[bin = kq][frame]
-    const unsigned row_off = (unsigned)f * (unsigned)n_mels + 4u * (unsigned)g;
 
     // lane constants of the tile update: sample pair p = tid + 512 r  ->  n2 = p & 31, q = p >> 5 (r = 0; + 16 per r).
     // Tile position of sample j of quad Q: 32 (4 Q + j) + n2.
-    const int tn2 = tid & 31, tq = tid >> 5;
-    const int lane_pos = 128 * tq + tn2;                 // position of (quad tq, j = 0)
 
     // PCM frames [frame0, frame0 + n) as a buffer: n <= 0 gives an empty range (every load returns 0, nothing is fetched)
     // (every component through readfirstlane: the unit record may live in vector registers, and a resource the compiler
@@ -307,6 +327,7 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
     // the new samples of tile (unit of d + k): tile positions [768, 4864) = PCM frames d.pcm0 + 4096 k + position
     const auto issue_piece = [&](raw_t (&dst)[2][4], const UnitDesc& d, int k, bool need) {
         const __amdgpu_buffer_rsrc_t rs = clip_rsrc(d.pcm0 + 4096 * k, (need && !(AF_V3_ABL & 128)) ? d.n_avail - 4096 * k : 0);
+        AF_LANE_VARS;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -316,14 +337,95 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memtime() : 0;
 
+    // The issue arbiter prefers the older wave of a SIMD: waves 4..7 (second half of the workgroup) would lose every
+    // contended slot to waves 0..3.  AF_V3_PRIO = 1 (experiment knob) gives them one priority step: measured level (1.77
+    // against 1.75 ms), off.
+#ifndef AF_V3_PRIO
+#define AF_V3_PRIO 0
+#endif
+    if (AF_V3_PRIO && w >= 4) __builtin_amdgcn_s_setprio(AF_V3_PRIO);
+
     bool fresh = true;
     UnitDesc ud_next = load_desc(p.units, u);
-    float c_cur = 1.0f;            // 16 / s of the tile in LDS
-    unsigned tail_prev = 0;        // bits of max |x| over the tile's last 768 samples
-    int hb = 0;                    // halo buffer that holds those samples as f32
-    // Two prefetch sets: while the piece for the next unit is consumed, the one after it stays in flight (one workgroup
-    // per CU: a unit lasts about 2 us, a loaded HBM round trip up to 4).  The loop body exists twice, once per set.
+    // the unit whose power rows sit in P: its mel phase runs at the top of the NEXT pass, beside that pass's stage 1
+    int64_t prev_out0 = 0;
+    int prev_rows = 0;
+    float prev_c = 1.0f;
+    float c_cur = 1.0f;            // 64 / s of the tile stage 1 reads next
+    unsigned tail_prev = 0;        // bits of max |x| over that tile's last 768 samples
+    int hb = 0, tb = 0;            // halo buffer holding those samples as f32; signal image stage 1 reads next
+    float mn[2][4];                // mono samples of the piece that completes the NEXT tile (their maxima are in wmax)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mn[r][j] = 0.0f;
+    // Two prefetch sets: at pass u the piece of tile u + 2 is consumed, the piece of tile u + 3 stays in flight and the
+    // piece of tile u + 4 is requested (one workgroup per CU: a unit lasts about 2 us, a loaded HBM round trip up to 4).
+    // The loop body exists twice, once per set.
     raw_t pf[2][2][4];
+
+    // mel of the unit described by (out0, rows, c): banded W (A, registers) x P^T (B, bins x 16 frames from the bin-major
+    // power rows) on v_mfma_f32_16x16x4_f32.  Every wave issues exactly NSLOT (QUADS) or 4 NSLOT store instructions (rows
+    // behind `rows` are out of the buffer's range, what must not be written gets an out-of-range offset): vector memory
+    // operations retire in order, the wait for a prefetched piece is "all but the youngest N", and with a count the
+    // compiler cannot see it waits for the stores issued just before it.  (log-mel output stays with features_v2.)
+    // Branch-free on purpose (features_kernel.hip, pitfall (iii): a wave-uniform branch in an MFMA stream costs about 150
+    // cycles of instruction fetch; with three of them per slot the phase took 3 500 cycles for 1 300 cycles of matrix work):
+    // every compiled-in slot runs (slots a wave does not use carry zero weights and no group end), a group end is a select.
+    const auto mel_phase = [&](int64_t out0, int rows, float cc) {
+        if constexpr (!(AF_V3_ABL & 1024)) {
+            AF_LANE_VARS;
+            const float* pbase = P + 16 * g + f;             // PT[bin = kq][frame]
+            const unsigned row_off = (unsigned)f * (unsigned)n_mels + 4u * (unsigned)g;
+            float bop[NSLOT * kSlotSteps];
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) {
+                const float* bq = pbase + 16 * lm[q];    // step i of the slot: bins bin0 + 4 i + kq
+#pragma unroll
+                for (int i = 0; i < kSlotSteps; ++i) bop[4 * q + i] = (AF_V3_ABL & 256) ? (float)(lane + i + q) : bq[64 * i];
+            }
+            const int rows_bytes = __builtin_amdgcn_readfirstlane(rows * n_mels * 4);
+            const unsigned long long oa = reinterpret_cast<unsigned long long>(p.out) + (unsigned long long)(out0 * n_mels) * 4ull;
+            const unsigned olo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)oa);
+            const unsigned ohi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(oa >> 32));
+            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void*>(((unsigned long long)ohi << 32) | olo), 0, (AF_V3_ABL & 64) ? 0 : rows_bytes, 0x00020000);
+            const int i0 = 4 * g;
+            constexpr unsigned kOob = 0x7fffffffu;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) {
+#pragma unroll
+                for (int st = q * kSlotSteps; st < (q + 1) * kSlotSteps; st += 2) {
+                    if constexpr (!(AF_V3_ABL & 32)) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], bop[st], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st + 1], bop[st + 1], acc1, 0, 0, 0);
+                    } else {
+                        acc0[0] += wf[st] * bop[st];
+                        acc1[0] += wf[st + 1] * bop[st + 1];
+                    }
+                }
+                const int e = slot_end_w[q];             // wave-uniform (kernarg); 0: the group continues
+                const int mm = e & 255, cnt = (e >> 8) & 31;
+                const float keep = e != 0 ? 0.0f : 1.0f; // the accumulators restart behind a group end
+                f32x4 r = acc0 + acc1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    r[i] = (r[i] * cc) * cc;             // the tile's scale leaves here
+                    acc0[i] *= keep;
+                    acc1[i] *= keep;
+                }
+                const unsigned off = (row_off + (unsigned)mm) * 4u;
+                if constexpr (QUADS) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), ors, (int)((e != 0 && i0 < cnt) ? off : kOob), 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r[i]), ors, (int)((e != 0 && i0 + i < cnt) ? off + 4u * i : kOob), 0, 0);
+                }
+            }
+        }
+    };
 
     const auto unit = [&](auto par_c) {
         constexpr int PAR = decltype(par_c)::value;
@@ -337,18 +439,58 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
         const bool has_next = (u + 1 < u_end) && run >= 1;
         AF_STAMP3(0);
 
-        if (fresh) {
-            // ---- a clip starts: the whole tile from global memory ----
-            __syncthreads();                             // nobody still reads T, P, the halo or wmax
-            const __amdgpu_buffer_rsrc_t rs = clip_rsrc(ud.pcm0, ud.n_avail);
-            raw_t raw[3][4];
+        if (__builtin_expect(fresh, 0)) {
+            // ---- a clip starts: the whole tile AND the piece that completes the next one, straight from global memory ----
+            __syncthreads();                             // nobody still reads T, the halo or the maxima
+            AF_LANE_VARS;
+            // (one after the other, each converted before the next is requested: a clip start may wait, it must not be the
+            // place that sets the kernel's register count)
+            float m[3][4];
+            float mx = 0.0f, mt = 0.0f;
+            {
+                const __amdgpu_buffer_rsrc_t rs = clip_rsrc(ud.pcm0, ud.n_avail);
+                raw_t raw[3][4];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+                for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) raw[r][j] = S::load(rs, (lane_pos + 2048 * r + 32 * j) * S::kBpf);
-            // the next two pieces go out now, each into its set -- with as many (empty-range) stores between them as a unit
-            // issues, so that the first piece has the same number of younger operations behind it as in the steady state
-            issue_piece(pf[PAR], ud, 1, has_next);
+                    for (int j = 0; j < 4; ++j) raw[r][j] = S::load(rs, (lane_pos + 2048 * r + 32 * j) * S::kBpf);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // (r = 2: quads 32..37 exist for tq < 6 only; the others read past the tile and are not used)
+                        m[r][j] = S::mono(raw[r][j], sel);
+                        if (r == 2 && tq >= kQuads - 32) m[r][j] = 0.0f;
+                        mx = fmaxf(mx, fabsf(m[r][j]));
+                        if (r == 2) mt = fmaxf(mt, fabsf(m[r][j]));        // the last 768 samples
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const unsigned wm = wave_max_bits(mx), wt = wave_max_bits(mt);
+                if (lane == 0) { wfresh[2 * w] = wm; wfresh[2 * w + 1] = wt; }
+            }
+            // the next tile's piece: mono samples and maxima, as the steady state leaves them behind
+            {
+                raw_t nu1[2][4];
+                issue_piece(nu1, ud, 1, has_next);
+                float nx = 0.0f, nt = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        mn[r][j] = S::mono(nu1[r][j], sel);
+                        nx = fmaxf(nx, fabsf(mn[r][j]));
+                        if (r == 1) nt = fmaxf(nt, fabsf(mn[r][j]));
+                    }
+                const unsigned wm = wave_max_bits(nx);
+                const unsigned wt = w >= 5 ? wave_max_bits(nt) : 0u;
+                if (lane == 0) { wmax[2 * w] = wm; wmax[2 * w + 1] = wt; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the pieces of tiles u + 2 and u + 3 go out now, each into its set -- with as many (empty-range) stores between
+            // them as a pass issues, so that the first has the same number of younger operations behind it as in the steady state
+            issue_piece(pf[PAR], ud, 2, (u + 2 < u_end) && run >= 2);
             {
                 const __amdgpu_buffer_rsrc_t nowhere = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0, 0x00020000);
 #pragma unroll
@@ -358,32 +500,22 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
                     else __builtin_amdgcn_raw_buffer_store_b32(0u, nowhere, 0x7ffff000 + 16 * q, 0, 0);
                 }
             }
-            issue_piece(pf[PAR ^ 1], ud, 2, (u + 2 < u_end) && run >= 2);
-            float m[3][4];
-            float mx = 0.0f, mt = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // (r = 2: quads 32..37 exist for tq < 6 only; the others read past the tile and are not used)
-                    m[r][j] = S::mono(raw[r][j], sel);
-                    if (r == 2 && tq >= kQuads - 32) m[r][j] = 0.0f;
-                    mx = fmaxf(mx, fabsf(m[r][j]));
-                    if (r == 2) mt = fmaxf(mt, fabsf(m[r][j]));            // the last 768 samples
-                }
-            const unsigned wm = wave_max_bits(mx), wt = wave_max_bits(mt);
-            if (lane == 0) { wmax[2 * w] = wm; wmax[2 * w + 1] = wt; }
+            issue_piece(pf[PAR ^ 1], ud, 3, (u + 3 < u_end) && run >= 3);
             __syncthreads();
             unsigned mall = 0, mtl = 0;
 #pragma unroll
-            for (int ww = 0; ww < kW; ++ww) {
-                mall = wmax[2 * ww] > mall ? wmax[2 * ww] : mall;
-                mtl = wmax[2 * ww + 1] > mtl ? wmax[2 * ww + 1] : mtl;
+            for (int ww = 0; ww < kW; ww += 2) {
+                const uint4 v = reinterpret_cast<const uint4*>(wfresh)[ww / 2];
+                mall = v.x > mall ? v.x : mall;
+                mall = v.z > mall ? v.z : mall;
+                mtl = v.y > mtl ? v.y : mtl;
+                mtl = v.w > mtl ? v.w : mtl;
             }
             const Scale sc = make_scale(mall);
             c_cur = sc.c;
             tail_prev = mtl;
             hb = 0;
+            tb = 0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int quad = tq + 16 * r;
@@ -401,90 +533,134 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
         }
         AF_STAMP3(1);
 
-        // ---- the prefetched piece (set PAR): mono samples and their maxima, published before barrier 1 ----
-        float mn[2][4];
-        if (has_next && !(AF_V3_ABL & 4)) {
-            float mx = 0.0f, mt = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    mn[r][j] = S::mono(pf[PAR][r][j], sel);
-                    mx = fmaxf(mx, fabsf(mn[r][j]));
-                    if (r == 1) mt = fmaxf(mt, fabsf(mn[r][j]));
-                }
-            const unsigned wm = wave_max_bits(mx);
-            // quads 32..37 (the next tile's last 768 samples) are r = 1 of threads 320..511 = waves 5..7
-            const unsigned wt = w >= 5 ? wave_max_bits(mt) : 0u;
-            if (lane == 0) { wmax[2 * w] = wm; wmax[2 * w + 1] = wt; }
-        }
-        // ---- stage 1: this wave's four n2 ----
-        {
-            f32x4 y[4][2];
-            const int bro = 16 * (f + g);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int n2 = 4 * w + t;
-                const f16x8 bh = lds_frag(Thi + n2 * kTRow + bro);
-                const f16x8 bl = lds_frag(Tlo + n2 * kTRow + bro);
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    f32x4 p1, p2;
-                    if constexpr (!(AF_V3_ABL & 1)) {
-                        p1 = mfma16(a1h[t][rb], bh, z);
-                        p2 = mfma16(a1h[t][rb], bl, z);
-                        p2 = mfma16(a1l[t][rb], bh, p2);
-                    } else {
-                        p1 = __builtin_bit_cast(f32x4, __builtin_bit_cast(uint4, bh)) ;
-                        p2 = __builtin_bit_cast(f32x4, __builtin_bit_cast(uint4, bl));
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) y[t][rb][i] = __builtin_fmaf(p2[i], 1.0f / 2048.0f, p1[i]);
-                }
-            }
-            // -> f16 pairs -> Y[k1 = 4g + i][f][row block rb: Yr | Yi][hi | lo'][n2 = 4w .. 4w+3]
-            if constexpr (AF_V3_ABL & 2) {
-                float sink = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) sink += y[t][rb][0] + y[t][rb][1] + y[t][rb][2] + y[t][rb][3];
-                if (sink == 1.2345e-30f) wmax[lane] = 1u;
-            } else {
-            // (the 16-byte piece n2 / 8 = w >> 1 of a part sits at position (w >> 1) ^ (f >> 2))
-            unsigned char* yw = Ybase + (4 * g) * kYSlot + f * kYRow + 16 * ((w >> 1) ^ (f >> 2)) + 8 * (w & 1);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    unsigned h[2], l[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float a = y[2 * q][rb][i], b = y[2 * q + 1][rb][i];
-                        const f16x2 hv = __builtin_convertvector(f32x2{a, b}, f16x2);
-                        const float ra = __builtin_fmaf((float)hv[0], -2048.0f, a * 2048.0f);
-                        const float rbb = __builtin_fmaf((float)hv[1], -2048.0f, b * 2048.0f);
-                        const f16x2 lv = __builtin_convertvector(f32x2{ra, rbb}, f16x2);
-                        h[q] = __builtin_bit_cast(unsigned, hv);
-                        l[q] = __builtin_bit_cast(unsigned, lv);
-                    }
-                    *reinterpret_cast<uint2*>(yw + i * kYSlot + rb * 64) = uint2{h[0], h[1]};
-                    *reinterpret_cast<uint2*>(yw + i * kYSlot + rb * 64 + 128) = uint2{l[0], l[1]};
-                }
-            }
-        }
+        // ======== first half of the pass: mel of the previous unit, stage 1 of this one, tile update for the next ========
+        // (AF_V3_STAGGER: the two waves of a SIMD, w and w + 4, take the two jobs in opposite order -- f32 matrix work
+        // beside vector-heavy work instead of both queueing for the same pipe; measured slower, off)
+        float c_next = c_cur;
+        unsigned tail_next = tail_prev;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+        if ((half == 0) == (w < 4 || !AF_V3_STAGGER)) {
+        mel_phase(prev_out0, prev_rows, prev_c);
         AF_STAMP3(2);
+        } else {
 
+        // ---- stage 1: this wave's four n2, two at a time (32 accumulator registers live) ----
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            AF_LANE_VARS;
+            const unsigned char* th = Thi + tb * kTBuf;
+            const unsigned char* tl = Tlo + tb * kTBuf;
+            const int bro = 16 * (f + g);
+            // -> f16 pairs -> Y[k1 = 4g + i][f][row block rb: Yr | Yi][hi | lo'][n2 = 4w .. 4w+3]:  hi = f16(P1),
+            // lo' = f16(2048 (P1 - hi) + P2)  (the value is P1 + P2 / 2048; |lo'| <= |P1| + |P2| < 2^14 with the 1/64 in A1)
+            unsigned hw[2][2][4], lw[2][2][4];           // [n2 pair][rb][i]: packed (n2 even, n2 odd)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4 p1[2][2], p2[2][2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = 2 * q + tt, n2 = 4 * w + t;
+                    const f16x8 bh = lds_frag(th + n2 * kTRow + bro);
+                    const f16x8 bl = lds_frag(tl + n2 * kTRow + bro);
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (!(AF_V3_ABL & 1)) {
+                            p1[tt][rb] = mfma16(a1h[t][rb], bh, z);
+                            p2[tt][rb] = mfma16(a1h[t][rb], bl, z);
+                            p2[tt][rb] = mfma16(a1l[t][rb], bh, p2[tt][rb]);
+                        } else {
+                            p1[tt][rb] = __builtin_bit_cast(f32x4, __builtin_bit_cast(uint4, bh));
+                            p2[tt][rb] = __builtin_bit_cast(f32x4, __builtin_bit_cast(uint4, bl));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float a = p1[0][rb][i], b = p1[1][rb][i];
+                        const f16x2 hv = __builtin_convertvector(f32x2{a, b}, f16x2);
+                        const float a2 = __builtin_fmaf(a, 2048.0f, p2[0][rb][i]), b2 = __builtin_fmaf(b, 2048.0f, p2[1][rb][i]);
+                        const float ra = __builtin_fmaf((float)hv[0], -2048.0f, a2);
+                        const float rbb = __builtin_fmaf((float)hv[1], -2048.0f, b2);
+                        const f16x2 lv = __builtin_convertvector(f32x2{ra, rbb}, f16x2);
+                        hw[q][rb][i] = __builtin_bit_cast(unsigned, hv);
+                        lw[q][rb][i] = __builtin_bit_cast(unsigned, lv);
+                    }
+                if (q == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (AF_V3_ABL & 2) {
+                unsigned sink = 0;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) sink += hw[q][rb][0] + hw[q][rb][1] + lw[q][rb][2] + lw[q][rb][3];
+                if (sink == 0x12345678u) wmax[lane] = 1u;
+            } else {
+                // (the 16-byte piece n2 / 8 = w >> 1 of a part sits at position (w >> 1) ^ (f >> 2))
+                unsigned char* yw = Ybase + (4 * g) * kYSlot + f * kYRow + 16 * ((w >> 1) ^ (f >> 2)) + 8 * (w & 1);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        *reinterpret_cast<uint2*>(yw + i * kYSlot + rb * 64) = uint2{hw[0][rb][i], hw[1][rb][i]};
+                        *reinterpret_cast<uint2*>(yw + i * kYSlot + rb * 64 + 128) = uint2{lw[0][rb][i], lw[1][rb][i]};
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         AF_STAMP3(3);
-        if constexpr (!(AF_V3_ABL & 512)) __syncthreads();   // B1: Y ready, maxima published, T free
+
+        // ---- tile update: the next unit's tile = this one's last 768 samples (f32 copy in the halo buffer) + the piece in
+        // mn, into the OTHER signal image (this one is being read by the slower waves' stage 1) ----
+        if (__builtin_expect(has_next && !(AF_V3_ABL & 4), 1)) {
+            AF_LANE_VARS;
+            unsigned mall = tail_prev, mtl = 0;
+#pragma unroll
+            for (int ww = 0; ww < kW; ww += 2) {
+                const uint4 v = reinterpret_cast<const uint4*>(wmax)[ww / 2];
+                mall = v.x > mall ? v.x : mall;
+                mall = v.z > mall ? v.z : mall;
+                mtl = v.y > mtl ? v.y : mtl;
+                mtl = v.w > mtl ? v.w : mtl;
+            }
+            const Scale sc = make_scale(mall);
+            c_next = sc.c;
+            tail_next = mtl;
+            unsigned char* th = Thi + (tb ^ 1) * kTBuf;
+            unsigned char* tl = Tlo + (tb ^ 1) * kTBuf;
+            if (w < 3) {                                 // quads 0..5 <- halo (threads 0..191)
+                const float4 hv = *reinterpret_cast<const float4*>(Halo + hb * (32 * kHaloRow) + tn2 * kHaloRow + tq * 16);
+                const float hm[4] = {hv.x, hv.y, hv.z, hv.w};
+                uint2 hi, lo;
+                split4(hm, sc, hi, lo);
+                *reinterpret_cast<uint2*>(th + tn2 * kTRow + tq * 8) = hi;
+                *reinterpret_cast<uint2*>(tl + tn2 * kTRow + tq * 8) = lo;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int quad = 6 + tq + 16 * r;
+                uint2 hi, lo;
+                split4(mn[r], sc, hi, lo);
+                *reinterpret_cast<uint2*>(th + tn2 * kTRow + quad * 8) = hi;
+                *reinterpret_cast<uint2*>(tl + tn2 * kTRow + quad * 8) = lo;
+                if (r == 1 && w >= 5)
+                    *reinterpret_cast<float4*>(Halo + (hb ^ 1) * (32 * kHaloRow) + tn2 * kHaloRow + (quad - 32) * 16) =
+                        float4{mn[r][0], mn[r][1], mn[r][2], mn[r][3]};
+            }
+        }
+        AF_STAMP3(5);
+        }
+        }
+        if constexpr (!(AF_V3_ABL & 512)) __syncthreads();   // B1: Y ready; the next signal image and halo written; maxima read
         AF_STAMP3(4);
 
-        AF_STAMP3(5);
-
-        // ---- stage 2: two k1 per wave -> power rows ----
+        // ======== second half: stage 2 (two k1 per wave -> power rows), the piece of tile u + 2 becomes mn ========
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
+            AF_LANE_VARS;
             const int slot = (2 * w + 1 + it) & 15;      // k1; 0: the special item (k1 = 0 and k1 = 16)
             const unsigned char* yb = Ybase + slot * kYSlot + f * kYRow + 16 * (g ^ (f >> 2));
             const f16x8 yrh = lds_frag(yb), yih = lds_frag(yb + 64), yrl = lds_frag(yb + 128), yil = lds_frag(yb + 192);
@@ -493,7 +669,7 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
             // the two lane groups of a 32-lane store half differ in the parity of k2, i.e. by 32 banks
             const int k2g = 4 * (g >> 1) + (g & 1);
             float* prow = P + f;                         // PT[bin][f]: bin b is prow[16 b]
-            if (slot != 0) {
+            if (__builtin_expect(slot != 0, 1)) {
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
                     const f32x4 a0p1 = mfma16s2(a2h[rb], yrh, z);
@@ -510,12 +686,14 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
                         pw[h] = __builtin_fmaf(re, re, im * im);
                     }
                     const int k2 = 8 * rb + k2g;         // and k2 + 2
-                    if (rb < 2) {
-                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (slot + 32 * k2)] = pw[0];
-                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (slot + 32 * k2 + 64)] = pw[1];
-                    } else {                             // bin 1024 - k
-                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (1024 - slot - 32 * k2)] = pw[0];
-                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (1024 - slot - 32 * k2 - 64)] = pw[1];
+                    if constexpr (!(AF_V3_ABL & 16)) {
+                        if (rb < 2) {
+                            prow[16 * (slot + 32 * k2)] = pw[0];
+                            prow[16 * (slot + 32 * k2 + 64)] = pw[1];
+                        } else {                         // bin 1024 - k
+                            prow[16 * (1024 - slot - 32 * k2)] = pw[0];
+                            prow[16 * (1024 - slot - 32 * k2 - 64)] = pw[1];
+                        }
                     }
                 }
             } else {
@@ -533,11 +711,13 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
                         pw[h] = __builtin_fmaf(re, re, im * im);
                     }
                     const int k2 = 8 * rb + k2g;
-                    if (rb < 2) {
-                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (32 * k2)] = pw[0];
-                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * (32 * k2 + 64)] = pw[1];
-                    } else if (g == 0) {
-                        if constexpr (!(AF_V3_ABL & 16)) prow[16 * 512] = pw[0];          // k2 = 16: bin 512
+                    if constexpr (!(AF_V3_ABL & 16)) {
+                        if (rb < 2) {
+                            prow[16 * (32 * k2)] = pw[0];
+                            prow[16 * (32 * k2 + 64)] = pw[1];
+                        } else if (g == 0) {
+                            prow[16 * 512] = pw[0];      // k2 = 16: bin 512
+                        }
                     }
                 }
                 // k1 = 16: X[16 + 32 k2] = A2s Y16, k2 = 0..15 (the matrix comes from LDS: one wave uses it)
@@ -556,128 +736,47 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
                         pw[h] = __builtin_fmaf(re, re, im * im);
                     }
                     const int k2 = 8 * rb + k2g;
-                    if constexpr (!(AF_V3_ABL & 16)) prow[16 * (16 + 32 * k2)] = pw[0];
-                    if constexpr (!(AF_V3_ABL & 16)) prow[16 * (16 + 32 * k2 + 64)] = pw[1];
+                    if constexpr (!(AF_V3_ABL & 16)) {
+                        prow[16 * (16 + 32 * k2)] = pw[0];
+                        prow[16 * (16 + 32 * k2 + 64)] = pw[1];
+                    }
                 }
             }
         }
         AF_STAMP3(6);
-        if constexpr (!(AF_V3_ABL & 512)) __syncthreads();   // B2: power rows ready; Y free
-        AF_STAMP3(4);
 
-        // ---- mel: banded W (A, registers) x P^T (B, bins x 16 frames) on v_mfma_f32_16x16x4_f32 (features_v2.hip), with the
-        // tile update for the next unit (vector work) beside its f32 MFMAs ----
-        float c_next = c_cur;
-        unsigned tail_next = tail_prev;
-        if (has_next && !(AF_V3_ABL & 4)) {
-            // ---- tile update: the next unit's tile = the last 768 samples (f32 copy in the halo buffer) + the new piece ----
-            unsigned mall = tail_prev, mtl = 0;
+        // ---- the piece of tile u + 2 (set PAR, requested two passes ago): mono samples and their maxima for the next
+        // pass's tile update (the maxima of the previous piece were read before barrier 1) ----
+        if (__builtin_expect((u + 2 < u_end) && run >= 2 && !(AF_V3_ABL & 4), 1)) {
+            const int lane = opaque_tid(tid) & 63;
+            float mx = 0.0f, mt = 0.0f;
 #pragma unroll
-            for (int ww = 0; ww < kW; ww += 2) {
-                const uint4 v = reinterpret_cast<const uint4*>(wmax)[ww / 2];
-                mall = v.x > mall ? v.x : mall;
-                mall = v.z > mall ? v.z : mall;
-                mtl = v.y > mtl ? v.y : mtl;
-                mtl = v.w > mtl ? v.w : mtl;
-            }
-            const Scale sc = make_scale(mall);
-            c_next = sc.c;
-            tail_next = mtl;
-            if (tid < 192) {                             // quads 0..5 <- halo
-                const float4 hv = *reinterpret_cast<const float4*>(Halo + hb * (32 * kHaloRow) + tn2 * kHaloRow + tq * 16);
-                const float hm[4] = {hv.x, hv.y, hv.z, hv.w};
-                uint2 hi, lo;
-                split4(hm, sc, hi, lo);
-                *reinterpret_cast<uint2*>(Thi + tn2 * kTRow + tq * 8) = hi;
-                *reinterpret_cast<uint2*>(Tlo + tn2 * kTRow + tq * 8) = lo;
-            }
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int quad = 6 + tq + 16 * r;
-                uint2 hi, lo;
-                split4(mn[r], sc, hi, lo);
-                *reinterpret_cast<uint2*>(Thi + tn2 * kTRow + quad * 8) = hi;
-                *reinterpret_cast<uint2*>(Tlo + tn2 * kTRow + quad * 8) = lo;
-                if (r == 1 && w >= 5)
-                    *reinterpret_cast<float4*>(Halo + (hb ^ 1) * (32 * kHaloRow) + tn2 * kHaloRow + (quad - 32) * 16) =
-                        float4{mn[r][0], mn[r][1], mn[r][2], mn[r][3]};
-            }
+                for (int j = 0; j < 4; ++j) {
+                    mn[r][j] = S::mono(pf[PAR][r][j], sel);
+                    mx = fmaxf(mx, fabsf(mn[r][j]));
+                    if (r == 1) mt = fmaxf(mt, fabsf(mn[r][j]));
+                }
+            const unsigned wm = wave_max_bits(mx);
+            // quads 32..37 (that tile's last 768 samples) are r = 1 of threads 320..511 = waves 5..7
+            const unsigned wt = w >= 5 ? wave_max_bits(mt) : 0u;
+            if (lane == 0) { wmax[2 * w] = wm; wmax[2 * w + 1] = wt; }
         }
-        if constexpr (!(AF_V3_ABL & 1024)) {
-            float bop[NSLOT * kSlotSteps];
-            const int* lm = lmeta + w * kMaxSlotsW;
-#pragma unroll
-            for (int q = 0; q < NSLOT; ++q) {
-                const float* bq = pbase + 16 * lm[q];    // step i of the slot: bins bin0 + 4 i + kq
-#pragma unroll
-                for (int i = 0; i < kSlotSteps; ++i) bop[4 * q + i] = (AF_V3_ABL & 256) ? (float)(lane + i + q) : bq[64 * i];
-            }
-            // The rows of this unit as a buffer: rows behind n_rows are out of range, what must not be written gets an
-            // out-of-range offset -- every wave issues exactly NSLOT (QUADS) or 4 NSLOT store instructions per unit, no branch
-            // around any of them.  The count matters: vector memory operations retire in order, the wait for a prefetched
-            // piece is "all but the youngest N", and with a count the compiler cannot see it waited for the stores issued
-            // just before -- a full store round trip in every unit (-0.2 ms when the stores were compiled out).
-            const int rows_bytes = __builtin_amdgcn_readfirstlane(ud.n_rows * n_mels * 4);
-            const unsigned long long oa = reinterpret_cast<unsigned long long>(p.out) + (unsigned long long)(ud.out0 * n_mels) * 4ull;
-            const unsigned olo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)oa);
-            const unsigned ohi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(oa >> 32));
-            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<void*>(((unsigned long long)ohi << 32) | olo), 0, (AF_V3_ABL & 64) ? 0 : rows_bytes, 0x00020000);
-            const int i0 = 4 * g;
-            constexpr unsigned kOob = 0x7fffffffu;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < NSLOT; ++q) {
-                // (slots this wave does not use are skipped -- a wave-uniform branch without any memory operation inside;
-                // the stores below stay unconditional)
-                if (q < n_slots_w) {
-#pragma unroll
-                    for (int st = q * kSlotSteps; st < (q + 1) * kSlotSteps; st += 2) {
-                        if constexpr (!(AF_V3_ABL & 32)) {
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], bop[st], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st + 1], bop[st + 1], acc1, 0, 0, 0);
-                        } else {
-                            acc0[0] += wf[st] * bop[st];
-                            acc1[0] += wf[st + 1] * bop[st + 1];
-                        }
-                    }
-                }
-                const int e = slot_end_w[q];             // wave-uniform (kernarg); 0: the group continues
-                const bool end = e != 0;
-                const int mm = e & 255, cnt = (e >> 8) & 31;
-                f32x4 r = acc0 + acc1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) r[i] = (r[i] * c_cur) * c_cur;          // the tile's scale leaves here
-                if (p.log_mel) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] = __log10f(fmaxf(r[i], 1e-10f));
-                }
-                const unsigned off = (row_off + (unsigned)mm) * 4u;
-                if constexpr (QUADS) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), ors, (int)((end && i0 < cnt) ? off : kOob), 0, 0);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r[i]), ors, (int)((end && i0 + i < cnt) ? off + 4u * i : kOob), 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc0[i] = end ? 0.0f : acc0[i];
-                    acc1[i] = end ? 0.0f : acc1[i];
-                }
-            }
-        }
-        // ---- the piece three units ahead goes into the set just consumed: the LAST vector memory operations of the
-        // iteration and unconditional (an empty range when there is nothing to fetch), so that "all but the youngest 8"
-        // is what the next consumer has to wait for on every path ----
-        if constexpr (!(AF_V3_ABL & 2048)) issue_piece(pf[PAR], ud, 3, has_next && (u + 3 < u_end) && run >= 3);
+        // ---- the piece of tile u + 4 goes into the set just consumed: the LAST vector memory operations of the pass and
+        // unconditional (an empty range when there is nothing to fetch), so that "all but the youngest N" is what the next
+        // consumer has to wait for on every path ----
+        if constexpr (!(AF_V3_ABL & 2048)) issue_piece(pf[PAR], ud, 4, (u + 4 < u_end) && run >= 4);
         AF_STAMP3(7);
-        if (has_next && !(AF_V3_ABL & 512)) __syncthreads();   // B3: the next tile is ready (a clip start brings its own barriers)
+        if constexpr (!(AF_V3_ABL & 512)) __syncthreads();   // B2: power rows ready; Y free; maxima published
         AF_STAMP3(4);
 
+        prev_out0 = ud.out0;
+        prev_rows = ud.n_rows;
+        prev_c = c_cur;
         c_cur = c_next;
         tail_prev = tail_next;
-        if (has_next) hb ^= 1;
+        if (has_next) { hb ^= 1; tb ^= 1; }
         fresh = !has_next;
         ++u;
     };
@@ -689,8 +788,9 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
         unit(std::integral_constant<int, 0>{});
         unit(std::integral_constant<int, 1>{});
     }
+    mel_phase(prev_out0, prev_rows, prev_c);             // the last unit's rows
     if constexpr (STAMPS) {
-        if (lane == 0 && w >= p.stamp_wave0 && w < p.stamp_wave0 + 4)
+        if ((tid & 63) == 0 && w >= p.stamp_wave0 && w < p.stamp_wave0 + 4)
             for (int i = 0; i < 8; ++i) atomicAdd(p.stamps + (w - p.stamp_wave0) * 8 + i, acc_t[i]);
     }
 }
@@ -725,10 +825,11 @@ static af_status launch_fmt(const Params& p, bool separate, int grid, hipStream_
         if (separate) return quads ? launch_k<CH, I16, true, 8, false, true>(p, grid, stream) : launch_k<CH, I16, true, 8, false, false>(p, grid, stream);
     }
     if constexpr (CH == 2 && !I16) {
-        if (p.stamps && quads) return launch_k<CH, I16, false, 8, true, true>(p, grid, stream);
+        if (p.stamps && quads && most <= 7) return launch_k<CH, I16, false, 7, true, true>(p, grid, stream);
     }
     if (!quads) return launch_k<CH, I16, false, 8, false, false>(p, grid, stream);
     if (most <= 6) return launch_k<CH, I16, false, 6, false, true>(p, grid, stream);
+    if (most <= 7) return launch_k<CH, I16, false, 7, false, true>(p, grid, stream);
     return launch_k<CH, I16, false, 8, false, true>(p, grid, stream);
 }
 
@@ -773,14 +874,15 @@ void put_frag(uint4* hi_dst, uint4* lo_dst, F&& a)
 void build_tables(const double* win, uint4* tabs)
 {
     // a1 [n2][rb][hi, lo'][64]: rows of row block 0 = Re k1 = 0..15; row block 1 = row 0: Re k1 = 16 WITHOUT the
-    // twiddle W1024^(16 n2) (it sits in a2s), rows 1..15: Im k1 = 1..15.  Scaled by 1/16 so that |Y'| <= 2^14 for a
-    // tile whose maximum is below 2^14 (sum over n1 of the Hann window = 16).
+    // twiddle W1024^(16 n2) (it sits in a2s), rows 1..15: Im k1 = 1..15.  Scaled by 1/64 so that |Y'| <= 2^12 for a
+    // tile whose maximum is below 2^14 (sum over n1 of the Hann window = 16): the lo' word of a Y' value is bounded by
+    // |P1| + |P2| <= 3 x 2^12.
     for (int n2 = 0; n2 < 32; ++n2)
         for (int rb = 0; rb < 2; ++rb) {
             uint4* dst = tabs + ((n2 * 2 + rb) * 2) * 64;
             put_frag(dst, dst + 64, [&](int m, int n1) {
                 const int n = 32 * n1 + n2;
-                const double wv = win[n] / 16.0;
+                const double wv = win[n] / 64.0;
                 if (rb == 0) return wv * std::cos(2.0 * kPi * (double)((n * m) % 1024) / 1024.0);
                 if (m == 0) return (n1 & 1) ? -wv : wv;
                 return -wv * std::sin(2.0 * kPi * (double)((n * m) % 1024) / 1024.0);

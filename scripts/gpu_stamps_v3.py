@@ -27,7 +27,7 @@ torch.cuda.synchronize()
 out = np.zeros(32, np.uint64)
 assert lib.af_features_debug_stamps(pipe._h, 0, out.ctypes.data) == 0
 per = out.reshape(4, 8).astype(np.float64) / (3 * tot / 16)
-names = ["desc", "fresh", "publish+stage 1", "-", "barrier waits", "-", "stage 2", "mel + tile update + issue"]
+names = ["desc", "clip start", "mel (previous unit)", "stage 1", "barrier waits", "tile update", "stage 2", "next piece + issue"]
 w0 = int(sys.argv[1])
 print(f"cycles per unit, waves {w0}..{w0 + 3}:")
 for i, nm in enumerate(names): print(f"  {nm:26s}", " ".join(f"{per[w, i]:8.0f}" for w in range(4)))
