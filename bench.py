@@ -255,6 +255,37 @@ def chain_secondary(torch, af, dev, pcm, n_clips: int, n_frames_pcm: int, stream
                       "launches": chain.n_launches()}}
 
 
+def features_v3_secondary(torch, af, dev, pcm, mel_ref, n_clips: int, n_frames_pcm: int, stream, device_index: int) -> dict:
+    """The matrix-core DFT kernel (features_v3.hip, `af_features_set_option(h, "kernel", 3)`) on the headline's shard:
+    the same launch with the 1024-point DFT as two f16-pair matrix products.  Measured beside the headline because it
+    is the design alternative of round 4: opt-in while it is the slower of the two."""
+    pipe = af.FeaturePipeline(sample_rate=SR, channels=CHANNELS, n_fft=N_FFT, hop=HOP, n_mels=N_MELS, device=device_index)
+    if af.library().af_features_set_option(pipe._h, b"kernel", 3) != 0:
+        return {}
+    total = pipe.set_batch_uniform(n_clips, n_frames_pcm)
+    mel = torch.empty(total, N_MELS, device=dev, dtype=torch.float32)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.2:
+        pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg = n_clips * n_frames_pcm * CHANNELS * 4 + total * N_MELS * 4
+    chk = oracle_check(pcm, mel, n_frames_pcm, pipe.n_frames(n_frames_pcm), n_clips)
+    # per-frame distance to the headline kernel's rows of the same input
+    d = (mel - mel_ref).double().norm(dim=1) / mel_ref.double().norm(dim=1).clamp_min(1e-300)
+    return {"features_v3": {"workload": "the headline's shard through af_features_v3_kernel (DFT on v_mfma_f32_16x16x32_f16, f16 operand pairs)",
+                            "ms": ms, "frac_hbm": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "max_rel_err": chk["max_rel_err"], "checked_clips": chk["clips"], "ok": chk["ok"],
+                            "max_rel_diff_vs_headline": float(d.max())}}
+
+
 def resample_secondary(torch, af, dev) -> dict:
     """The polyphase resampler on its own, device-resident, HIP events: BASELINE config 3 (4096 mono clips of 10 s,
     44.1 -> 16 kHz: ten block matrices, banded_kernel) and the everyday device ratio 48 -> 44.1 kHz (147 block
@@ -567,6 +598,7 @@ def run_rank(args) -> None:
         m["check"] = oracle_check(pcm, mel, n_frames_pcm, pipe.n_frames(n_frames_pcm), n_clips)
     if rank == 0 and world == 1 and not args.no_secondary:
         m["secondary"] = chain_secondary(torch, af, dev, pcm, n_clips, n_frames_pcm, stream)
+        m["secondary"].update(features_v3_secondary(torch, af, dev, pcm, mel, n_clips, n_frames_pcm, stream, local_rank))
         if args.northstar_clips > 0:
             m["secondary"].update(northstar_secondary(torch, af, dev, args.northstar_clips, n_frames_pcm,
                                                       stream, local_rank))

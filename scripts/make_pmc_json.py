@@ -1,12 +1,13 @@
-"""Condense gpurun_out/r03p (scripts/profile_r03.sh) into the committed evidence under profiles/:
+"""Condense gpurun_out/rNNp (scripts/profile_rNN.sh; NN = AF_ROUND_NO, default 4) into the committed evidence under profiles/:
    r03_*.txt copies, profiles/pmc_traffic.json (calibrated HBM bytes per launch = bench.py's roofline.traffic) and
    profiles/pmc_resources.json (busy fractions of the other resources = bench.py's roofline.other).
-   python3 scripts/make_pmc_json.py [gpurun_out/r03p]"""
+   python3 scripts/make_pmc_json.py [gpurun_out/r04p]"""
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03p")
+ROUND = int(os.environ.get("AF_ROUND_NO", "4"))
+RT = f"r{ROUND:02d}"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", RT + "p")
 dst = os.path.join(ROOT, "profiles")
-ROUND = 3
 
 
 def table(name):
@@ -30,16 +31,18 @@ def first(tab, key):
     raise SystemExit(f"no kernel matching {key} in the table")
 
 
-copies = {"kernel_stats.txt": "r03_kernel_stats.txt", "pmc_fetch.txt": "r03_pmc_fetch.txt", "pmc_write.txt": "r03_pmc_write.txt",
-          "pmc_sq.txt": "r03_pmc_sq.txt", "pmc_sq2.txt": "r03_pmc_sq2.txt", "pmc_cal_fetch.txt": "r03_pmc_cal_fetch.txt",
-          "pmc_cal_write.txt": "r03_pmc_cal_write.txt", "bench.json": "r03_bench.json",
-          "bench_driver_args.json": "r03_bench_driver_args.json", "chain_kernel_stats.txt": "r03_chain_kernel_stats.txt",
-          "pmc_chain_fetch.txt": "r03_chain_pmc_fetch.txt", "pmc_chain_write.txt": "r03_chain_pmc_write.txt",
-          "pmc_chain_sq.txt": "r03_chain_pmc_sq.txt", "pmc_chain_sq2.txt": "r03_chain_pmc_sq2.txt",
-          "pmc_res_fetch.txt": "r03_res_pmc_fetch.txt", "pmc_res_write.txt": "r03_res_pmc_write.txt",
-          "pmc_res_sq.txt": "r03_res_pmc_sq.txt", "pmc_res_sq2.txt": "r03_res_pmc_sq2.txt",
-          "resample_ratios.json": "r03_resample_ratios.json", "ops.json": "r03_ops.json",
-          "ops_kernel_stats.txt": "r03_ops_kernel_stats.txt"}
+copies = {"kernel_stats.txt": RT + "_kernel_stats.txt", "pmc_fetch.txt": RT + "_pmc_fetch.txt", "pmc_write.txt": RT + "_pmc_write.txt",
+          "pmc_sq.txt": RT + "_pmc_sq.txt", "pmc_sq2.txt": RT + "_pmc_sq2.txt", "pmc_cal_fetch.txt": RT + "_pmc_cal_fetch.txt",
+          "pmc_cal_write.txt": RT + "_pmc_cal_write.txt", "bench.json": RT + "_bench.json",
+          "bench_driver_args.json": RT + "_bench_driver_args.json", "chain_kernel_stats.txt": RT + "_chain_kernel_stats.txt",
+          "pmc_chain_fetch.txt": RT + "_chain_pmc_fetch.txt", "pmc_chain_write.txt": RT + "_chain_pmc_write.txt",
+          "pmc_chain_sq.txt": RT + "_chain_pmc_sq.txt", "pmc_chain_sq2.txt": RT + "_chain_pmc_sq2.txt",
+          "pmc_res_fetch.txt": RT + "_res_pmc_fetch.txt", "pmc_res_write.txt": RT + "_res_pmc_write.txt",
+          "pmc_res_sq.txt": RT + "_res_pmc_sq.txt", "pmc_res_sq2.txt": RT + "_res_pmc_sq2.txt",
+          "resample_ratios.json": RT + "_resample_ratios.json", "ops.json": RT + "_ops.json",
+          "ops_kernel_stats.txt": RT + "_ops_kernel_stats.txt",
+          "v3_kernel_stats.txt": RT + "_v3_kernel_stats.txt", "pmc_v3_fetch.txt": RT + "_v3_pmc_fetch.txt",
+          "pmc_v3_write.txt": RT + "_v3_pmc_write.txt", "pmc_v3_sq.txt": RT + "_v3_pmc_sq.txt", "pmc_v3_sq2.txt": RT + "_v3_pmc_sq2.txt"}
 for a, b in copies.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
@@ -63,7 +66,7 @@ traffic = {
                     "note": "gfx950 FETCH_SIZE tallies 16-B-per-lane coalesced reads at exactly 1/2 (MI355X_MICROARCH.md, HBM); corrected below"},
     "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
     "algorithmic_bytes_per_launch": ALG, "traffic_over_algorithmic": round((rd + wr) / ALG, 4),
-    "source": ["profiles/r03_pmc_fetch.txt", "profiles/r03_pmc_write.txt", "profiles/r03_pmc_cal_fetch.txt", "profiles/r03_pmc_cal_write.txt"],
+    "source": ["profiles/" + RT + "_pmc_fetch.txt", "profiles/" + RT + "_pmc_write.txt", "profiles/" + RT + "_pmc_cal_fetch.txt", "profiles/" + RT + "_pmc_cal_write.txt"],
     "round2": {k: old[k] for k in ("kernel", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch",
                                    "traffic_over_algorithmic") if k in old},
     "round1": old.get("round1"), "banded_kernel_config3": old.get("banded_kernel_config3"),
@@ -79,10 +82,10 @@ if cfch and cwch:
                    "hbm_read_bytes_per_launch": int(r_), "hbm_write_bytes_per_launch": int(w_)}
         tot += r_ + w_
     alg4 = 256 * 1440000 * 8 + 479232 * 320
-    traffic["chain_config4"] = {"workload": "256 x 30 s stereo 48 kHz f32 -> downmix + 48->16 kHz + FIR 129 (one launch) -> STFT -> 80 mel (one launch); scripts/profile_r03.sh",
+    traffic["chain_config4"] = {"workload": "256 x 30 s stereo 48 kHz f32 -> downmix + 48->16 kHz + FIR 129 (one launch) -> STFT -> 80 mel (one launch); scripts/profile_r04.sh",
                                 "kernels": kern, "hbm_bytes_per_pass": int(tot), "algorithmic_bytes_per_pass": alg4,
                                 "traffic_over_algorithmic": round(tot / alg4, 4),
-                                "source": ["profiles/r03_chain_pmc_fetch.txt", "profiles/r03_chain_pmc_write.txt"]}
+                                "source": ["profiles/" + RT + "_chain_pmc_fetch.txt", "profiles/" + RT + "_chain_pmc_write.txt"]}
 rf, rw = table("pmc_res_fetch.txt"), table("pmc_res_write.txt")
 if rf and rw:
     k, v = first(rf, "banded_stream")
@@ -94,7 +97,7 @@ if rf and rw:
     traffic["banded_stream_48k_44k1"] = {"workload": "1024 x 30 s mono 48 kHz -> 44.1 kHz, one launch", "kernel": k,
                                          "hbm_read_bytes_per_launch_indicative": int(r_), "hbm_write_bytes_per_launch": int(w_),
                                          "algorithmic_bytes_per_launch": alg,
-                                         "source": ["profiles/r03_res_pmc_fetch.txt", "profiles/r03_res_pmc_write.txt"]}
+                                         "source": ["profiles/" + RT + "_res_pmc_fetch.txt", "profiles/" + RT + "_res_pmc_write.txt"]}
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
 # ---- the other resources of the headline kernel (HBM fraction AND VALU / MFMA / LDS fractions)
@@ -114,9 +117,29 @@ res = {
                  "SQ_WAVE_CYCLES": s1["SQ_WAVE_CYCLES"], "SQ_WAIT_ANY": s1["SQ_WAIT_ANY"],
                  "SQ_WAIT_INST_ANY": s1["SQ_WAIT_INST_ANY"], "SQ_ACTIVE_INST_ANY": s1["SQ_ACTIVE_INST_ANY"]},
     "formulas": "lds = SQ_LDS_IDX_ACTIVE / 256 CUs; valu = SQ_INSTS_VALU x 2 cycles / 1024 SIMDs; mfma = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; all over GRBM_GUI_ACTIVE / 8 XCDs of the profiled launch",
-    "source": ["profiles/r03_pmc_sq.txt", "profiles/r03_pmc_sq2.txt"],
-    "note": "recorded by separate rocprofv3 --pmc passes (scripts/profile_r03.sh), not measured by the bench run that quotes it",
+    "source": ["profiles/" + RT + "_pmc_sq.txt", "profiles/" + RT + "_pmc_sq2.txt"],
+    "note": "recorded by separate rocprofv3 --pmc passes (scripts/profile_r04.sh), not measured by the bench run that quotes it",
 }
+# the matrix-core DFT kernel (opt-in) on the same workload, same formulas
+if table("pmc_v3_sq.txt") and table("pmc_v3_sq2.txt"):
+    k3, v1 = first(table("pmc_v3_sq.txt"), "af_features_v3")
+    _, v2 = first(table("pmc_v3_sq2.txt"), "af_features_v3")
+    c3 = v2["GRBM_GUI_ACTIVE"] / 8.0
+    res["features_v3"] = {
+        "kernel": k3, "launch_cycles": c3,
+        "lds_frac": round(v2["SQ_LDS_IDX_ACTIVE"] / 256 / c3, 4), "valu_frac": round(v1["SQ_INSTS_VALU"] * 2 / 1024 / c3, 4),
+        "mfma_frac": round(v2["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / c3, 4),
+        "waves_waiting": round(v1["SQ_WAIT_ANY"] / v1["SQ_WAVE_CYCLES"], 4),
+        "waves_stalled_on_issue": round(v1["SQ_WAIT_INST_ANY"] / v1["SQ_WAVE_CYCLES"], 4),
+        "waves_issuing": round(v1["SQ_ACTIVE_INST_ANY"] / v1["SQ_WAVE_CYCLES"], 4),
+        "counters": {"SQ_LDS_IDX_ACTIVE": v2["SQ_LDS_IDX_ACTIVE"], "SQ_LDS_BANK_CONFLICT": v2["SQ_LDS_BANK_CONFLICT"],
+                     "SQ_INSTS_VALU": v1["SQ_INSTS_VALU"], "SQ_INSTS_LDS": v1["SQ_INSTS_LDS"],
+                     "SQ_VALU_MFMA_BUSY_CYCLES": v2["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": v2["GRBM_GUI_ACTIVE"]},
+        "source": ["profiles/" + RT + "_v3_pmc_sq.txt", "profiles/" + RT + "_v3_pmc_sq2.txt"]}
+    if table("pmc_v3_fetch.txt") and table("pmc_v3_write.txt"):
+        _, f3 = first(table("pmc_v3_fetch.txt"), "af_features_v3")
+        _, w3 = first(table("pmc_v3_write.txt"), "af_features_v3")
+        res["features_v3"]["traffic_over_algorithmic"] = round((f3["FETCH_SIZE"] * 1024 / cal_f + w3["WRITE_SIZE"] * 1024 / cal_w) / ALG, 4)
 json.dump(res, open(os.path.join(dst, "pmc_resources.json"), "w"), indent=1)
 print(json.dumps({"traffic_over_algorithmic": traffic["traffic_over_algorithmic"], "lds": res["lds_frac"], "valu": res["valu_frac"],
                   "mfma": res["mfma_frac"]}))
