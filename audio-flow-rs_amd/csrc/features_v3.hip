@@ -25,15 +25,24 @@
 // (scripts/proto/dft_mfma_model.py is the numpy model of exactly this arithmetic).
 //
 // Structure: 512 threads = 8 waves, ONE workgroup per CU (256 registers per lane: the stage-1 fragments of a wave's four
-// n2, 64 VGPRs, and the stage-2 fragments, 32 + 16, stay resident), a persistent grid over contiguous unit ranges.
-//   stage 1   wave w: n2 = 4w .. 4w+3; B operand = 16 bytes of the f16 signal image T[n2][blk] (hi and lo' planes; frames
-//             overlap, so lanes (f, g) with equal f + g read the same address); results -> f16 pairs -> Y in LDS,
-//             [k1][f][Yr hi | Yi hi | Yr lo' | Yi lo'] (one ds_write_b64 = four n2)
+// n2, 64 VGPRs, the stage-2 fragments, 32, and its mel fragments stay resident; 136 KB of LDS), a persistent grid over
+// contiguous unit ranges, two barriers per unit:
+//   first half    mel of the PREVIOUS unit (the banded f32 contraction of features_v2.hip on v_mfma_f32_16x16x4_f32, from
+//                 bin-major power rows, branch-free), then
+//                 stage 1 of this unit: wave w takes n2 = 4w .. 4w+3; B operand = 16 bytes of the f16 signal image
+//                 T[n2][blk] (hi and lo' planes; frames overlap, so lanes (f, g) with equal f + g read the same address);
+//                 results -> f16 pairs -> Y in LDS, [k1][f][Yr hi | Yi hi | Yr lo' | Yi lo'] (one ds_write_b64 = four n2), then
+//                 the tile update for the NEXT unit into the second signal image (its piece of PCM arrived a pass ago and
+//                 was turned into mono samples + maxima in the previous second half)
 //   barrier 1
-//   tile update for the next unit (the prefetched PCM -> mono -> scaled f16 pairs -> T), then
-//   stage 2   wave w: k1 = 2w+1, 2w+2 (wave 7: k1 = 15 and the special item) -> power rows P[f][bin] in LDS
+//   second half   stage 2: wave w takes k1 = 2w+1, 2w+2 (wave 7: k1 = 15 and the special item) -> power rows PT[bin][f];
+//                 the prefetched piece of the tile after next -> mono samples and their maxima; the piece two tiles
+//                 further is requested (two register sets: 64 KB per CU in flight)
 //   barrier 2
-//   mel       the banded f32 contraction of features_v2.hip on v_mfma_f32_16x16x4_f32 (same plan, same fragments)
+// Status (round 4): correct everywhere it applies (1-3e-7 per frame against the oracle) and SLOWER than features_v2
+// (1.70-1.77 ms against 1.13 ms on config 2), hence opt-in: at f32-grade accuracy a product costs three MFMAs plus the
+// f16-pair hand-over on the vector pipe, and with two waves per SIMD nothing covers a wave's dependent chains (matrix pipes
+// 34 % busy; DESIGN.md section 6d has the ablation table).
 #include "features_dev.hpp"
 
 // AF_V3_ABL (diagnostic builds only, scripts/ablate/): bit mask of work compiled OUT of the kernel to see what it costs.
