@@ -142,6 +142,14 @@ __device__ __forceinline__ unsigned wave_max_bits(float x)
     return m01 > m23 ? m01 : m23;
 }
 
+// |x| for the unit maximum: non-finite samples do not count (an Inf would push every other sample of the unit out of f16's
+// range; the frames that contain it come out non-finite either way, the others stay exact)
+__device__ __forceinline__ float finite_abs(float x)
+{
+    const float a = fabsf(x);
+    return a < __builtin_inff() ? a : 0.0f;
+}
+
 // the unit's power-of-two scale from the bit pattern of max |x|:  s = 2^(140 - E) puts the maximum into [2^13, 2^14);
 // c = 64 / s is what one factor of the power rows' scale is (X_acc = X s / 64)
 struct Scale {
@@ -470,8 +478,8 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
                         // (r = 2: quads 32..37 exist for tq < 6 only; the others read past the tile and are not used)
                         m[r][j] = S::mono(raw[r][j], sel);
                         if (r == 2 && tq >= kQuads - 32) m[r][j] = 0.0f;
-                        mx = fmaxf(mx, fabsf(m[r][j]));
-                        if (r == 2) mt = fmaxf(mt, fabsf(m[r][j]));        // the last 768 samples
+                        mx = fmaxf(mx, finite_abs(m[r][j]));
+                        if (r == 2) mt = fmaxf(mt, finite_abs(m[r][j]));        // the last 768 samples
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -489,8 +497,8 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         mn[r][j] = S::mono(nu1[r][j], sel);
-                        nx = fmaxf(nx, fabsf(mn[r][j]));
-                        if (r == 1) nt = fmaxf(nt, fabsf(mn[r][j]));
+                        nx = fmaxf(nx, finite_abs(mn[r][j]));
+                        if (r == 1) nt = fmaxf(nt, finite_abs(mn[r][j]));
                     }
                 const unsigned wm = wave_max_bits(nx);
                 const unsigned wt = w >= 5 ? wave_max_bits(nt) : 0u;
@@ -764,8 +772,8 @@ __global__ __launch_bounds__(kT, 2) void af_features_v3_kernel(const Params p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     mn[r][j] = S::mono(pf[PAR][r][j], sel);
-                    mx = fmaxf(mx, fabsf(mn[r][j]));
-                    if (r == 1) mt = fmaxf(mt, fabsf(mn[r][j]));
+                    mx = fmaxf(mx, finite_abs(mn[r][j]));
+                    if (r == 1) mt = fmaxf(mt, finite_abs(mn[r][j]));
                 }
             const unsigned wm = wave_max_bits(mx);
             // quads 32..37 (that tile's last 768 samples) are r = 1 of threads 320..511 = waves 5..7

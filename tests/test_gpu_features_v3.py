@@ -71,6 +71,25 @@ def test_v3_level_steps_inside_a_unit(af, po):
     assert np.all(z == 0.0)
 
 
+def test_v3_non_finite_samples_stay_local(af, po):
+    """A NaN and an Inf sample: the frames whose support contains one come out non-finite, every other frame -- also those
+    in the same 16-frame unit, whose tile scale must not be driven by the Inf -- matches the oracle of the clean signal."""
+    n = 1024 + 256 * 80
+    x = synth_clip(77, n, 1, 48000).copy()
+    clean = po.features(x, 1, 48000.0)
+    for pos, bad in ((5000, np.float32(np.nan)), (12345, np.float32(np.inf)), (17000, np.float32(-np.inf))):
+        y = x.copy()
+        y[pos] = bad
+        _, got = _run(af, [y], 1, 0, 3)
+        got = np.asarray(got, np.float64)
+        touched = np.array([(256 * f <= pos < 256 * f + 1024) for f in range(got.shape[0])])
+        assert not np.any(np.isfinite(got[touched]).all(axis=1))
+        ok = ~touched
+        assert np.all(np.isfinite(got[ok]))
+        err = np.linalg.norm(got[ok] - clean[ok], axis=1) / np.linalg.norm(clean[ok], axis=1)
+        assert err.max() < TOL, (pos, err.max())
+
+
 @pytest.mark.parametrize("kw", [dict(channel_mode=1), dict(n_mels=40), dict(n_mels=128, sample_rate=44100), dict(n_fft=512),
                                 dict(n_fft=256), dict(mel_scale=1, mel_norm=1), dict(n_mels=64, sample_rate=16000, channels=1)])
 def test_v3_other_configurations(af, po, kw):
