@@ -1,9 +1,10 @@
 """Numpy model of the MFMA formulation of the hop-256 feature kernel (features_v3.hip).
 
 Checks, on the CPU, (1) the index algebra of the 32 x 32 two-stage DFT with every twiddle and the
-window folded into the stage-1 matrices, (2) the accuracy of the f16 hi/lo operand split
-(three products per MAC: hi*hi + hi*lo + lo*hi, f32 accumulation) against a float64 rfft.
-Not a test and not shipped: a design aid kept for the record.
+window folded into the stage-1 matrices -- row order, scales and bin mapping as in the kernel --
+and (2) the accuracy of the f16-pair operands (x = hi + lo' / 2048; three products per MAC:
+hi*hi -> P1, hi*lo' + lo'*hi -> P2, f32 accumulation, value P1 + P2 / 2048) against a float64 rfft.
+tests/test_dft_mfma_model.py runs it; the kernel itself is checked on the GPU (tests/test_gpu_features_v3.py).
 """
 import numpy as np
 
@@ -18,7 +19,7 @@ def hann(n_fft=N):
     return w
 
 
-def stage1_matrix(n2, w, scale=16.0):
+def stage1_matrix(n2, w, scale=1.0 / 64.0):
     """A1[n2]: 32 rows x 32 (n1).  Rows 0..15: Re k1 = 0..15; rows 16..31: row 16 = Re k1 = 16 (untwiddled), 17..31 = Im k1 = 1..15."""
     n1 = np.arange(32)
     n = 32 * n1 + n2
@@ -31,45 +32,52 @@ def stage1_matrix(n2, w, scale=16.0):
     return A * scale
 
 
-def stage2_matrix(scale=16.0):
-    """A2: 64 rows x 32 (n2).  Row 16 rb + m: q = m >> 2, i = m & 3: k2 = 8 rb + 2 q + (i >> 1); type i & 1 (0 cos, 1 -sin)."""
+def k2_of(rb, m):
+    """row m of row block rb: q = m >> 2, i = m & 3  ->  k2 = 8 rb + 4 (q >> 1) + (q & 1) + 2 (i >> 1)  (features_v3.hip)"""
+    q, i = m >> 2, m & 3
+    return 8 * rb + 4 * (q >> 1) + (q & 1) + 2 * (i >> 1)
+
+
+def stage2_matrix(scale=1.0):
+    """A2: 64 rows x 32 (n2).  Row 16 rb + m is k2_of(rb, m); type m & 1 (0 cos, 1 -sin)."""
     n2 = np.arange(32)
     A = np.zeros((64, 32))
     for r in range(64):
         rb, m = divmod(r, 16)
-        q, i = m >> 2, m & 3
-        k2 = 8 * rb + 2 * q + (i >> 1)
+        k2 = k2_of(rb, m)
         ang = 2 * np.pi * n2 * k2 / 32
-        A[r] = -np.sin(ang) if (i & 1) else np.cos(ang)
+        A[r] = -np.sin(ang) if (m & 1) else np.cos(ang)
     return A * scale
 
 
-def stage2_special(scale=16.0):
+def stage2_special(scale=1.0):
     """A2s (k1 = 16): 32 rows (k2 = 0..15) x 32 (n2), the twiddle W64^n2 folded in."""
     n2 = np.arange(32)
     A = np.zeros((32, 32))
     for r in range(32):
         rb, m = divmod(r, 16)
-        q, i = m >> 2, m & 3
-        k2 = 8 * rb + 2 * q + (i >> 1)
+        k2 = k2_of(rb, m)
         ang = 2 * np.pi * n2 * (2 * k2 + 1) / 64
-        A[r] = -np.sin(ang) if (i & 1) else np.cos(ang)
+        A[r] = -np.sin(ang) if (m & 1) else np.cos(ang)
     return A * scale
 
 
 def split16(a):
+    """x -> (hi, lo') with hi = f16(x), lo' = f16((x - hi) 2048)"""
     hi = a.astype(np.float16)
-    lo = (a - hi.astype(np.float64)).astype(np.float16)
+    lo = ((a - hi.astype(np.float64)) * 2048.0).astype(np.float16)
     return hi.astype(np.float32), lo.astype(np.float32)
 
 
 def mm3(A, B, exact):
-    """A @ B the way the kernel does it: three f16 products per MAC, f32 accumulation (or exact float64)."""
+    """A @ B the way the kernel does it: P1 = hi hi, P2 = hi lo' + lo' hi (f32 accumulation), value P1 + P2 / 2048."""
     if exact:
         return A @ B
     ah, al = split16(A)
     bh, bl = split16(B)
-    return (ah @ bh + ah @ bl + al @ bh).astype(np.float32)
+    p1 = (ah @ bh).astype(np.float32)
+    p2 = (ah @ bl + al @ bh).astype(np.float32)
+    return (p1 + p2 * np.float32(1.0 / 2048.0)).astype(np.float32)
 
 
 def power_rows(x, n_frames, exact=True, n_fft=N):
@@ -89,36 +97,29 @@ def power_rows(x, n_frames, exact=True, n_fft=N):
     for n2 in range(32):
         B = xs[(HOP * f[None, :] + 32 * n1[:, None] + n2)]
         Y[:, n2, :] = mm3(stage1_matrix(n2, w), B, exact)
-    Y *= 2.0 ** -8                  # the kernel's scale in front of the f16 conversion
     A2 = stage2_matrix()
     A2s = stage2_special()
     P = np.zeros((F, 513))
-    inv = (2.0 ** -e * 2.0 ** 8 / 256.0) ** 2     # Xacc = 16 * (16 s Y 2^-8) -> X_true = Xacc * 2^-e * 2^8 / 256
+    inv = (64.0 * 2.0 ** -e) ** 2                 # X_acc = X s / 64 with s = 2^e: the mel rows are scaled by (64 / s)^2
     for k1 in range(1, 16):
         Yr, Yi = Y[k1], Y[16 + k1]               # [n2][f]
         a0 = mm3(A2, Yr, exact)
         a1 = mm3(A2, Yi, exact)
         for r in range(0, 64, 2):
-            rb, m = divmod(r, 16)
-            q, i = m >> 2, m & 3
-            k2 = 8 * rb + 2 * q + (i >> 1)
+            k2 = k2_of(*divmod(r, 16))
             re = a0[r] - a1[r + 1]
             im = a1[r] + a0[r + 1]
             b = k1 + 32 * k2 if k2 < 16 else (32 - k1) + 32 * (31 - k2)
             P[:, b] = (re * re + im * im) * inv
     # special: k1 = 0 (rows of A2 for k2 = 0..16), k1 = 16 (A2s)
     a0 = mm3(A2[:48], Y[0], exact)
-    for r in range(0, 34, 2):
-        rb, m = divmod(r, 16)
-        q, i = m >> 2, m & 3
-        k2 = 8 * rb + 2 * q + (i >> 1)
+    for r in range(0, 48, 2):
+        k2 = k2_of(*divmod(r, 16))
         if k2 <= 16:
             P[:, 32 * k2] = (a0[r] ** 2 + a0[r + 1] ** 2) * inv
     a16 = mm3(A2s, Y[16], exact)
     for r in range(0, 32, 2):
-        rb, m = divmod(r, 16)
-        q, i = m >> 2, m & 3
-        k2 = 8 * rb + 2 * q + (i >> 1)
+        k2 = k2_of(*divmod(r, 16))
         P[:, 16 + 32 * k2] = (a16[r] ** 2 + a16[r + 1] ** 2) * inv
     return P
 
