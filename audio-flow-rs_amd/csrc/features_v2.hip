@@ -38,6 +38,14 @@
 #ifndef AF_V2_ALL_SLOTS
 #define AF_V2_ALL_SLOTS 0
 #endif
+// AF_V2_PH (diagnostic builds only, scripts/ablate/v2_phases.sh): bit mask of PHASES compiled out, for the steady-clock
+// phase table of profiles/r05_v2_ablations.txt.  Results are garbage; every guard that bounds a global access stays in.
+//   1 arithmetic of FFT part 1 (window, radix-16, first twiddle)   2 arithmetic of FFT part 2 (radix-16, T2, radix-4, split)
+//   4 mel MFMAs   8 workgroup barriers   16 global stores   32 PCM prefetch loads   64 filterbank fragment loads
+//   128 the whole mel block (operand reads, MFMAs, stores)
+#ifndef AF_V2_PH
+#define AF_V2_PH 0
+#endif
 // staging loads of the next unit requested at the top of a unit; the others go out behind FFT part 1 (99: all at the top)
 #ifndef AF_V2_PF_EARLY
 #define AF_V2_PF_EARLY 99
@@ -54,7 +62,17 @@ namespace af {
 namespace feat {
 namespace v2 {
 
-__device__ __forceinline__ float abl_val(int lane, int i) { return (float)(lane + i) * 0.001f; }
+// (a stand-in for a value an ablated access would have delivered: lane-dependent, and opaque per use so that the
+// arithmetic behind it is neither folded nor hoisted out of the unit loop)
+__device__ __forceinline__ float abl_val(int lane, int i)
+{
+    float z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return (float)(lane + i) * 0.001f + z;
+}
+// (phase ablations) a value the compiler must have in a register here / a register whose content it cannot know
+__device__ __forceinline__ void abl_use(float v) { asm volatile("" : : "v"(v)); }
+__device__ __forceinline__ float abl_any() { float v; asm volatile("" : "=v"(v)); return v; }
 
 __device__ __forceinline__ constexpr int brev4(int x)
 {
@@ -223,7 +241,12 @@ __device__ __forceinline__ void fft_pair_1(const float (&s)[20], const float (&w
     // ---- stage 1: z[64 n1 + n2] = w * (a + i b); frame b = frame a shifted by
     // kHop samples = 4 registers.  The window multiply is fused into the twiddle-free first DIT
     // stage (element e holds input brev4(e): elements (e, e + 1) are inputs (na, na + 8)).
-    {
+    if constexpr (AF_V2_PH & 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { re[e] = s[e]; im[e] = win[e]; }
+#pragma unroll
+        for (int e = 16; e < 20; ++e) abl_use(s[e]);
+    } else {
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
             const int na = brev4(e), nb = na + 8;
@@ -234,7 +257,7 @@ __device__ __forceinline__ void fft_pair_1(const float (&s)[20], const float (&w
             im[e + 1] = __builtin_fmaf(s[na + 4], win[na], -mi);
         }
     }
-    fftr::dit_fft<16, 2>(re, im);                  // Y[k1] at element k1
+    if constexpr (!(AF_V2_PH & 1)) fftr::dit_fft<16, 2>(re, im);                  // Y[k1] at element k1
 
     // twiddle W1024^(n2 k1): this lane's row of the table holds (cos, sin) for k1 = 1..15 (k1 = 0 needs none), so
     // that every 16-byte piece is used whole: with k1 = 0 in the row hipcc dropped the unused first pair, re-cut the
@@ -251,6 +274,10 @@ __device__ __forceinline__ void fft_pair_1(const float (&s)[20], const float (&w
 #pragma unroll
             for (int jj = 0; jj < kTwEarly; ++jj) asm volatile("" : "+v"(twr[jj]));
         }
+        if constexpr (AF_V2_PH & 1) {
+#pragma unroll
+            for (int jj = kTwEarly; jj < 8; ++jj) { abl_use(late[jj].x); abl_use(late[jj].y); abl_use(late[jj].z); abl_use(late[jj].w); }
+        } else
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const float4 t = jj < kTwEarly ? float4{twr[jj < kTwEarly ? jj : 0][0], twr[jj < kTwEarly ? jj : 0][1],
@@ -314,12 +341,13 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
     // ---- stage 2a: radix-16 over m -> b.  Its twiddle W64^(c b) is applied AFTER the transposition below, where
     // c has become the register index and b = j + 4 b' has one lane-dependent part only: every lane keeps its
     // four w = W64^b (and w^2) in registers and no table row is read (was 8 ds_read_b128 per frame pair).
-    fftr::dit_fft<16>(ur, ui);
+    if constexpr (!(AF_V2_PH & 2)) fftr::dit_fft<16>(ur, ui);
 
     // ---- T2: lane (k1, j) needs U[k1][c][j + 4b'] for c = 0..3 from the four lanes (k1, c): per b' a
     // 4 x 4 transpose (lane row c, register j) -> (lane row j, register c) of registers 4b'..4b'+3,
     // done in registers: v_permlane32_swap exchanges rows {2, 3} of one register with rows {0, 1} of
     // another, v_permlane16_swap rows {1, 3} with rows {0, 2}.  Afterwards element 4b' + c holds U_c.
+    if constexpr (!(AF_V2_PH & 2))
 #pragma unroll
     for (int bp = 0; bp < 4; ++bp) {
         swap_rows32(ur[4 * bp], ur[4 * bp + 2]);
@@ -338,6 +366,7 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
     // E / O butterflies at compile time (fft_regs.hpp); w itself in the FMA form w = cos (1 - i tan) from
     // ltw[2 + 2b'], ltw[3 + 2b'] (angle <= 84.4 degrees).
     const float c2 = ltw[0], s2 = ltw[1];
+    if constexpr (!(AF_V2_PH & 2))
 #pragma unroll
     for (int bp = 0; bp < 4; ++bp) {
         const float t1 = ltw[2 + 2 * bp], c1 = ltw[3 + 2 * bp];
@@ -381,6 +410,11 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
             // t = 8 only matters for lane 0 (bin 512, its own register 8 = plane 0)
             const float pr = (AF_ABL & 128) ? ZR(15 - t) : t < 8 ? ex[(7 - t) * 64] : wb[pl];
             const float pi = (AF_ABL & 128) ? ZI(15 - t) : t < 8 ? ex[576 + (7 - t) * 64] : wb[576 + pl];
+            if constexpr (AF_V2_PH & 2) {
+                pa[t] = pr; pb[t] = pi;
+                if (t < 7) { abl_use(ZR(t)); abl_use(ZI(t)); }
+                continue;
+            }
             const float a1 = ZR(t) + pr, a2 = ZI(t) - pi;
             const float b1 = ZI(t) + pi, b2 = ZR(t) - pr;
             pa[t] = __builtin_fmaf(a1, a1, a2 * a2);
@@ -516,7 +550,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         const int64_t n_avail = ud.n_avail;
 
         if (fresh) {
-            __syncthreads();                         // nobody still reads the old tile / power rows
+            if constexpr (!(AF_V2_PH & 8)) __syncthreads();     // nobody still reads the old tile / power rows
 #pragma unroll
             for (int i = 0; i < kFreshIters; ++i) {
                 const int v = tid + i * kT;
@@ -527,7 +561,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                 }
             }
         }
-        __syncthreads();                             // B1: tile ready, previous mel phase done
+        if constexpr (!(AF_V2_PH & 8)) __syncthreads();         // B1: tile ready, previous mel phase done
         AF_STAMP2(1);
         // the next unit's record, a unit ahead (the table ends with one spare record)
         ud_next = load_desc(p.units, u + 1);
@@ -537,6 +571,10 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         uint4 pf[PFU];
         const auto issue_prefetch = [&](auto lo_c, auto hi_c) {
             constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+            if constexpr (AF_V2_PH & 32) {
+#pragma unroll
+                for (int i = LO; i < HI; ++i) pf[i] = uint4{0u, 0u, 0u, 0u};
+            } else
             if (has_next && LO < HI) {
                 // (lane offsets from an opaque copy of tid: hoisted out of the unit loop they end up in scratch,
                 // and a scratch reload waits for every outstanding vector memory operation)
@@ -574,7 +612,10 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             AF_STAMP2(2);
             // This wave's filterbank fragments (L2-resident, one float4 per slot), issued where the
             // register pressure has dropped and early enough to be back for the mel phase.
-            if constexpr (!POWER) {
+            if constexpr (!POWER && (AF_V2_PH & (64 | 128))) {
+#pragma unroll
+                for (int q = 0; q < NSLOT * kSlotSteps; ++q) wf[q] = abl_val(lane, q);
+            } else if constexpr (!POWER) {
                 int opaque_zero;                     // pins the loads here (and defeats hoisting)
                 asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
                 // (scalar base + 32-bit lane offset: a hoisted 64-bit lane pointer is one more loop-carried register pair)
@@ -594,7 +635,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         }
         AF_STAMP2(3);
 
-        __syncthreads();                             // B2: power rows ready, tile reads done
+        if constexpr (!(AF_V2_PH & 8)) __syncthreads();         // B2: power rows ready, tile reads done
         // the tile update and the mel phase hold up the next unit's FFT and issue few instructions:
         // let them go ahead of the other workgroup's FFT stream
         __builtin_amdgcn_s_setprio(AF_V2_BASE_PRIO ? 3 : 2);
@@ -632,7 +673,9 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             }
         }
 
-        if constexpr (!POWER) {
+        if constexpr (!POWER && (AF_V2_PH & 128)) {
+            abl_use(wf[0]);
+        } else if constexpr (!POWER) {
             // mel: banded W (A, registers) x P^T (B, bins x 16 frames from the power rows) on
             // v_mfma_f32_16x16x4_f32; all B operands first, then the chain; a slot that ends a group
             // sends the 16 frames x <= 16 filters accumulator to HBM (one 16-byte store per lane)
@@ -670,6 +713,11 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                 if (AF_V2_ALL_SLOTS || q < n_slots_w) {
 #pragma unroll
                     for (int st = q * kSlotSteps; st < (q + 1) * kSlotSteps; st += 2) {
+                        if constexpr (AF_V2_PH & 4) {
+                            acc0[st & 3] += wf[st] + bop[st];
+                            acc1[st & 3] += wf[st + 1] + bop[st + 1];
+                            continue;
+                        }
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], bop[st], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st + 1], bop[st + 1], acc1, 0, 0, 0);
                     }
@@ -686,6 +734,9 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                         float* o = obase + mm + row_off;            // uniform base + 32-bit lane offset
                         if constexpr (AF_ABL & 2048)                // (diagnostic: wrong place, 1 KB contiguous per instruction)
                             o = obase + (mm >> 4) * 256 + 4 * lane;
+                        if constexpr (AF_V2_PH & 16) {
+                            abl_use(r[0]); abl_use(r[1]); abl_use(r[2]); abl_use(r[3]);
+                        } else
                         if (vec_ok && ((cnt | mm) & 3) == 0) {      // wave-uniform choice
                             if (fvalid && i0 < cnt) *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
                         } else if (fvalid) {
