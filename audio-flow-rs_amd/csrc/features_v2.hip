@@ -46,12 +46,27 @@
 #ifndef AF_V2_PH
 #define AF_V2_PH 0
 #endif
+// AF_V2_CLK (diagnostic builds only): with stamps enabled the PRODUCT instance runs (not the stamping one) and every
+// workgroup adds its lifetime in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime) to stamps[0], [1] and
+// 1 to stamps[2]: the clock the chip holds inside this kernel = stamps[0] / stamps[1] x 100 MHz.
+#ifndef AF_V2_CLK
+#define AF_V2_CLK 0
+#endif
+// (experiment) cache policy nt on: 1 the PCM prefetch loads, 2 the mel row stores
+#ifndef AF_V2_NT
+#define AF_V2_NT 0
+#endif
 // staging loads of the next unit requested at the top of a unit; the others go out behind FFT part 1 (99: all at the top)
 #ifndef AF_V2_PF_EARLY
 #define AF_V2_PF_EARLY 99
 #endif
 #ifndef AF_V2_TW_EARLY
 #define AF_V2_TW_EARLY 0
+#endif
+// 1: the 16 new hops of unit u + 2 are requested behind the tile update of unit u (they fly through that unit's mel
+// phase and the whole of unit u + 1) instead of at the top of unit u + 1; 0: round 2-4's placement
+#ifndef AF_V2_PF_AHEAD
+#define AF_V2_PF_AHEAD 0
 #endif
 // issue priority of the kernel's waves outside their raised sections (experiment: 1 when it shares CUs with another kernel)
 #ifndef AF_V2_BASE_PRIO
@@ -509,6 +524,9 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     unsigned u = (unsigned)(p.total_units * bid / G);
     const unsigned u_end = (unsigned)(p.total_units * (bid + 1) / G);
     if (u >= u_end) return;
+#if AF_V2_CLK
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // tables -> LDS (visible after the first barrier)
     for (int i = tid; i < kTabFloats / 4; i += kT)
@@ -542,6 +560,8 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memtime() : 0;
     bool fresh = true;
+    bool pf_ready = false;                           // pf[] already holds / awaits the new hops of the next unit
+    uint4 pf[PFU];
     UnitDesc ud_next = load_desc(p.units, u);
     while (u < u_end) {
         const UnitDesc ud = ud_next;
@@ -568,33 +588,41 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         __builtin_amdgcn_sched_barrier(0);
 
         const bool has_next = (u + 1 < u_end) && (ud.flags & 1);
-        uint4 pf[PFU];
-        const auto issue_prefetch = [&](auto lo_c, auto hi_c) {
+        // requests the 16 new hops of the unit BEHIND unit `d` (whose tile starts at d.pcm0) into pf[LO..HI)
+        const auto issue_prefetch = [&](const UnitDesc& d, bool wanted, auto lo_c, auto hi_c) {
             constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
             if constexpr (AF_V2_PH & 32) {
 #pragma unroll
                 for (int i = LO; i < HI; ++i) pf[i] = uint4{0u, 0u, 0u, 0u};
             } else
-            if (has_next && LO < HI) {
+            if (wanted && LO < HI) {
                 // (lane offsets from an opaque copy of tid: hoisted out of the unit loop they end up in scratch,
                 // and a scratch reload waits for every outstanding vector memory operation)
                 const int t0 = opaque_tid(tid);
-                if (n_avail >= kTile + 16 * kHop) {  // wave-uniform: the new region lies inside the clip
+                if (d.n_avail >= kTile + 16 * kHop) {  // wave-uniform: the new region lies inside the clip
                     const char* src = static_cast<const char*>(p.pcm) +
-                                      (ud.pcm0 + kTile) * St::kBytesPerFrame;
+                                      (d.pcm0 + kTile) * St::kBytesPerFrame;
 #pragma unroll
-                    for (int i = LO; i < HI; ++i)
-                        pf[i] = *reinterpret_cast<const uint4*>(src + (unsigned)(t0 + i * kT) * 16u);
+                    for (int i = LO; i < HI; ++i) {
+                        const uint4* a = reinterpret_cast<const uint4*>(src + (unsigned)(t0 + i * kT) * 16u);
+                        if constexpr (AF_V2_NT & 1) {
+                            typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                            const u32x4v q = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(a));
+                            pf[i] = uint4{q[0], q[1], q[2], q[3]};
+                        } else {
+                            pf[i] = *a;
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int i = LO; i < HI; ++i)
-                        pf[i] = St::load_raw(p.pcm, ud.pcm0, kTile + (int64_t)(t0 + i * kT) * MS, n_avail, true);
+                        pf[i] = St::load_raw(p.pcm, d.pcm0, kTile + (int64_t)(t0 + i * kT) * MS, d.n_avail, true);
                 }
             }
         };
         // AF_V2_PF_EARLY of the PFU staging loads go out here, the rest behind part 1 (experiment: default all here)
         constexpr int kPfEarly = AF_V2_PF_EARLY < PFU ? AF_V2_PF_EARLY : PFU;
-        issue_prefetch(std::integral_constant<int, 0>{}, std::integral_constant<int, kPfEarly>{});
+        issue_prefetch(ud, has_next && !pf_ready, std::integral_constant<int, 0>{}, std::integral_constant<int, kPfEarly>{});
 
         float wf[NSLOT * kSlotSteps];
         {
@@ -607,7 +635,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             float s1[20], win[16];
             stage1_load(tile, w, lane, wtab, s1, win);
             fft_pair_1(s1, win, wb, wv, lane, tw1, ur, ui);
-            issue_prefetch(std::integral_constant<int, kPfEarly>{}, std::integral_constant<int, PFU>{});
+            issue_prefetch(ud, has_next && !pf_ready, std::integral_constant<int, kPfEarly>{}, std::integral_constant<int, PFU>{});
 
             AF_STAMP2(2);
             // This wave's filterbank fragments (L2-resident, one float4 per slot), issued where the
@@ -671,6 +699,15 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                 }
                 tile_store<MS>(tile, kTail + v * MS, m);
             }
+        }
+        if constexpr (AF_V2_PF_AHEAD) {
+            // The staging registers are free again: request the new hops of the unit AFTER next (they lie behind the
+            // next unit's tile; its record arrived a phase ago).  They are in flight through this mel phase and the whole
+            // next unit -- requested at the top of the next unit (rounds 2-4) they had one FFT's time, which the loaded
+            // HBM latency of a chip whose workgroups all request at the same moment exceeds (profiles/r05_v2_ablations.txt).
+            const bool has_next2 = has_next && (u + 2 < u_end) && (ud_next.flags & 1);
+            issue_prefetch(ud_next, has_next2, std::integral_constant<int, 0>{}, std::integral_constant<int, PFU>{});
+            pf_ready = has_next2;
         }
 
         if constexpr (!POWER && (AF_V2_PH & 128)) {
@@ -738,6 +775,9 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                             abl_use(r[0]); abl_use(r[1]); abl_use(r[2]); abl_use(r[3]);
                         } else
                         if (vec_ok && ((cnt | mm) & 3) == 0) {      // wave-uniform choice
+                            if constexpr (AF_V2_NT & 2) {
+                                if (fvalid && i0 < cnt) __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(o));
+                            } else
                             if (fvalid && i0 < cnt) *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
                         } else if (fvalid) {
                             if (i0 < cnt) o[0] = r[0];
@@ -768,6 +808,13 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         if (lane == 0 && w < 4)
             for (int i = 0; i < 8; ++i) atomicAdd(p.stamps + w * 8 + i, acc_t[i]);
     }
+#if AF_V2_CLK
+    if (p.stamps && tid == 0) {
+        atomicAdd(p.stamps, __builtin_amdgcn_s_memtime() - clk_t0);
+        atomicAdd(p.stamps + 1, __builtin_amdgcn_s_memrealtime() - clk_r0);
+        atomicAdd(p.stamps + 2, 1ull);
+    }
+#endif
 }
 
 template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS, bool POWER>
@@ -800,9 +847,11 @@ static af_status launch_fmt(const Params& p, bool separate, int grid, hipStream_
     if constexpr (CH == 2) {
         if (separate) return launch_k<CH, I16, true, 8>(p, grid, stream);
     }
+#if !AF_V2_CLK
     if constexpr (CH == 2 && !I16) {
         if (p.stamps) return launch_k<CH, I16, false, 8, true>(p, grid, stream);
     }
+#endif
     if (most <= 6) return launch_k<CH, I16, false, 6>(p, grid, stream);
     return launch_k<CH, I16, false, 8>(p, grid, stream);
 }

@@ -11,6 +11,7 @@ ffi = importlib.util.module_from_spec(spec); spec.loader.exec_module(ffi)
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20); ap.add_argument("--warm", type=int, default=30)
 ap.add_argument("--clips", type=int, default=256); ap.add_argument("libs", nargs="+")
+ap.add_argument("--clk", action="store_true", help="AF_V2_CLK builds: also print the in-kernel clock (s_memtime / s_memrealtime)")
 ap.add_argument("--kernel", type=int, default=-1, help="af_features_set_option kernel (1 general, 2 features_v2, 3 features_v3)")
 a = ap.parse_args()
 n = 1440000
@@ -21,7 +22,8 @@ for path in a.libs:
     # RTLD_LOCAL: every build resolves its own symbols (RTLD_GLOBAL would bind later builds to the first one's)
     lib = C.CDLL(os.path.abspath(path), mode=os.RTLD_LOCAL | os.RTLD_NOW)
     for name in ("af_features_default_config", "af_features_create", "af_features_set_batch_uniform",
-                 "af_features_run_device", "af_features_destroy", "af_last_error", "af_features_set_option"):
+                 "af_features_run_device", "af_features_destroy", "af_last_error", "af_features_set_option",
+                 "af_features_debug_stamps"):
         fn = getattr(lib, name); fn.restype, fn.argtypes = ffi.SIGNATURES[name]
     cfg = ffi.FeaturesConfig(); lib.af_features_default_config(C.byref(cfg))
     h = C.c_void_p(); assert lib.af_features_create(C.byref(cfg), C.byref(h)) == 0
@@ -34,5 +36,14 @@ for path in a.libs:
     e0.record()
     for _ in range(a.reps): assert lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), s) == 0
     e1.record(); torch.cuda.synchronize()
-    print(f"{os.path.basename(path):28s} {e0.elapsed_time(e1) / a.reps:8.4f} ms", flush=True)
+    clk = ""
+    if a.clk:
+        import numpy as np
+        assert lib.af_features_debug_stamps(h, 1, None) == 0
+        for _ in range(10): assert lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), s) == 0
+        torch.cuda.synchronize()
+        st = np.zeros(32, np.uint64)
+        assert lib.af_features_debug_stamps(h, 0, st.ctypes.data) == 0
+        if st[1]: clk = f"   in-kernel clock {float(st[0]) / float(st[1]) * 0.1:6.3f} GHz, {float(st[0]) / float(st[2]) / 1e6:6.3f} M cycles per workgroup"
+    print(f"{os.path.basename(path):28s} {e0.elapsed_time(e1) / a.reps:8.4f} ms{clk}", flush=True)
     lib.af_features_destroy(h)
