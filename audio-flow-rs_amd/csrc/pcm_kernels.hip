@@ -74,7 +74,10 @@ __global__ void to_mono_kernel(const float* __restrict__ in, size_t n_samples, u
          f += stride) {
         const size_t b = f * channels;
         const size_t e = b + channels < n_samples ? b + channels : n_samples;
-        float sum = 0.0f;
+        // capture.rs:36 `chunk.iter().sum::<f32>()`: a left fold from the additive identity -0.0 (what `impl Sum for f32`
+        // folds from in the toolchains edition 2024 needs; docs/OPS.md "to_mono"), i.e. x0 + x1 + ... with nothing in
+        // front: a frame of all -0.0 stays -0.0, as in to_mono2_kernel's (L + R) / 2 and in every fused load
+        float sum = -0.0f;
         for (size_t j = b; j < e; ++j) sum = sum + in[j];   // left fold, f32
         out[f] = sum / (float)channels;
     }

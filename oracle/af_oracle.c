@@ -24,7 +24,12 @@
 
 /* capture.rs:30-42.  `.chunks(channels)` yields a final short chunk when
  * n % channels != 0; its partial sum is still divided by `channels`
- * (capture.rs:37-38).  `iter().sum::<f32>()` is a left fold. */
+ * (capture.rs:37-38).  `iter().sum::<f32>()` is a left fold from the additive
+ * identity -0.0: the reference is edition 2024 (src-tauri/Cargo.toml:4), i.e.
+ * rustc >= 1.85, whose `impl Sum for f32` folds from -0.0 (std changed the
+ * seed from +0.0 in 1.83; recollection, not verifiable offline).  The seed
+ * only shows in a frame whose samples are all -0.0: -0.0 here, +0.0 with the
+ * older seed (docs/OPS.md "to_mono"). */
 size_t afo_to_mono(const float* in, size_t n, unsigned channels, float* out)
 {
     if (channels == 0) return 0;
@@ -35,7 +40,7 @@ size_t afo_to_mono(const float* in, size_t n, unsigned channels, float* out)
     size_t n_out = 0;
     for (size_t i = 0; i < n; i += channels) {
         size_t end = i + channels < n ? i + channels : n;
-        volatile float sum = 0.0f;             /* volatile: keep f32 rounding */
+        volatile float sum = -0.0f;            /* volatile: keep f32 rounding */
         for (size_t j = i; j < end; ++j) sum = sum + in[j];
         out[n_out++] = sum / (float)channels;  /* capture.rs:38 */
     }

@@ -5,7 +5,7 @@ the float64 oracle chain at the docs/OPS.md tolerance."""
 import numpy as np
 import pytest
 
-from util import frame_rel_err, synth_clip
+from util import bits_equal, frame_rel_err, synth_clip
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -87,7 +87,7 @@ def test_chain_fused_stage_equals_separate_launches(af, ch, fi, fo, K, n_clips, 
     assert bool(torch.isfinite(out[0]).all())
     assert chain.n_launches() == 2
     if 34 <= K <= 65 or 98 <= K <= 129 or K == 1:
-        assert torch.equal(out[0], out[1])
+        assert bits_equal(out[0], out[1])
     else:
         rel = (out[0] - out[1]).norm(dim=1) / out[1].norm(dim=1).clamp_min(1e-30)
         assert float(rel.max()) < 2e-6
@@ -117,7 +117,7 @@ def test_chain_config4_per_gpu_share(af, po):
     chain.run_device(pcm.data_ptr(), mel2.data_ptr(), stream)
     torch.cuda.synchronize()
     m = mel.view(n_clips, nf, 80)
-    assert bool(torch.isfinite(mel).all()) and torch.equal(mel, mel2) and torch.equal(m[1023], m[5])
+    assert bool(torch.isfinite(mel).all()) and bits_equal(mel, mel2) and bits_equal(m[1023], m[5])
     for c in (0, 512, 1022):
         ref = oracle_chain(po, pcm[c].cpu().numpy().reshape(-1), 2, 48000, 16000, taps)
         assert frame_rel_err(m[c].cpu().numpy(), ref) < 2e-5
@@ -143,7 +143,7 @@ def test_streaming_chunks_equal_one_shot_bit_exact(af, po):
     n_st = st.set_batch_spans(starts, lengths)
     assert n_st == n_one == po.stft_n_frames(100000)            # same frames, same order
     chunked = st.run(x)
-    assert np.array_equal(chunked, full)                         # bit-exact
+    assert bits_equal(chunked, full)                         # bit-exact
     assert frame_rel_err(full, po.features(x, 2, 48000.0)) < TOL
 
 
@@ -184,7 +184,7 @@ def test_streaming_step_by_step_with_hipgraph(af, po):
     one.set_batch_uniform(1, n_total)
     full = one.run(x)
     assert got.shape == full.shape == (n_steps * frames_per_step, 80)
-    assert np.array_equal(got, full)                             # same frame indices, same bits
+    assert bits_equal(got, full)                             # same frame indices, same bits
 
 
 def test_chain_is_capturable_without_a_warm_up(af, po):
@@ -231,7 +231,7 @@ def test_feature_stream_small_steps_vs_one_shot_and_oracle(af, po):
         assert got.shape[0] == st.total_rows(n) == po.stft_n_frames(n)          # bookkeeping exact
         one = af.FeaturePipeline(channels=ch, sample_format=fmt)
         one.set_batch_uniform(1, n)
-        assert np.array_equal(got, one.run(x))                                    # bit for bit
+        assert bits_equal(got, one.run(x))                                    # bit for bit
         if got.shape[0]:
             xf = x.astype(np.float32) / np.float32(32768.0) if fmt else x
             assert frame_rel_err(got, po.features(xf, ch, 48000.0)) < TOL
@@ -263,7 +263,7 @@ def test_feature_stream_ten_minutes_bit_equal_to_one_shot(af):
     one = af.FeaturePipeline()
     one.set_batch_uniform(1, n)
     full = one.run(x.reshape(-1))
-    assert np.array_equal(got, full)
+    assert bits_equal(got, full)
     # per-step latency (device time of the replayed graph incl. both PCIe copies, and host wall time)
     print(f"\nfeature stream: {len(dev_ms)} steps of {step / sr:.1f} s audio; device ms/step "
           f"median {np.median(dev_ms):.2f} max {np.max(dev_ms):.2f}; wall ms/step median {np.median(wall_ms):.2f}; "
@@ -313,7 +313,7 @@ def test_feature_stream_eight_hours_config5(af):
     full = torch.empty(total, 80, device=dev)
     one.run_device(pcm.data_ptr(), full.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert torch.equal(rows, full.cpu())
+    assert bits_equal(rows, full.cpu())
     print(f"\n8 h stream: {st.stats()['steps']} steps, wall ms per step median {np.median(wall):.2f}, "
           f"{n / sr / (np.median(wall) * 1e-3 * st.stats()['steps']):.0f}x real time on the step path alone")
 
@@ -347,7 +347,7 @@ def test_chain_ragged_and_i16_fused_equals_unfused_and_oracle(af, po, ch, fmt):
     assert chain.n_launches() > 2
     staged = chain.run(pcm)
     chain.set_option("unfused", -1)
-    assert np.array_equal(fused, staged)
+    assert bits_equal(fused, staged)
     row = 0
     for x, nf in zip(clips, nfs):
         if nf:
@@ -359,7 +359,7 @@ def test_chain_ragged_and_i16_fused_equals_unfused_and_oracle(af, po, ch, fmt):
     uni.set_batch_uniform(1, lens[4])
     x4 = clips[4] if not fmt else _as_i16(clips[4])
     r0 = sum(nfs[:4])
-    assert np.array_equal(uni.run(x4), fused[r0:r0 + nfs[4]])
+    assert bits_equal(uni.run(x4), fused[r0:r0 + nfs[4]])
 
 
 def test_chain_mono_i16_odd_lengths(af, po):
@@ -380,13 +380,13 @@ def test_chain_mono_i16_odd_lengths(af, po):
         chain.set_option("unfused", 1)
         staged = chain.run(x)
         chain.set_option("unfused", -1)
-        assert np.array_equal(fused, staged), n
+        assert bits_equal(fused, staged), n
         xf = x.astype(np.float32) / np.float32(32768.0)
         assert frame_rel_err(fused, oracle_chain(po, xf, 1, 48000, 16000, taps)) < 2e-5
         # behind the clip sits a loud sample that must not leak into its last frame
         pad = np.concatenate([x, np.array([32767], np.int16)])
         chain.set_batch(np.array([0, n], np.int64))
-        assert np.array_equal(chain.run(pad), fused), n
+        assert bits_equal(chain.run(pad), fused), n
     # ragged: even clips, the last one odd (its base stays even, the fused launch applies)
     lens = [40000, 11520 * 2, 3 * (1024 + 256 * 9) + 1]
     clips = [_as_i16(synth_clip(920 + i, m, 1, 48000)) for i, m in enumerate(lens)]
@@ -395,7 +395,7 @@ def test_chain_mono_i16_odd_lengths(af, po):
     assert chain.n_launches() == 2
     fused = chain.run(np.concatenate(clips))
     chain.set_option("unfused", 1)
-    assert np.array_equal(chain.run(np.concatenate(clips)), fused)
+    assert bits_equal(chain.run(np.concatenate(clips)), fused)
     chain.set_option("unfused", -1)
     row = 0
     for xc, m in zip(clips, lens):
@@ -413,7 +413,7 @@ def test_chain_mono_i16_odd_lengths(af, po):
     one.set_batch_uniform(1, n)
     nf = one.n_frames(n)
     for i, xc in enumerate(clips):
-        assert np.array_equal(got[i * nf:(i + 1) * nf], one.run(xc))
+        assert bits_equal(got[i * nf:(i + 1) * nf], one.run(xc))
 
 
 @pytest.mark.parametrize("fi,fo,ch,fmt,with_fir", [(44100, 16000, 2, 0, True), (44100, 16000, 1, 1, True),
@@ -442,7 +442,7 @@ def test_chain_ragged_without_a_fused_plan(af, po, fi, fo, ch, fmt, with_fir):
         if nf:
             alone.set_batch_uniform(1, n)
             one = alone.run(x.reshape(-1))
-            assert np.array_equal(mel[row:row + nf], one)
+            assert bits_equal(mel[row:row + nf], one)
             xf = x.astype(np.float32) / 32768.0 if fmt else x
             assert frame_rel_err(mel[row:row + nf], oracle_chain(po, xf, ch, fi, fo, taps)) < 2e-5
         row += nf
@@ -467,7 +467,7 @@ def test_chain_ragged_strip_many_clips(af):
     for i in (0, 1, 299, 598, 599):
         alone.set_batch_uniform(1, lens[i])
         one = alone.run(x[offs[i]:offs[i + 1]].reshape(-1))
-        assert np.array_equal(mel[rows[i]:rows[i + 1]], one)
+        assert bits_equal(mel[rows[i]:rows[i + 1]], one)
     assert rows[-1] == mel.shape[0]
 
 
@@ -484,9 +484,9 @@ def test_chain_pipelined_form_same_bits(af):
     for k in (1, 3, 8, 37, 64):
         chain.set_option("pipeline", k)
         assert chain.n_launches() == 2 * min(k, n_clips)
-        assert np.array_equal(chain.run(x), ref)
+        assert bits_equal(chain.run(x), ref)
     chain.set_option("pipeline", 0)
-    assert chain.n_launches() == 2 and np.array_equal(chain.run(x), ref)
+    assert chain.n_launches() == 2 and bits_equal(chain.run(x), ref)
 
 
 def test_chain_ragged_random_configurations(af, po):
@@ -517,7 +517,7 @@ def test_chain_ragged_random_configurations(af, po):
             if nf:
                 alone.set_batch_uniform(1, n)
                 one = alone.run(x.reshape(-1))
-                assert np.array_equal(mel[row:row + nf], one), (case, fi, fo, ch, fmt, K, lens)
+                assert bits_equal(mel[row:row + nf], one), (case, fi, fo, ch, fmt, K, lens)
                 if not checked:
                     xf = x.astype(np.float32) / 32768.0 if fmt else x
                     assert frame_rel_err(one, oracle_chain(po, xf, ch, fi, fo, taps)) < 3e-5, (case, fi, fo, ch, fmt, K)
@@ -545,7 +545,7 @@ def test_chain_ragged_strip_more_clips_than_a_grid_dimension(af):
     for i in (7, 40000, 65999):
         alone.set_batch_uniform(1, int(lens[i]))
         one = alone.run(x[offs[i]:offs[i + 1]].reshape(-1))
-        assert np.array_equal(mel[row:row + one.shape[0]], one)
+        assert bits_equal(mel[row:row + one.shape[0]], one)
         row += one.shape[0]
     assert row == mel.shape[0]
 
@@ -572,7 +572,7 @@ def test_chain_ragged_strip_in_groups_beyond_2_30_samples(af):
     for i in (0, 213, 214, 215, 239):                                 # (the cut falls behind clip 213 or 214)
         alone.set_batch_uniform(1, int(lens[i]))
         one = alone.run(pcm[offs[i]:offs[i + 1]].cpu().numpy())
-        assert np.array_equal(mel[rows[i]:rows[i + 1]].cpu().numpy(), one)
+        assert bits_equal(mel[rows[i]:rows[i + 1]].cpu().numpy(), one)
 
 
 # ---- ChainStream (af_chain_stream_*): config 5 on the whole chain ----------------------------------------------
@@ -601,7 +601,7 @@ def test_chain_stream_small_steps_equal_one_shot(af, po, ch, fmt, n):
     assert got.shape[0] == st.total_rows(n) == one.n_frames(n)
     if n:
         full = one.run(x)
-        assert np.array_equal(got, full)
+        assert bits_equal(got, full)
         if got.shape[0]:
             xf = x.astype(np.float32) / np.float32(32768.0) if fmt else x
             assert frame_rel_err(got, oracle_chain(po, xf, ch, 48000, 16000, taps)) < 2e-5
@@ -640,7 +640,7 @@ def test_chain_stream_ten_minutes_bit_equal_to_one_shot(af):
     full = one.run(x.reshape(-1))
     need0 = st.step_frames + 3 * 767 + 33                     # step 0 also needs the STFT halo and the resampler's look-ahead
     assert got.shape == full.shape == (st.total_rows(n), 80) and st.stats()["steps"] == 1 + (n - need0) // st.step_frames == 26
-    assert np.array_equal(got, full)
+    assert bits_equal(got, full)
     step_s = st.step_frames / sr
     print(f"\nchain stream: {len(dev_ms)} replayed steps of {step_s:.1f} s audio; device ms/step median "
           f"{np.median(dev_ms):.2f} max {np.max(dev_ms):.2f}; wall ms/step median {np.median(wall_ms):.2f}; "
@@ -677,13 +677,13 @@ def test_chain_stream_time_sharded_equals_one_shot(af, ch, fmt, world):
         r = st.push(x[lo:hi])
         rps = st.step_frames // 3 // 256                          # rows per step: 48 k -> 16 k, hop 256
         assert r.shape[0] == (k1 - k0) * rps
-        assert np.array_equal(r, full[k0 * rps:k1 * rps])
+        assert bits_equal(r, full[k0 * rps:k1 * rps])
         rows.append(r)
         if flush:
             rows.append(st.flush())
     got = np.concatenate(rows)
     assert got.shape == full.shape
-    assert np.array_equal(got, full)
+    assert bits_equal(got, full)
     # a rank that is handed too few frames for its history cannot flush
     st.seek(3)
     st.push(x[:100])
@@ -692,7 +692,7 @@ def test_chain_stream_time_sharded_equals_one_shot(af, ch, fmt, world):
     # seek(0) is a plain restart
     assert st.seek(0) == 0
     r0 = st.push(x[:st.first_step_frames])
-    assert np.array_equal(r0, full[:r0.shape[0]])
+    assert bits_equal(r0, full[:r0.shape[0]])
 
 
 def test_chain_stream_needs_the_fused_launch(af):
@@ -711,5 +711,5 @@ def test_features_per_handle_option(af):
     lib = af.library()
     assert lib.af_features_set_option(a._h, b"kernel", 1) == 0
     gen = a.run(x)
-    assert np.array_equal(b.run(x), base)                        # b still on the hop-256 kernel
+    assert bits_equal(b.run(x), base)                        # b still on the hop-256 kernel
     assert frame_rel_err(gen, base) < 2e-6 and lib.af_features_set_option(a._h, b"bogus", 1) != 0

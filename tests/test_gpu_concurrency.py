@@ -7,7 +7,7 @@ import threading
 import numpy as np
 import pytest
 
-from util import synth_clip
+from util import bits_equal, synth_clip
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +52,7 @@ def test_handles_on_four_threads_at_once(af):
     for t in range(4):
         for rep in got[t]:
             for a, b in zip(rep, ref[t]):
-                assert np.array_equal(a, b), t
+                assert bits_equal(a, b), t
 
 
 def test_error_text_is_per_thread(af):

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from util import frame_rel_err, synth_clip
+from util import bits_equal, frame_rel_err, synth_clip
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -140,7 +140,7 @@ def test_other_filterbanks(af, po, sr, n_mels):
     ref = po.features(x, 1, float(sr), n_mels=n_mels)
     assert frame_rel_err(mel, ref) < TOL
     # the device's filterbank is the oracle's, rounded to f32
-    assert np.array_equal(pipe.mel_weights(), po.mel_weights(float(sr), n_mels=n_mels).astype(np.float32))
+    assert bits_equal(pipe.mel_weights(), po.mel_weights(float(sr), n_mels=n_mels).astype(np.float32))
 
 
 def test_process_batch_surface(af, po):
@@ -206,12 +206,12 @@ def test_full_size_properties(af, po):
     assert bool(torch.isfinite(mel).all())         # every row written
     m = mel.view(n_clips, nf, 80)
     # 1. a clip's result does not depend on where it sits in the batch (bit-exact)
-    assert torch.equal(m[7], m[3]) and torch.equal(m[255], m[0])
+    assert bits_equal(m[7], m[3]) and bits_equal(m[255], m[0])
     # 2. determinism: a second launch reproduces every bit
     mel2 = torch.empty_like(mel)
     pipe.run_device(pcm.data_ptr(), mel2.data_ptr(), stream)
     torch.cuda.synchronize()
-    assert torch.equal(mel, mel2)
+    assert bits_equal(mel, mel2)
     # 3. power-of-two scaling is exact: x*2 -> mel*4
     pcm2 = pcm[:4] * 2.0
     pipe4 = af.FeaturePipeline()
@@ -219,7 +219,7 @@ def test_full_size_properties(af, po):
     mel4 = torch.empty(4 * nf, 80, device=dev)
     pipe4.run_device(pcm2.data_ptr(), mel4.data_ptr(), stream)
     torch.cuda.synchronize()
-    assert torch.equal(mel4.view(4, nf, 80), m[:4] * 4.0)
+    assert bits_equal(mel4.view(4, nf, 80), m[:4] * 4.0)
     # 4. sampled clips against the float64 oracle
     for c in (0, 131, 254):
         ref = po.features(pcm[c].cpu().numpy().reshape(-1), ch, 48000.0)
@@ -247,18 +247,18 @@ def test_host_buffer_path_is_chunked_and_identical(af):
     torch.cuda.synchronize()
     ref = ref.cpu().numpy()
     got_pageable = pipe.run(pinned.numpy().copy())                   # a fresh pageable copy
-    assert np.array_equal(got_pageable, ref)
+    assert bits_equal(got_pageable, ref)
     out = torch.empty(total, 80).pin_memory()
     st = af.library().af_features_run(pipe._h, C.c_void_p(pinned.data_ptr()), pinned.numel(),
                                       C.c_void_p(out.data_ptr()), out.numel())
-    assert st == 0 and np.array_equal(out.numpy(), ref)
+    assert st == 0 and bits_equal(out.numpy(), ref)
     # separate channels: a clip's two table entries stay in one chunk
     sep = af.FeaturePipeline(channel_mode=af._ffi.AF_CH_SEPARATE)
     tot2 = sep.set_batch(offs)
     ref2 = torch.empty(tot2, 80, device=dev)
     sep.run_device(d.data_ptr(), ref2.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert np.array_equal(sep.run(pinned.numpy()), ref2.cpu().numpy())
+    assert bits_equal(sep.run(pinned.numpy()), ref2.cpu().numpy())
 
 
 def test_many_ragged_clips_stress(af, po):
@@ -342,5 +342,5 @@ def test_hop256_kernel_on_clips_off_16_byte_boundaries(af, po, ch, fmt):
         alone = af.FeaturePipeline(channels=ch, sample_format=fmt)
         alone.set_batch_uniform(1, n)
         if not (ch == 1 and fmt == 1):
-            assert np.array_equal(alone.run(x), got[row:row + nf])
+            assert bits_equal(alone.run(x), got[row:row + nf])
         row += nf

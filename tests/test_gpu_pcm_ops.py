@@ -7,7 +7,7 @@ import base64
 import numpy as np
 import pytest
 
-from util import synth_clip
+from util import bits_equal, synth_clip
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,7 @@ def test_to_mono_reference_vectors(af):
     assert m.channels == 1 and m.samples.size == 2
     assert abs(m.samples[0] - 0.375) < 0.001 and abs(m.samples[1] + 0.375) < 0.001
     m1 = af.AudioFrame.new([0.5, -0.5], 16000, 1, 1000).to_mono()               # capture.rs:372-382
-    assert np.array_equal(m1.samples, np.array([0.5, -0.5], np.float32))
+    assert bits_equal(m1.samples, np.array([0.5, -0.5], np.float32))
 
 
 @pytest.mark.parametrize("channels", [1, 2, 3, 4, 6])
@@ -28,7 +28,86 @@ def test_to_mono_bit_exact(af, po, channels, n):
     got = af.to_mono(x, channels)
     want = po.to_mono(x, channels)
     assert got.size == want.size == (n if channels == 1 else -(-n // channels))
-    assert np.array_equal(got, want)
+    assert bits_equal(got, want)
+
+
+def _signed_zero_frames(channels: int, n_frames: int, tail: int = 0) -> np.ndarray:
+    """Interleaved frames cycling through the signed-zero cases: all -0.0, all +0.0, -0.0 first then +0.0s, +0.0 first
+    then -0.0s, a value among -0.0s, opposite values (sum +0.0), -0.0s behind a value; `tail` extra samples of -0.0
+    (a trailing partial frame, `chunks` semantics)."""
+    nz, pz = np.float32(-0.0), np.float32(0.0)
+    pats = [[nz] * channels, [pz] * channels, [nz] + [pz] * (channels - 1), [pz] + [nz] * (channels - 1),
+            [nz] * (channels - 1) + [np.float32(-1.5)], [np.float32(0.25), np.float32(-0.25)] + [nz] * (channels - 2),
+            [np.float32(0.75)] + [nz] * (channels - 1)]
+    x = np.array([pats[i % len(pats)] for i in range(n_frames)], np.float32).reshape(-1)
+    return np.concatenate([x, np.full(tail, nz, np.float32)])
+
+
+@pytest.mark.parametrize("channels,n_frames,tail", [(2, 7, 0), (2, 7, 1), (2, 20011, 0), (2, 20011, 1), (3, 7, 2), (3, 5000, 1),
+                                                    (4, 7, 3), (4, 5000, 0), (6, 33, 5)])
+def test_to_mono_signed_zero(af, po, channels, n_frames, tail):
+    """docs/OPS.md "to_mono", the fold's seed: `chunk.iter().sum()` (capture.rs:36) folds from -0.0, so a frame of all
+    -0.0 stays -0.0; to_mono2_kernel (stereo pairs), to_mono_kernel (everything else, incl. the tail of a stereo buffer)
+    and the oracle give the same BITS on every signed-zero case."""
+    x = _signed_zero_frames(channels, n_frames, tail)
+    got, want = af.to_mono(x, channels), po.to_mono(x, channels)
+    assert bits_equal(got, want)
+    assert np.signbit(got[0]) and not np.signbit(got[1])            # all -0.0 -> -0.0, all +0.0 -> +0.0
+    assert not np.signbit(got[2]) and not np.signbit(got[3])         # mixed zeros -> +0.0
+    assert got[5] == 0.0 and not np.signbit(got[5])                  # x + (-x) = +0.0
+    if tail:
+        assert np.signbit(got[-1])                                   # the partial frame of -0.0s
+
+
+def test_to_mono_signed_zero_device_both_kernels(af, po):
+    """A stereo buffer long enough that the pair kernel takes the bulk and the general kernel the rest: same bits."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    x = _signed_zero_frames(2, 300001, 1)
+    dev = torch.device("cuda:0")
+    xd = torch.from_numpy(x).to(dev)
+    out = torch.empty((x.size + 1) // 2, device=dev)
+    assert af.library().af_to_mono_device(C.c_void_p(xd.data_ptr()), x.size, 2, C.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert bits_equal(out.cpu().numpy(), po.to_mono(x, 2))
+
+
+def _stereo_with_signed_zero_blocks(n_frames: int, seed: int) -> np.ndarray:
+    """[n_frames, 2] f32: a synthetic clip with stretches of (-0.0, -0.0), (-0.0, +0.0), (+0.0, -0.0) and (x, -x) frames."""
+    x = synth_clip(seed, n_frames, 2, 48000).reshape(n_frames, 2).copy()
+    q = n_frames // 8
+    x[q:q + 700] = np.float32(-0.0)
+    x[2 * q:2 * q + 300, 0] = np.float32(-0.0); x[2 * q:2 * q + 300, 1] = np.float32(0.0)
+    x[3 * q:3 * q + 300, 0] = np.float32(0.0); x[3 * q:3 * q + 300, 1] = np.float32(-0.0)
+    x[4 * q:4 * q + 500, 1] = -x[4 * q:4 * q + 500, 0]
+    x[-5:] = np.float32(-0.0)
+    return x
+
+
+def test_fused_downmix_equals_to_mono_on_signed_zeros(af, po):
+    """The fused loads ((L + R) * 0.5 in the feature, resampler and chain kernels) against the stand-alone to_mono in
+    front of the mono form of the same kernel, on input full of signed zeros: identical bits."""
+    n = 48000
+    x = _stereo_with_signed_zero_blocks(n, 3)
+    mono = af.to_mono(x.reshape(-1), 2)
+    assert bits_equal(mono, po.to_mono(x.reshape(-1), 2))
+    q = n // 8
+    assert np.signbit(mono[q:q + 700]).all() and not np.signbit(mono[2 * q:2 * q + 300]).any()
+    # feature kernel (hop 256: features_v2; hop 160: the general kernel)
+    for hop in (256, 160):
+        f2 = af.FeaturePipeline(sample_rate=48000, channels=2, hop=hop)
+        f1 = af.FeaturePipeline(sample_rate=48000, channels=1, hop=hop)
+        f2.set_batch_uniform(1, n); f1.set_batch_uniform(1, n)
+        assert bits_equal(f2.run(x), f1.run(mono))
+    # resampler with stereo staging (one block matrix: 48 -> 16 kHz; ten: 44.1 -> 16 kHz), against to_mono + mono resampler
+    for rin, rout in ((48000, 16000), (44100, 16000)):
+        assert bits_equal(af.resample_stereo_batch(x.reshape(1, -1), rin, rout), af.resample_batch(mono[None, :], rin, rout))
+    # chain: stereo in (downmix fused into the first launch) against mono in
+    taps = np.hamming(129).astype(np.float32); taps /= taps.sum()
+    c2 = af.ChainPipeline(input_rate=48000, channels=2, output_rate=16000, fir_taps=taps)
+    c1 = af.ChainPipeline(input_rate=48000, channels=1, output_rate=16000, fir_taps=taps)
+    c2.set_batch_uniform(1, n); c1.set_batch_uniform(1, n)
+    assert bits_equal(c2.run(x), c1.run(mono))
 
 
 def test_to_mono_full_size_round_trip(af, po):
@@ -42,14 +121,14 @@ def test_to_mono_full_size_round_trip(af, po):
                                         C.c_void_p(out.data_ptr()), None)
     assert st == 0
     torch.cuda.synchronize()
-    assert torch.equal(out, (x[:, 0] + x[:, 1]) / 2)           # exact: one add, one halving
+    assert bits_equal(out, (x[:, 0] + x[:, 1]) / 2)           # exact: one add, one halving
     # to_mono of [m, m] interleaved is the identity (idempotence on duplicated channels)
     dup = torch.stack([out, out], dim=1).contiguous()
     out2 = torch.empty_like(out)
     assert af.library().af_to_mono_device(C.c_void_p(dup.data_ptr()), dup.numel(), 2,
                                           C.c_void_p(out2.data_ptr()), None) == 0
     torch.cuda.synchronize()
-    assert torch.equal(out2, out)
+    assert bits_equal(out2, out)
 
 
 # ---- quantiser + base64 ----------------------------------------------------------------
@@ -57,13 +136,13 @@ def test_quantiser_reference_vector_and_edges(af, po):
     assert af.quantize_pcm16([0.5, -0.5, 0.25, -0.25]).tolist() == [16383, -16383, 8191, -8191]
     x = np.array([1.0, -1.0, 2.0, -2.0, np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-9, 0.99999,
                   3.0517578e-05, -3.0517578e-05, 0.1, -0.1], np.float32)
-    assert np.array_equal(af.quantize_pcm16(x), po.quantize_pcm16(x))
+    assert bits_equal(af.quantize_pcm16(x), po.quantize_pcm16(x))
 
 
 @pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 320, 1001, 250007])
 def test_quantiser_bit_exact(af, po, n):
     x = (np.random.default_rng(n).standard_normal(n) * 0.6).astype(np.float32)
-    assert np.array_equal(af.quantize_pcm16(x), po.quantize_pcm16(x))
+    assert bits_equal(af.quantize_pcm16(x), po.quantize_pcm16(x))
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 6, 7, 11, 12, 13, 320, 1000, 99991])
@@ -97,9 +176,9 @@ def test_energy_is_the_reference_fold_bit_for_bit(af, po, frame_len):
     x = synth_clip(40, frame_len * n_frames, 1, 16000)
     got = af.vad_energy(x, frame_len)
     want = np.array([po.vad_energy(x[i * frame_len:(i + 1) * frame_len]) for i in range(n_frames)], np.float32)
-    assert np.array_equal(got, want)
+    assert bits_equal(got, want)
     off = af.vad_energy(x[1:1 + frame_len * 7], frame_len)           # 4-byte aligned only: scalar loads
-    assert np.array_equal(off, np.array([po.vad_energy(x[1 + i * frame_len:1 + (i + 1) * frame_len])
+    assert bits_equal(off, np.array([po.vad_energy(x[1 + i * frame_len:1 + (i + 1) * frame_len])
                                          for i in range(7)], np.float32))
 
 
@@ -177,7 +256,7 @@ def test_vad_batch_device_scan_equals_oracle(af, po, cfg):
     c = af.VadConfig(**cfg)
     af.VoiceActivityDetector.detect_batch_device(ed.data_ptr(), n_clips, n_frames, st.data_ptr(), c)
     torch.cuda.synchronize()
-    assert np.array_equal(st.cpu().numpy(), want)
+    assert bits_equal(st.cpu().numpy(), want)
     if np.isfinite(thr):
         assert {0, 1} <= set(np.unique(want).tolist())
     # streaming: two pieces (the second one not a multiple of 4 frames in), lanes carried on the device
@@ -191,7 +270,7 @@ def test_vad_batch_device_scan_equals_oracle(af, po, cfg):
     af.VoiceActivityDetector.detect_batch_device(b.data_ptr(), n_clips, n_frames - cut, sb.data_ptr(), c,
                                                  lanes.data_ptr())
     torch.cuda.synchronize()
-    assert np.array_equal(torch.cat([sa, sb], 1).cpu().numpy(), want)
+    assert bits_equal(torch.cat([sa, sb], 1).cpu().numpy(), want)
 
 
 def test_vad_batch_host_entry_equals_single_handles(af, po):

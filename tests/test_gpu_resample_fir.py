@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from util import rel_err, synth_clip
+from util import bits_equal, rel_err, synth_clip
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -89,7 +89,7 @@ def test_resample_reference_surface(af):
     assert not af.AudioResampler.new(48000, 48000).needs_resampling()   # :200-204
     p = af.AudioResampler.new(16000, 16000)                      # :184-190 bit-identical passthrough
     x = np.array([0.1, 0.2, 0.3, 0.4], np.float32)
-    assert np.array_equal(p.process(x), x)
+    assert bits_equal(p.process(x), x)
     d = af.AudioResampler.default()                              # :169-178
     assert (d.input_rate(), d.output_rate()) == (48000, 16000)
     assert af.AudioResampler.create_48k_to_16k().needs_resampling()   # :60-62
@@ -112,7 +112,7 @@ def test_streaming_equals_one_shot_bit_exact(af, po, fi, fo):
     parts.append(r.flush())
     got = np.concatenate(parts)
     assert got.size == one.size                                   # ceil(n*L/M)
-    assert np.array_equal(got, one)                               # same arithmetic per output index
+    assert bits_equal(got, one)                               # same arithmetic per output index
     assert rel_err(got, po.resample(x, fi, fo)) < TOL
 
 
@@ -148,7 +148,7 @@ def test_batch_resampler_chunking(af, po):
     # the inner resampler saw 8 chunks: 7 full + the remainder zero-padded to 128
     padded = np.concatenate([x, np.zeros(8 * 128 - 1000, np.float32)])
     want = inner.process(padded)
-    assert np.array_equal(got, want)
+    assert bits_equal(got, want)
     assert got.size == -(-(1024 - 32) // 3)
 
 
@@ -156,7 +156,7 @@ def test_batch_resampler_equal_rates_is_passthrough(af):
     # the reference never terminates here (chunk_size 0); documented deviation: passthrough
     b = af.BatchResampler.new(16000, 16000)
     x = np.arange(10, dtype=np.float32)
-    assert np.array_equal(b.process(x), x)
+    assert bits_equal(b.process(x), x)
     assert b.flush().size == 0
 
 
@@ -180,7 +180,7 @@ def test_resample_config3_full_size(af, po):
         assert lib.af_resample_batch_device(44100, 16000, C.c_void_p(x.data_ptr()), n_clips, n_in,
                                             C.c_void_p(dst.data_ptr()), None) == 0
     torch.cuda.synchronize()
-    assert bool(torch.isfinite(y).all()) and torch.equal(y, y2) and torch.equal(y[4095], y[17])
+    assert bool(torch.isfinite(y).all()) and bits_equal(y, y2) and bits_equal(y[4095], y[17])
     for c in (0, 2048, 4094):
         ref = po.resample(x[c].cpu().numpy(), 44100, 16000)
         assert rel_err(y[c].cpu().numpy(), ref) < TOL
@@ -209,7 +209,7 @@ def test_resample_48k_to_44k1_full_size(af, po):
         assert lib.af_resample_batch_device(48000, 44100, C.c_void_p(x.data_ptr()), n_clips, n_in,
                                             C.c_void_p(dst.data_ptr()), None) == 0
     torch.cuda.synchronize()
-    assert bool(torch.isfinite(y).all()) and torch.equal(y, y2) and torch.equal(y[1023], y[9])
+    assert bool(torch.isfinite(y).all()) and bits_equal(y, y2) and bits_equal(y[1023], y[9])
     assert float((y[500, 100:-100] - 0.25).abs().max()) < 1e-6
     for c in (0, 511, 1022):
         ref = po.resample(x[c].cpu().numpy(), 48000, 44100)
@@ -332,7 +332,7 @@ def test_resample_aligned_rows_take_the_16_byte_store_paths(af, po, fi, fo, n):
             parts.append(r.process(clips[i][pos:pos + k]))
             pos += k
         parts.append(r.flush())
-        assert np.array_equal(np.concatenate(parts), y[i])
+        assert bits_equal(np.concatenate(parts), y[i])
         assert rel_err(y[i], po.resample(clips[i], fi, fo)) < TOL
 
 
@@ -362,7 +362,7 @@ def test_fir_streaming_chunk_invariance_mfma(af, po):
         if pos >= x.size:
             break
     got = np.concatenate(parts)
-    assert np.array_equal(got, whole[:got.size])
+    assert bits_equal(got, whole[:got.size])
     assert rel_err(whole, po.fir(x, taps)) < 1e-5
 
 
@@ -404,4 +404,4 @@ def test_resample_batch_host_path_pipelined_from_pinned_memory(af):
     st = lib.af_resample_batch(48000, 16000, C.c_void_p(xp.data_ptr()), n_clips, n_in, C.c_void_p(out.data_ptr()),
                                out.numel())
     assert st == 0
-    assert np.array_equal(out.numpy(), ref)
+    assert bits_equal(out.numpy(), ref)

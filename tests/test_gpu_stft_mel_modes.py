@@ -6,7 +6,7 @@ test_gpu_features.py: per frame ||got - ref||_2 / ||ref||_2 <= 1e-5 against floa
 import numpy as np
 import pytest
 
-from util import frame_rel_err, synth_clip
+from util import bits_equal, frame_rel_err, synth_clip
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -109,7 +109,7 @@ def test_slaney_filterbank(af, po, scale, norm):
     pipe = af.FeaturePipeline(sample_rate=16000, channels=1, mel_scale=scale, mel_norm=norm)
     pipe.set_batch_uniform(1, 20000)
     W = po.mel_weights(16000.0, scale=scale, norm=norm)
-    assert np.array_equal(pipe.mel_weights(), W.astype(np.float32))
+    assert bits_equal(pipe.mel_weights(), W.astype(np.float32))
     ref = po.mel_apply(po.stft_power(x), W)
     assert frame_rel_err(pipe.run(x), ref) < TOL
 
@@ -120,7 +120,7 @@ def test_mel_filterbank_apply(af, po, n_frames):
     P = (rng.random((n_frames, 513)) ** 4).astype(np.float32) * 100.0
     fb = af.MelFilterbank(sample_rate=16000, n_mels=80)
     W = po.mel_weights(16000.0)
-    assert np.array_equal(fb.weights(), W.astype(np.float32))
+    assert bits_equal(fb.weights(), W.astype(np.float32))
     got = fb.apply(P)
     assert got.shape == (n_frames, 80)
     assert frame_rel_err(got, po.mel_apply(P, W)) < TOL
@@ -149,7 +149,7 @@ def test_wide_filterbanks_take_the_dense_contraction(af, po, sr, ch, n_mels, hop
     got = pipe.run(np.concatenate([x.reshape(-1) for x in clips]))
     assert got.shape == (total, n_mels)
     W = po.mel_weights(float(sr), n_mels=n_mels)
-    assert np.array_equal(pipe.mel_weights(), W.astype(np.float32))
+    assert bits_equal(pipe.mel_weights(), W.astype(np.float32))
     row = 0
     for x, n in zip(clips, lens):
         nf = pipe.n_frames(n)
@@ -181,7 +181,7 @@ def test_shorter_transforms(af, po, n_fft, hop, sr, ch, n_mels):
     assert total == sum(po.stft_n_frames(n, n_fft, hop) for n in lens)
     got = pipe.run(flat)
     W = po.mel_weights(float(sr), n_fft=n_fft, n_mels=n_mels)
-    assert np.array_equal(pipe.mel_weights(), W.astype(np.float32))
+    assert bits_equal(pipe.mel_weights(), W.astype(np.float32))
     pw = af.FeaturePipeline(sample_rate=sr, channels=ch, n_fft=n_fft, hop=hop, n_mels=n_mels, output=af._ffi.AF_OUT_POWER)
     assert pw.set_batch(offs) == total and pw.row_len() == n_fft // 2 + 1
     power = pw.run(flat)
@@ -222,4 +222,4 @@ def test_shorter_transform_streams_like_one_shot(af):
         got = np.concatenate(rows)
         one = af.FeaturePipeline(**kw)
         one.set_batch_uniform(1, n)
-        assert np.array_equal(got, one.run(x.reshape(-1)))
+        assert bits_equal(got, one.run(x.reshape(-1)))

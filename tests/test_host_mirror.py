@@ -6,26 +6,28 @@ import threading
 
 import numpy as np
 
+from util import bits_equal
+
 
 def test_ring_buffer_reference_suite(af):
     r = af.RingBuffer(1024)
     assert r.capacity == 1024                                   # capture.rs:426-430
     assert r.write([1.0, 2.0, 3.0]) == 3                        # :432-442
-    assert np.array_equal(r.read(3), [1.0, 2.0, 3.0])
+    assert bits_equal(r.read(3), [1.0, 2.0, 3.0])
     r.write([1.0, 2.0, 3.0, 4.0, 5.0])                          # :444-457
-    assert np.array_equal(r.read(2), [1.0, 2.0])
-    assert np.array_equal(r.read(3), [3.0, 4.0, 5.0])
+    assert bits_equal(r.read(2), [1.0, 2.0])
+    assert bits_equal(r.read(3), [3.0, 4.0, 5.0])
     assert r.read(100) is None                                  # :487-492
 
     r = af.RingBuffer(10)                                       # :459-471 wrap-around
     r.write([1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0])
     r.read(5)
     r.write([8.0, 9.0, 10.0])
-    assert np.array_equal(r.read(5), [6.0, 7.0, 8.0, 9.0, 10.0])
+    assert bits_equal(r.read(5), [6.0, 7.0, 8.0, 9.0, 10.0])
 
     r = af.RingBuffer(10)                                       # :473-485 overflow
     assert r.write([1.0] * 20) == 9
-    assert np.array_equal(r.read(9), [1.0] * 9)
+    assert bits_equal(r.read(9), [1.0] * 9)
 
     r = af.RingBuffer(1024)                                     # :494-514
     assert r.available() == 0
@@ -40,7 +42,7 @@ def test_ring_buffer_reference_suite(af):
     t = threading.Thread(target=lambda: r.write([1.0, 2.0, 3.0]))
     t.start()
     t.join()
-    assert np.array_equal(r.read(3), [1.0, 2.0, 3.0])
+    assert bits_equal(r.read(3), [1.0, 2.0, 3.0])
 
 
 def test_ring_buffer_matches_oracle_on_random_traffic(af, po):
@@ -55,7 +57,7 @@ def test_ring_buffer_matches_oracle_on_random_traffic(af, po):
             x, y = a.read(n), b.read(n)
             assert (x is None) == (y is None)
             if x is not None:
-                assert np.array_equal(x, y)
+                assert bits_equal(x, y)
         assert a.available() == b.available()
 
 
@@ -79,10 +81,10 @@ def test_ring_buffer_c_abi_directly(af):
     assert lib.af_ring_read(h, 5, out.ctypes.data, 3, C.byref(n), None) == af._ffi.AF_ERR_BUFFER_TOO_SMALL
     assert lib.af_ring_available(h) == 9                                # nothing consumed by the failed read
     assert lib.af_ring_read(h, 5, out.ctypes.data, out.size, C.byref(n), None) == 0 and n.value == 5
-    assert np.array_equal(out[:5], x[:5])
+    assert bits_equal(out[:5], x[:5])
     assert lib.af_ring_write(h, x.ctypes.data, 7) == 5                  # wraps, truncated to the free slots
     assert lib.af_ring_read(h, 100, out.ctypes.data, out.size, C.byref(n), None) == 0 and n.value == 9
-    assert np.array_equal(out[:9], np.concatenate([x[5:9], x[:5]]))
+    assert bits_equal(out[:9], np.concatenate([x[5:9], x[:5]]))
     lib.af_ring_clear(h)
     assert lib.af_ring_available(h) == 0
     t = threading.Thread(target=lambda: lib.af_ring_write(h, x.ctypes.data, 3))
@@ -107,9 +109,9 @@ def test_audio_frame_container(af):
     assert f.samples.size == 3 and f.sample_rate == 16000 and f.channels == 1
     assert f.timestamp_ns == 1000
     m = f.to_mono()                                             # capture.rs:371-382 (1 ch: clone)
-    assert m.channels == 1 and np.array_equal(m.samples, f.samples)
+    assert m.channels == 1 and bits_equal(m.samples, f.samples)
     c = f.clone()                                               # capture.rs:536-544
-    assert np.array_equal(c.samples, f.samples) and c is not f
+    assert bits_equal(c.samples, f.samples) and c is not f
 
 
 def test_configure_message(af):

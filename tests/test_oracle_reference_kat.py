@@ -9,13 +9,15 @@ import json
 import threading
 
 import numpy as np
+
+from util import bits_equal
 import pytest
 
 
 # ---- capture.rs: AudioFrame::to_mono -------------------------------------------
 def test_audio_frame_to_mono_single_channel(po):
     # capture.rs:371-382
-    assert np.array_equal(po.to_mono([0.5, -0.5], 1), np.array([0.5, -0.5], np.float32))
+    assert bits_equal(po.to_mono([0.5, -0.5], 1), np.array([0.5, -0.5], np.float32))
 
 
 def test_audio_frame_to_mono_stereo(po):
@@ -24,7 +26,7 @@ def test_audio_frame_to_mono_stereo(po):
     assert mono.size == 2
     assert abs(mono[0] - 0.375) < 0.001
     assert abs(mono[1] - (-0.375)) < 0.001
-    assert np.array_equal(mono, np.array([0.375, -0.375], np.float32))     # and exactly so
+    assert bits_equal(mono, np.array([0.375, -0.375], np.float32))     # and exactly so
 
 
 def test_to_mono_partial_trailing_frame(po):
@@ -39,21 +41,21 @@ def test_to_mono_three_channels_sequential_f32_sum(po):
     x = np.array([0.1, 0.2, 0.3, 1e-8, 1.0, -1.0], np.float32)
     want = [np.float32((np.float32(np.float32(0.1) + np.float32(0.2)) + np.float32(0.3)) / np.float32(3)),
             np.float32((np.float32(np.float32(1e-8) + np.float32(1.0)) + np.float32(-1.0)) / np.float32(3))]
-    assert np.array_equal(po.to_mono(x, 3), np.array(want, np.float32))
+    assert bits_equal(po.to_mono(x, 3), np.array(want, np.float32))
 
 
 # ---- capture.rs: RingBuffer ------------------------------------------------------
 def test_ring_buffer_write_read(po):
     r = po.Ring(1024)                                   # capture.rs:432-442
     assert r.write([1.0, 2.0, 3.0]) == 3
-    assert np.array_equal(r.read(3), [1.0, 2.0, 3.0])
+    assert bits_equal(r.read(3), [1.0, 2.0, 3.0])
 
 
 def test_ring_buffer_partial_read(po):
     r = po.Ring(1024)                                   # capture.rs:444-457
     r.write([1.0, 2.0, 3.0, 4.0, 5.0])
-    assert np.array_equal(r.read(2), [1.0, 2.0])
-    assert np.array_equal(r.read(3), [3.0, 4.0, 5.0])
+    assert bits_equal(r.read(2), [1.0, 2.0])
+    assert bits_equal(r.read(3), [3.0, 4.0, 5.0])
 
 
 def test_ring_buffer_wrap_around(po):
@@ -61,7 +63,7 @@ def test_ring_buffer_wrap_around(po):
     r.write([1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0])
     r.read(5)
     r.write([8.0, 9.0, 10.0])
-    assert np.array_equal(r.read(5), [6.0, 7.0, 8.0, 9.0, 10.0])
+    assert bits_equal(r.read(5), [6.0, 7.0, 8.0, 9.0, 10.0])
 
 
 def test_ring_buffer_overflow(po):
@@ -97,7 +99,7 @@ def test_ring_buffer_cross_thread(po):
     t = threading.Thread(target=lambda: r.write([1.0, 2.0, 3.0]))
     t.start()
     t.join()
-    assert np.array_equal(r.read(3), [1.0, 2.0, 3.0])
+    assert bits_equal(r.read(3), [1.0, 2.0, 3.0])
 
 
 # ---- resampler.rs ------------------------------------------------------------------

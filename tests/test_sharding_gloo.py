@@ -7,6 +7,8 @@ import socket
 import sys
 
 import numpy as np
+
+from util import bits_equal
 import pytest
 import torch
 import torch.distributed as dist
@@ -43,7 +45,7 @@ def test_stream_shards_reproduce_one_shot_framing(af, po):
         rows = [po.features(x[s:s + n], 1, 16000.0) for spans in shards for s, n in spans]
         got = np.concatenate(rows) if rows else np.zeros((0, 80))
         assert got.shape == one.shape
-        assert np.array_equal(got, one)
+        assert bits_equal(got, one)
     with pytest.raises(ValueError):
         stream_shards(1000, 2, 1000)
 
@@ -93,7 +95,7 @@ def _worker(rank, world, port, n_clips, q):
         mine = scatter_rows(root, per, 6000, dtype=torch.float32, device=torch.device("cpu"))
         assert mine.shape == (e - b, 6000)
         for i, c in enumerate(range(b, e)):
-            assert np.array_equal(mine[i].numpy(), synth_clip(c, 3000, 2, 48000))
+            assert bits_equal(mine[i].numpy(), synth_clip(c, 3000, 2, 48000))
         # each rank computes ITS clips only (the checker stands in for the device here)
         rows = [po.features(mine[i].numpy(), 2, 48000.0) for i in range(e - b)]
         local = torch.from_numpy(np.concatenate(rows) if rows else np.zeros((0, 80)))
@@ -127,6 +129,6 @@ def test_two_rank_sharded_features_equal_single_process(po):
     want = np.concatenate([po.features(synth_clip(c, 3000, 2, 48000), 2, 48000.0)
                            for c in range(n_clips)])
     assert full.shape == want.shape == (n_clips * 8, 80)
-    assert np.array_equal(full, want)          # sharding changes nothing, bit for bit
+    assert bits_equal(full, want)          # sharding changes nothing, bit for bit
     assert t == 2.0                            # MAX over ranks of (1 + rank)
     assert units == n_clips * 8
