@@ -15,6 +15,7 @@ Names, argument meaning and error behaviour follow the reference
 ``VadConfig/VadState/``    vad.rs:21-205
 ``VoiceActivityDetector``
 ``MessageBuilder``         network/websocket.rs:333-363 (audio quantiser)
+``WireEncoder``            capture.rs:30-42 + resampler.rs:60-93 + websocket.rs:244-254 in one launch
 ``AudioError``             error.rs:96-111
 ``FirFilter`` / ``Stft`` / build-defined siblings in the same style
 ``MelFilterbank`` /        (docs/OPS.md)
@@ -30,12 +31,12 @@ from .audio import (AudioFrame, AudioResampler, BatchResampler, ChainPipeline, C
                     MelSpectrogram, MessageBuilder, RingBuffer, VadConfig, VadLevel, VadState,
                     VoiceActivityDetector, device_count, library, quantize_pcm16, to_mono,
                     vad_energy, resample_batch, fir_batch, AudioLevel, level_meter, Stft, MelFilterbank, resample_stereo_batch,
-                    resample_cubic_batch)
+                    resample_cubic_batch, WireEncoder)
 
 __all__ = [
     "AudioError", "AudioFrame", "AudioResampler", "BatchResampler", "ChainPipeline", "ChainStream", "FeaturePipeline", "FeatureStream",
     "FirFilter",
     "MelSpectrogram", "MessageBuilder", "RingBuffer", "VadConfig", "VadLevel", "VadState",
     "VoiceActivityDetector", "device_count", "library", "quantize_pcm16", "to_mono", "vad_energy",
-    "resample_batch", "fir_batch", "AudioLevel", "level_meter", "Stft", "MelFilterbank", "resample_stereo_batch", "resample_cubic_batch",
+    "resample_batch", "fir_batch", "AudioLevel", "level_meter", "Stft", "MelFilterbank", "resample_stereo_batch", "resample_cubic_batch", "WireEncoder",
 ]

@@ -65,6 +65,11 @@ class ChainConfig(C.Structure):
                 ("device", C.c_int32), ("sample_format", C.c_uint32)]
 
 
+class WireConfig(C.Structure):
+    _fields_ = [("input_rate", C.c_uint32), ("output_rate", C.c_uint32), ("channels", C.c_uint32),
+                ("sample_format", C.c_uint32), ("frame_samples", C.c_uint32), ("device", C.c_int32)]
+
+
 class VadConfig(C.Structure):
     _fields_ = [("threshold_db", C.c_float), ("smoothing_factor", C.c_float),
                 ("silence_timeout_frames", C.c_size_t), ("min_speech_frames", C.c_size_t)]
@@ -205,6 +210,21 @@ SIGNATURES = {
     "af_chain_stream_first_step_frames": (_sz, [_vp]),
     "af_chain_stream_history_frames": (_sz, [_vp]),
     "af_chain_stream_seek": (_st, [_vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    # WireEncoder: capture -> wire path in one launch (capture.rs:30-42, resampler.rs:60-93, websocket.rs:244-254)
+    "af_wire_default_config": (None, [C.POINTER(WireConfig)]),
+    "af_wire_create": (_st, [C.POINTER(WireConfig), C.POINTER(_vp)]),
+    "af_wire_destroy": (None, [_vp]),
+    "af_wire_out_samples": (_sz, [_vp, _sz]),
+    "af_wire_text_len": (_sz, [_vp, _sz]),
+    "af_wire_message_len": (_sz, [_vp]),
+    "af_wire_n_messages": (_sz, [_vp, _sz]),
+    "af_wire_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp, _szp]),
+    "af_wire_set_batch": (_st, [_vp, _vp, _sz, _szp, _szp]),
+    "af_wire_text_offsets": (_st, [_vp, _vp, _sz]),
+    "af_wire_run_device": (_st, [_vp, _vp, _vp, _vp, _vp]),
+    "af_wire_run": (_st, [_vp, _vp, _sz, _vp, _sz, _vp, _sz]),
+    "af_wire_set_option": (_st, [_vp, C.c_char_p, C.c_int]),
+    "af_wire_n_launches": (C.c_int, [_vp]),
     # RingBuffer (capture.rs:84-161)
     "af_ring_create": (_st, [_sz, C.POINTER(_vp)]),
     "af_ring_destroy": (None, [_vp]),

@@ -794,6 +794,95 @@ class ChainPipeline:
         return mel
 
 
+class WireEncoder:
+    """The reference's capture -> wire path on a batch of clips in ONE launch (``af_wire_*``): interleaved PCM ->
+    ``AudioFrame::to_mono`` (capture.rs:30-42) -> ``AudioResampler::create_48k_to_16k`` / ``process`` (resampler.rs:60-93)
+    -> ``(x.clamp(-1, 1) * 32767.0) as i16`` little-endian (websocket.rs:246-251) -> ``STANDARD.encode`` (websocket.rs:254).
+    ``frame_samples = 0``: one base64 string per clip; ``frame_samples = 320``: one string per 20 ms send batch
+    (specs/0002-design.md:1543-1546), a trailing partial batch is not sent."""
+
+    def __init__(self, input_rate: int = 48000, output_rate: int = 16000, channels: int = 2,
+                 sample_format: int = _ffi.AF_PCM_F32, frame_samples: int = 0, device: int = -1):
+        self._lib = library()
+        self.cfg = _ffi.WireConfig(input_rate, output_rate, channels, sample_format, frame_samples, device)
+        h = C.c_void_p()
+        _check(self._lib.af_wire_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h
+        self.total_text = 0
+        self.total_samples = 0
+        self.n_clips = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.af_wire_destroy(h)
+
+    def _dtype(self):
+        return np.int16 if self.cfg.sample_format == _ffi.AF_PCM_I16 else np.float32
+
+    def out_samples(self, n_frames: int) -> int:
+        return int(self._lib.af_wire_out_samples(self._h, n_frames))
+
+    def text_len(self, n_frames: int) -> int:
+        return int(self._lib.af_wire_text_len(self._h, n_frames))
+
+    def message_len(self) -> int:
+        return int(self._lib.af_wire_message_len(self._h))
+
+    def n_messages(self, n_frames: int) -> int:
+        return int(self._lib.af_wire_n_messages(self._h, n_frames))
+
+    def set_batch_uniform(self, n_clips: int, frames_per_clip: int) -> int:
+        tt, ts = C.c_size_t(), C.c_size_t()
+        _check(self._lib.af_wire_set_batch_uniform(self._h, n_clips, frames_per_clip, C.byref(tt), C.byref(ts)))
+        self.total_text, self.total_samples, self.n_clips = tt.value, ts.value, n_clips
+        return self.total_text
+
+    def set_batch(self, clip_offsets) -> int:
+        off = np.ascontiguousarray(clip_offsets, np.int64)
+        tt, ts = C.c_size_t(), C.c_size_t()
+        _check(self._lib.af_wire_set_batch(self._h, _ptr(off), off.size - 1, C.byref(tt), C.byref(ts)))
+        self.total_text, self.total_samples, self.n_clips = tt.value, ts.value, off.size - 1
+        return self.total_text
+
+    def text_offsets(self) -> np.ndarray:
+        off = np.zeros(self.n_clips + 1, np.int64)
+        _check(self._lib.af_wire_text_offsets(self._h, _ptr(off), off.size))
+        return off
+
+    def set_option(self, key: str, value: int) -> None:
+        _check(self._lib.af_wire_set_option(self._h, key.encode(), int(value)))
+
+    def n_launches(self) -> int:
+        return int(self._lib.af_wire_n_launches(self._h))
+
+    def run_device(self, pcm_ptr: int, text_ptr: int, pcm16_ptr: int = 0, stream: int = 0) -> None:
+        _check(self._lib.af_wire_run_device(self._h, C.c_void_p(pcm_ptr), C.c_void_p(text_ptr),
+                                            C.c_void_p(pcm16_ptr) if pcm16_ptr else None, C.c_void_p(stream)))
+
+    def run(self, pcm, with_pcm16: bool = False):
+        """Host buffers -> the batch's text as ``bytes`` (cut it with ``text_offsets()`` / ``message_len()``), and the
+        quantised samples (int16) when asked for."""
+        x = np.ascontiguousarray(pcm, self._dtype()).reshape(-1)
+        text = np.empty(self.total_text, np.uint8)
+        q = np.empty(self.total_samples, np.int16) if with_pcm16 else None
+        _check(self._lib.af_wire_run(self._h, _ptr(x), x.size, _ptr(text), text.size,
+                                     _ptr(q) if q is not None else None, q.size if q is not None else 0))
+        return (text.tobytes(), q) if with_pcm16 else text.tobytes()
+
+    def messages(self, pcm) -> List[List[str]]:
+        """``frame_samples > 0``: per clip, the base64 payloads of its messages (what ``send_audio`` puts into
+        ``audio_base_64``, websocket.rs:257-260)."""
+        text = self.run(pcm)
+        off = self.text_offsets()
+        ml = self.message_len()
+        out = []
+        for i in range(self.n_clips):
+            row = text[off[i]:off[i + 1]]
+            out.append([row[k:k + ml].decode("ascii") for k in range(0, len(row), ml)] if ml else [row.decode("ascii")])
+        return out
+
+
 def _chain_config(taps, input_rate, channels, output_rate, hop, n_mels, f_min, f_max, device, sample_format):
     return _ffi.ChainConfig(input_rate, channels, output_rate, _ptr(taps) if taps is not None else None,
                             taps.size if taps is not None else 0, hop, n_mels, f_min, f_max, device, sample_format)

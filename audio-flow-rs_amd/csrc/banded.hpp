@@ -140,6 +140,58 @@ af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* af
 // longest clip (frames) the fused kernel's 32-bit byte offsets reach
 bool fits(const FusedPlan& f, int64_t x_len);
 
+// ---- the reference's wire path as ONE launch -------------------------------------------------------------------
+// interleaved PCM (f32 | i16, mono | stereo) -> to_mono (capture.rs:30-42) -> polyphase resampler (any ratio with a
+// single block matrix: 48 k / 32 k -> 16 k, 48 -> 24 k ...; resampler.rs:60-62 names 48 -> 16 k) -> (x.clamp(-1, 1) * 32767) as
+// i16, little-endian (websocket.rs:246-251) -> padded base64 (websocket.rs:254).  The 16 kHz f32 signal and the i16 signal
+// exist in LDS only.  The banded resampler of resfir_kernel's phase A with 15 of its 16 block periods per column in use: a
+// tile is 3 840 resampled samples = 640 base64 groups of 6 samples = 12 messages of 320 samples (the reference's send batch,
+// specs/0002-design.md:1543-1546) -- no group and no message straddles two tiles, so no workgroup needs another's samples.
+// Block alignment, k-slot mapping and chain order are the stand-alone resampler's: the samples are its bits.
+struct WirePlan {
+    bool ok = false;
+    Plan a;                    // the resampler's plan (mono; nb = 1, eight waves, G = 16)
+    int fmt = kFmtMonoF32;     // how x is staged (FusedFmt)
+    int Gv = 0;                // block periods per column whose samples are used (15)
+    int frame = 0;             // samples per message; 0: every clip is ONE base64 string
+    int row_len = 0;           // characters per message: 4 ceil(2 frame / 3)
+    int shift = 0, seg_stride_a = 0;
+    int img_off = 0;           // floats from the start of LDS: the tile's samples as i16
+    int64_t y_per_tile = 0;    // 256 Gv
+    size_t smem = 0;
+};
+WirePlan make_wire_plan(const Plan& resampler, int fmt, int frame_samples);
+// characters of one clip's text: frame == 0: af_base64_len(2 n_res); else (n_res / frame) messages of row_len (a trailing
+// partial batch is never sent: specs/0002-design.md:1543-1546 `if self.batch_buffer.len() < 320 { return None; }`)
+inline int64_t wire_text_len(const WirePlan& w, int64_t n_res)
+{
+    return w.frame ? (n_res / w.frame) * (int64_t)w.row_len : 4 * ((2 * n_res + 2) / 3);
+}
+// One tile of a ragged batch (64 bytes, two scalar loads).
+struct WireTile {
+    int64_t x_off;             // first frame of the clip, in frames from x
+    int64_t text_off;          // first character of the clip's text, in bytes from text
+    int64_t pcm_off;           // first sample of the clip's PCM16 row, in samples from pcm16
+    int32_t x_len;             // frames of the clip
+    int32_t n_res;             // resampled samples of the clip
+    int32_t t;                 // tile of the clip
+    int32_t pad[7];
+};
+static_assert(sizeof(WireTile) == 64, "WireTile is read with two s_load_dwordx8");
+struct WireArgs {
+    const void* x = nullptr;   // device PCM; uniform: clip i starts x_stride frames behind clip i - 1
+    char* text = nullptr;      // device; uniform: row i starts text_stride bytes behind row i - 1
+    int16_t* pcm16 = nullptr;  // device, optional: the quantised samples beside the text (row i at pcm_stride samples)
+    int64_t x_len = 0, x_stride = 0, text_stride = 0, pcm_stride = 0;
+    int64_t n_res = 0;         // resampled samples per clip
+    int64_t n_clips = 0;
+    const WireTile* tiles = nullptr;    // device; ragged batch (then x_len .. n_clips are ignored)
+    int64_t n_tiles = 0;
+    int text_align = 16;       // largest of 16 / 8 / 4 / 1 that divides the text pointer and every row / message offset
+};
+af_status launch_wire(const WirePlan& w, const float* afrag_a, const WireArgs& args, hipStream_t stream);
+bool fits(const WirePlan& w, int64_t x_len);
+
 }  // namespace banded
 
 // resample.hip: MFMA plan (ch = 1 | 2) and device fragments of the cached design for a rate pair.

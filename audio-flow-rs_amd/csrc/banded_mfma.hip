@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "banded.hpp"
+#include "pcm_dev.hpp"
 
 // AF_BANDED_PAIRS (0: ablation): mono x is staged in sample pairs (8-byte buffer loads) instead of single dwords
 #ifndef AF_BANDED_PAIRS
@@ -1002,6 +1003,297 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+
+// ---- the wire path: resampler -> PCM16 -> base64 in one launch (banded.hpp WirePlan) ----------------------------
+// Phase A is resfir_kernel's (same staging of the four PCM formats, same chain pair per wave), with the columns 15
+// block periods apart instead of 16: wave 7's second chain (period 15) overlaps the next column and is dropped.  The
+// accumulators are quantised where they are (websocket.rs:248), packed little-endian (:249) and written into an LDS
+// image of the tile's 3 840 samples; behind the second barrier every thread takes whole base64 groups (6 samples = 12
+// bytes = three dwords of the image -> 16 characters, websocket.rs:254) and stores them where consecutive lanes
+// write consecutive 16 bytes.  With messages (frame > 0) a group never crosses a message: the last group of a message
+// is short and carries the '=' padding of that message.
+struct WireGeom {
+    const void* x;
+    char* text;
+    int16_t* pcm16;                  // optional
+    const float* afrag_a;
+    const WireTile* tiles;           // ragged batch, or null
+    int64_t x_len, x_stride, text_stride, pcm_stride, n_res;
+    int64_t tiles_per_clip, n_tiles;
+    int lo_off, S, seg_len, seg_stride, shift;
+    int Gv, frame, gpf, row_len;     // gpf = groups per message (ceil(frame / 6)); frame == 0: one string per clip
+    int img_off;                     // floats
+    int text_align;                  // 16, 8, 4 or 1
+};
+
+struct WireCtx {
+    const char* xp;
+    char* tp;                        // the clip's first character
+    int16_t* pp;                     // the clip's first PCM16 sample (or null)
+    int64_t n_res, t_abs;
+    uint32_t x_bytes;
+};
+
+template <int NKA, int FMT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void wire_kernel(const WireGeom g)
+{
+    using F = FusedFmt<FMT>;
+    constexpr bool PAIR = F::kPair;
+    constexpr int BPF = F::kBytesPerFrame;
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    unsigned* img = reinterpret_cast<unsigned*>(xs + g.img_off);       // [128 Gv] dwords = 256 Gv little-endian i16
+    constexpr int FULLA = NKA / 16, TAILA = NKA % 16;
+    constexpr int nthreads = 512;
+    constexpr int kGpw = 2;                                         // one chain pair per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g4 = lane >> 4;
+
+    const int wave_off_a = wave * kGpw * g.S;
+    const int base_full_a = col * g.seg_stride + 16 * g4 + wave_off_a + g.shift;
+    const int base_tail_a = col * g.seg_stride + TAILA * g4 + 64 * FULLA + wave_off_a + g.shift;
+    const int y_lane = 16 * (col * g.Gv + wave * kGpw) + 4 * g4;    // tile-relative resampled index of acc0[0]
+    const int y_per_tile = 256 * g.Gv;
+    const int col_span = g.Gv * g.S;
+    const bool first = PAIR ? 2 * tid < g.seg_len + g.shift : tid < g.seg_len;
+    const bool second = !PAIR && tid + nthreads < g.seg_len;
+    const uint32_t tpc = (uint32_t)g.tiles_per_clip, n_tiles = (uint32_t)g.n_tiles;
+
+    auto tile_ctx = [&](uint32_t tile) {
+        WireCtx c;
+        if (g.tiles) {
+            typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+            typedef const __attribute__((address_space(4))) u32x8* cptr;
+            const cptr rec = reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(g.tiles)) + 2 * (size_t)__builtin_amdgcn_readfirstlane(tile);
+            const u32x8 r = rec[0];
+            const int64_t x_off = (int64_t)(((unsigned long long)r[1] << 32) | r[0]);
+            const int64_t t_off = (int64_t)(((unsigned long long)r[3] << 32) | r[2]);
+            const int64_t p_off = (int64_t)(((unsigned long long)r[5] << 32) | r[4]);
+            c.xp = static_cast<const char*>(g.x) + x_off * BPF;
+            c.tp = g.text + t_off;
+            c.pp = g.pcm16 ? g.pcm16 + p_off : nullptr;
+            c.x_bytes = r[6] * (uint32_t)BPF;
+            c.n_res = (int64_t)r[7];
+            c.t_abs = (int64_t)rec[1][0];
+        } else {
+            const uint32_t clip = tile / tpc;
+            c.xp = static_cast<const char*>(g.x) + (int64_t)clip * g.x_stride * BPF;
+            c.tp = g.text + (int64_t)clip * g.text_stride;
+            c.pp = g.pcm16 ? g.pcm16 + (int64_t)clip * g.pcm_stride : nullptr;
+            c.x_bytes = (uint32_t)(g.x_len * BPF);
+            c.n_res = g.n_res;
+            c.t_abs = tile - clip * tpc;
+        }
+        return c;
+    };
+
+    // the resampler's fragments stay in registers for the whole launch.  Waited for HERE, with a wait the compiler sees:
+    // otherwise its wait-count pass carries these loads as possibly pending around the tile loop and waits for the
+    // x requests of the tile in flight in front of every chain.
+    float a1[NKA];
+#pragma unroll
+    for (int t = 0; t < NKA; ++t) a1[t] = g.afrag_a[t * 64 + lane];
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
+#pragma unroll
+    for (int t = 0; t < NKA; ++t) asm volatile("" : "+v"(a1[t]));
+
+    constexpr uint32_t kOob = 0xFFF00000u;
+    constexpr int kLoads = PAIR ? kCols : kCols * kPfSlots;          // load instructions per thread and tile
+    constexpr int kRegs = kCols * F::kRegsPerCol;
+    float pf[kRegs];
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[kPfSlots];
+    uint32_t x_frames = 0;           // FMT 3: frames of the clip whose tile is staged next (see staged_pair)
+    auto prep_tile = [&](uint32_t tile, bool live) {
+        const WireCtx c = tile_ctx(tile);
+        // x index of the first staged sample of the tile: q(y0) + lo_off - shift, y0 = t y_per_tile
+        const int64_t base = c.t_abs * (int64_t)(16 * g.Gv) * g.S + g.lo_off - g.shift;
+        // (mono i16, odd frame counts: see resfir_kernel)
+        if constexpr (FMT == 3) x_frames = c.x_bytes >> 1;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.xp), 0, (int)(FMT == 3 ? (c.x_bytes + 2u) & ~3u : c.x_bytes),
+                                                 0x00020000);
+        if constexpr (PAIR) {
+            const uint32_t v0 = ((uint32_t)base + 2u * (uint32_t)(tid + opaque_zero())) * (uint32_t)BPF;
+            voff[0] = live && first ? v0 : kOob;
+        } else {
+            const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * 4u;
+            voff[0] = live && first ? v0 : kOob;
+            voff[1] = live && second ? v0 + (uint32_t)nthreads * 4u : kOob;
+        }
+    };
+    auto issue_load = [&](int s) {
+        if constexpr (FMT == 0) {                                   // s = h * 16 + cc
+            const int cc = s % kCols, h = s / kCols;
+            pf[cc * kPfSlots + h] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, AF_X_AUX));
+        } else if constexpr (FMT == 1) {                            // s = cc
+            const f32x4 v = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 8u), 0, AF_X_AUX));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[s * 4 + i] = v[i];
+        } else if constexpr (FMT == 2) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 v = __builtin_bit_cast(
+                f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 4u), 0, AF_X_AUX));
+            pf[s * 2] = v[0];
+            pf[s * 2 + 1] = v[1];
+        } else {
+            pf[s] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 2u), 0, AF_X_AUX));
+        }
+    };
+    auto staged_pair = [&](int cc, float& m0, float& m1) {
+        auto lo16 = [](float w) { return (float)(int16_t)(__float_as_uint(w) & 0xffffu) * (1.0f / 32768.0f); };
+        auto hi16 = [](float w) { return (float)(int16_t)(__float_as_uint(w) >> 16) * (1.0f / 32768.0f); };
+        if constexpr (FMT == 1) {
+            m0 = (pf[cc * 4] + pf[cc * 4 + 1]) * 0.5f;
+            m1 = (pf[cc * 4 + 2] + pf[cc * 4 + 3]) * 0.5f;
+        } else if constexpr (FMT == 2) {
+            m0 = (lo16(pf[cc * 2]) + hi16(pf[cc * 2])) * 0.5f;
+            m1 = (lo16(pf[cc * 2 + 1]) + hi16(pf[cc * 2 + 1])) * 0.5f;
+        } else {
+            m0 = lo16(pf[cc]);
+            const uint32_t b1 = voff[0] + (uint32_t)(cc * col_span) * 2u + 2u;
+            m1 = b1 < 2u * x_frames ? hi16(pf[cc]) : 0.0f;
+        }
+    };
+
+    uint32_t tile = blockIdx.x;
+    if (tile < n_tiles) {
+        prep_tile(tile, true);
+#pragma unroll
+        for (int s2 = 0; s2 < kLoads; ++s2) issue_load(s2);
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
+        // No barrier here: xs was last read by the previous tile's chains and the image by its encoding threads; a wave
+        // writes xs before, and the image after, the next barrier, which every wave reaches after its own encoding.
+        {
+            if constexpr (PAIR) {
+                float* dst = xs + 2 * (tid + opaque_zero());
+                if (first) {
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc) {
+                        float m0, m1;
+                        staged_pair(cc, m0, m1);
+                        dst[cc * g.seg_stride] = m0;
+                        dst[cc * g.seg_stride + 1] = m1;
+                    }
+                }
+            } else {
+                float* dst = xs + tid + opaque_zero();
+                if (first) {
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = pf[cc * kPfSlots];
+                }
+                if (second) {
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = pf[cc * kPfSlots + 1];
+                }
+            }
+        }
+        __syncthreads();
+        const WireCtx tc = tile_ctx(tile);
+        {
+            const bool live = tile + gridDim.x < n_tiles;
+            prep_tile(live ? tile + gridDim.x : tile, live);
+        }
+
+        // ---- resampled samples [y0, y0 + 256 Gv) -> PCM16 image ----
+        const int64_t y0 = tc.t_abs * y_per_tile;
+        const int64_t y_left = tc.n_res - y0;
+        const int y_hi = y_left > y_per_tile ? y_per_tile : y_left < 0 ? 0 : (int)y_left;
+        {
+            const float* b0p = xs + base_full_a;
+            const float* t0p = xs + base_tail_a;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            chain2<NKA>(a1, b0p, b0p + g.S, t0p, t0p + g.S, acc0, acc1, [&](int t) {
+                // all of the next tile's requests in the first half of the chain
+                constexpr int kSpan = (NKA + 1) / 2;
+                if (t < kSpan) {
+#pragma unroll
+                    for (int s2 = (kLoads * t) / kSpan; s2 < (kLoads * (t + 1)) / kSpan; ++s2) issue_load(s2);
+                }
+            });
+            // websocket.rs:248-249; samples behind the clip's end are zero bytes (the padding bits of its last group)
+            auto quads = [&](const f32x4& acc, int yi, unsigned& lo, unsigned& hi) {
+                unsigned q[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = yi + j < y_hi ? (unsigned)pcmdev::quant1(acc[j]) & 0xffffu : 0u;
+                lo = q[0] | (q[1] << 16);
+                hi = q[2] | (q[3] << 16);
+            };
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            unsigned lo, hi;
+            quads(acc0, y_lane, lo, hi);
+            *reinterpret_cast<u32x2*>(img + (y_lane >> 1)) = u32x2{lo, hi};
+            if (wave * kGpw + 1 < g.Gv) {                            // wave-uniform: period 15 belongs to the next column
+                quads(acc1, y_lane + 16, lo, hi);
+                *reinterpret_cast<u32x2*>(img + ((y_lane + 16) >> 1)) = u32x2{lo, hi};
+            }
+        }
+        __syncthreads();
+
+        // ---- base64: whole groups of 6 samples per thread ----
+        {
+            const int n_items = g.frame ? (y_per_tile / g.frame) * g.gpf : y_per_tile / 6;
+            for (int it = tid; it < n_items; it += nthreads) {
+                int s0, cnt;                                         // first sample of the group in the tile, real samples
+                int64_t toff;                                        // its first character in the clip's text
+                if (g.frame) {
+                    const int f = it / g.gpf, j = it - f * g.gpf;
+                    s0 = f * g.frame + 6 * j;
+                    const int left = g.frame - 6 * j;
+                    // only whole messages are sent (specs/0002-design.md:1543-1546)
+                    const int64_t fa = y0 / g.frame + f;
+                    cnt = (fa + 1) * g.frame <= tc.n_res ? (left < 6 ? left : 6) : 0;
+                    toff = fa * g.row_len + 16 * j;
+                } else {
+                    s0 = 6 * it;
+                    const int left = y_hi - s0;
+                    cnt = left < 0 ? 0 : left < 6 ? left : 6;
+                    toff = (y0 / 6 + it) * 16;
+                }
+                if (cnt <= 0) continue;
+                const unsigned* ip = img + (s0 >> 1);                // s0 is even (frame is)
+                unsigned w0 = ip[0], w1 = ip[1], w2 = ip[2];
+                if (g.frame && cnt < 6) {                            // the samples behind a message's end belong to the next one
+                    if (cnt <= 4) w2 = 0u;
+                    if (cnt <= 2) w1 = 0u;
+                }
+                const uint4 o = pcmdev::b64_encode_words(w0, w1, w2);
+                char* dst = tc.tp + toff;
+                if (cnt == 6) {
+                    if (g.text_align == 16) {
+                        *reinterpret_cast<uint4*>(dst) = o;
+                    } else if (g.text_align == 8) {
+                        reinterpret_cast<uint2*>(dst)[0] = uint2{o.x, o.y};
+                        reinterpret_cast<uint2*>(dst)[1] = uint2{o.z, o.w};
+                    } else if (g.text_align == 4) {
+                        unsigned* d4 = reinterpret_cast<unsigned*>(dst);
+                        d4[0] = o.x; d4[1] = o.y; d4[2] = o.z; d4[3] = o.w;
+                    } else {
+                        const unsigned ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) dst[c] = (char)((ow[c >> 2] >> (8 * (c & 3))) & 0xffu);
+                    }
+                } else {
+                    pcmdev::b64_store_tail(dst, o, 2u * (unsigned)cnt);
+                }
+                if (tc.pp) {                                         // the samples themselves, if wanted
+                    int16_t* d16 = tc.pp + y0 + s0;
+                    if (cnt == 6 && (reinterpret_cast<uintptr_t>(d16) & 3) == 0) {
+                        unsigned* d = reinterpret_cast<unsigned*>(d16);
+                        d[0] = w0; d[1] = w1; d[2] = w2;
+                    } else {
+                        const unsigned ww[3] = {w0, w1, w2};
+                        for (int e = 0; e < cnt; ++e) d16[e] = (int16_t)(ww[e >> 1] >> (16 * (e & 1)));
+                    }
+                }
+            }
+        }
+    }
+}
+
 const int kNkInstances[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 48};
 
 template <int NK>
@@ -1481,6 +1773,106 @@ af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* af
     if (grid > cap) grid = cap;
     if (f.a.NK == 24) return launch_resfir_f<24>(f.fmt, f.NKB, g, (unsigned)grid, f.smem, stream);
     return launch_resfir_f<28>(f.fmt, f.NKB, g, (unsigned)grid, f.smem, stream);
+}
+
+
+// ---- the wire launch ---------------------------------------------------------------------------------------------
+namespace {
+template <int NKA>
+af_status launch_wire_f(int fmt, const WireGeom& g, unsigned grid, size_t smem, hipStream_t s)
+{
+    auto go = [&](auto kern) -> af_status {
+        static LdsAttrFlags attr_set;
+        AF_HIP(allow_big_lds(kern, 160 * 1024, attr_set));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, g);
+        AF_HIP(hipGetLastError());
+        return AF_OK;
+    };
+    switch (fmt) {
+    case kFmtMonoF32: return go(wire_kernel<NKA, 0>);
+    case kFmtStereoF32: return go(wire_kernel<NKA, 1>);
+    case kFmtStereoI16: return go(wire_kernel<NKA, 2>);
+    case kFmtMonoI16: return go(wire_kernel<NKA, 3>);
+    default: return fail(AF_ERR_UNSUPPORTED, "wire kernel: unknown input format %d", fmt);
+    }
+}
+}  // namespace
+
+WirePlan make_wire_plan(const Plan& a, int fmt, int frame_samples)
+{
+    WirePlan w;
+    w.a = a;
+    w.fmt = fmt;
+    if (!a.ok || a.nb != 1 || a.nwaves != 8 || a.G != 16 || fmt < 0 || fmt > 3 || frame_samples < 0) return w;
+    if (a.NK != 24 && a.NK != 28) return w;                    // the instances built above
+    w.Gv = a.G - 1;
+    w.y_per_tile = (int64_t)256 * w.Gv;
+    // a message never straddles two tiles, a group never straddles two messages' dwords
+    if (frame_samples && (w.y_per_tile % frame_samples != 0 || frame_samples % 2 != 0)) return w;
+    w.frame = frame_samples;
+    w.row_len = 4 * ((2 * frame_samples + 2) / 3);
+    if (fmt != kFmtMonoF32) {
+        if (a.S % 2) return w;                                 // frame pairs need an even tile origin
+        w.shift = (a.c - (a.T - 1)) & 1;
+        if (a.seg_len + w.shift > 2 * 512) return w;           // a thread stages one pair per column
+        w.seg_stride_a = ((a.seg_len + w.shift + 1) / 2 * 2) | 1;
+    } else {
+        w.seg_stride_a = a.seg_stride;
+    }
+    w.img_off = (kCols * w.seg_stride_a + 3) & ~3;             // 16-byte aligned
+    w.smem = ((size_t)w.img_off + (size_t)128 * w.Gv) * sizeof(float);
+    if (2 * w.smem > 160 * 1024) return w;                     // two workgroups per CU or not at all
+    w.ok = true;
+    return w;
+}
+
+bool fits(const WirePlan& w, int64_t x_len)
+{
+    return w.ok && x_len * fused_bytes_per_frame(w.fmt) < (int64_t)kMaxClip * 4 && x_len < (1ll << 31);
+}
+
+af_status launch_wire(const WirePlan& w, const float* afrag_a, const WireArgs& q, hipStream_t stream)
+{
+    if (!w.ok) return fail(AF_ERR_UNSUPPORTED, "banded::launch_wire without a plan");
+    WireGeom g{};
+    g.x = q.x;
+    g.text = q.text;
+    g.pcm16 = q.pcm16;
+    g.afrag_a = afrag_a;
+    if (q.tiles) {
+        if (q.n_tiles <= 0) return AF_OK;
+        g.tiles = q.tiles;
+        g.n_tiles = q.n_tiles;
+        g.tiles_per_clip = 1;
+    } else {
+        if (q.n_res <= 0 || q.n_clips <= 0) return AF_OK;
+        if (!fits(w, q.x_len))
+            return fail(AF_ERR_UNSUPPORTED, "clips of %lld frames are beyond the wire kernel's 32-bit offsets", (long long)q.x_len);
+        g.x_len = q.x_len;
+        g.x_stride = q.x_stride;
+        g.text_stride = q.text_stride;
+        g.pcm_stride = q.pcm_stride;
+        g.n_res = q.n_res;
+        g.tiles_per_clip = (q.n_res + w.y_per_tile - 1) / w.y_per_tile;
+        g.n_tiles = g.tiles_per_clip * q.n_clips;
+    }
+    if (g.n_tiles >= (1ll << 31)) return fail(AF_ERR_UNSUPPORTED, "banded::launch_wire: too many tiles");
+    g.lo_off = w.a.c - (w.a.T - 1);
+    g.S = w.a.S;
+    g.seg_len = w.a.seg_len;
+    g.seg_stride = w.seg_stride_a;
+    g.shift = w.shift;
+    g.Gv = w.Gv;
+    g.frame = w.frame;
+    g.gpf = (w.frame + 5) / 6;
+    g.row_len = w.row_len;
+    g.img_off = w.img_off;
+    g.text_align = q.text_align;
+    int64_t grid = g.n_tiles;
+    const int64_t cap = 2 * (int64_t)device_cu_count(current_device());
+    if (grid > cap) grid = cap;
+    if (w.a.NK == 24) return launch_wire_f<24>(w.fmt, g, (unsigned)grid, w.smem, stream);
+    return launch_wire_f<28>(w.fmt, g, (unsigned)grid, w.smem, stream);
 }
 
 }  // namespace banded

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "af_common.hpp"
+#include "pcm_dev.hpp"
 
 namespace af {
 namespace {
@@ -84,14 +85,9 @@ __global__ void to_mono_kernel(const float* __restrict__ in, size_t n_samples, u
 }
 
 // ---- PCM16 quantiser ---------------------------------------------------------
-__device__ __forceinline__ int quant1(float x)
-{
-    // websocket.rs:248: (x.clamp(-1.0, 1.0) * 32767.0) as i16
-    if (x != x) return 0;                   // NaN survives clamp, `as i16` gives 0
-    x = x < -1.0f ? -1.0f : x;
-    x = x > 1.0f ? 1.0f : x;
-    return (int)(x * 32767.0f);             // f32 product, truncation toward zero
-}
+// (quant1, the base64 primitives: pcm_dev.hpp, shared with the fused wire launch)
+using pcmdev::quant1;
+using pcmdev::b64_encode16;
 
 __device__ __forceinline__ vu2 quant4(const vf4 v)
 {
@@ -124,46 +120,7 @@ __global__ void quantize_kernel(const float* __restrict__ in, size_t n, int16_t*
 }
 
 // ---- quantise + base64 ---------------------------------------------------------
-// 6 samples = 12 bytes -> 16 characters (one 16-byte store)
-// Four 6-bit values, one per byte of v, to their RFC 4648 characters with byte-parallel
-// arithmetic: c = v + 'A' + 6 [v > 25] - 75 [v > 51] - 15 [v > 61] + 3 [v > 62].  v <= 63 keeps
-// every byte sum below 256, and the subtracted bytes never exceed the added ones, so no carry
-// or borrow crosses a byte.
-__device__ __forceinline__ unsigned b64_chars4(unsigned v)
-{
-    const unsigned m25 = (v + 0x66666666u) & 0x80808080u;   // 0x80 where v >= 26
-    const unsigned m51 = (v + 0x4C4C4C4Cu) & 0x80808080u;   //            v >= 52
-    const unsigned m61 = (v + 0x42424242u) & 0x80808080u;   //            v >= 62
-    const unsigned m62 = (v + 0x41414141u) & 0x80808080u;   //            v >= 63
-    const unsigned add = v + 0x41414141u + (m25 >> 5) + (m25 >> 6) + (m62 >> 6) + (m62 >> 7);   // +6, +3
-    const unsigned sub = (m51 >> 1) + (m51 >> 4) + (m51 >> 6) + (m51 >> 7)                      // 75
-                         + (m61 >> 3) - (m61 >> 7);                                             // 15
-    return add - sub;
-}
-
-// 6 samples -> 12 bytes (little-endian i16) -> 16 characters, packed 4 per dword
-__device__ __forceinline__ uint4 b64_encode16(const float (&x)[6])
-{
-    unsigned q[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) q[j] = (unsigned)quant1(x[j]) & 0xffffu;
-    // byte stream b0..b11 = q0.lo q0.hi q1.lo q1.hi ...; triple t = bytes 3t, 3t+1, 3t+2
-    const unsigned w0 = q[0] | (q[1] << 16), w1 = q[2] | (q[3] << 16), w2 = q[4] | (q[5] << 16);
-    auto triple = [](unsigned b0, unsigned b1, unsigned b2) {
-        const unsigned t = (b0 << 16) | (b1 << 8) | b2;             // 24 bits, first byte on top
-        // characters in memory order: byte 0 = bits 23..18, byte 1 = 17..12, byte 2 = 11..6, byte 3 = 5..0
-        const unsigned v = ((t >> 18) & 63u) | (((t >> 12) & 63u) << 8) | (((t >> 6) & 63u) << 16) |
-                           ((t & 63u) << 24);
-        return b64_chars4(v);
-    };
-    uint4 o;
-    o.x = triple(w0 & 0xffu, (w0 >> 8) & 0xffu, (w0 >> 16) & 0xffu);
-    o.y = triple(w0 >> 24, w1 & 0xffu, (w1 >> 8) & 0xffu);
-    o.z = triple((w1 >> 16) & 0xffu, w1 >> 24, w2 & 0xffu);
-    o.w = triple((w2 >> 8) & 0xffu, (w2 >> 16) & 0xffu, w2 >> 24);
-    return o;
-}
-
+// 6 samples = 12 bytes -> 16 characters (one 16-byte store): pcmdev::b64_encode16
 // Fast path: a lane takes 12 consecutive samples = three 16-byte loads (the three loads of a
 // wave cover one contiguous 3 KB span, every cache line is used whole) -> two 16-byte stores.
 // The last (n mod 12) samples, and everything when a pointer is not 16-byte aligned, go
@@ -191,24 +148,14 @@ __global__ __launch_bounds__(kBlock) void pcm16_base64_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 6; ++j) x[j] = g * 6 + j < n ? in[g * 6 + j] : 0.0f;
         const uint4 o = b64_encode16(x);
-        const unsigned w[4] = {o.x, o.y, o.z, o.w};
-        auto chr = [&](size_t c) { return (char)((w[c >> 2] >> (8 * (c & 3))) & 0xffu); };
         const size_t byte0 = g * 12;
         if (byte0 + 12 <= n_bytes) {
+            const unsigned w[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-            for (int c = 0; c < 16; ++c) out[g * 16 + c] = chr(c);
+            for (int c = 0; c < 16; ++c) out[g * 16 + c] = (char)((w[c >> 2] >> (8 * (c & 3))) & 0xffu);
         } else {
             // last, partial group: whole 3-byte triples, then '=' padding
-            const size_t rem = n_bytes - byte0;          // 2,4,6,8,10
-            const size_t full = rem / 3, tail = rem % 3;
-            for (size_t c = 0; c < full * 4; ++c) out[g * 16 + c] = chr(c);
-            if (tail) {
-                char* op = out + g * 16 + full * 4;
-                op[0] = chr(full * 4);
-                op[1] = chr(full * 4 + 1);           // low bits already zero (samples beyond are 0)
-                op[2] = tail == 2 ? chr(full * 4 + 2) : '=';
-                op[3] = '=';
-            }
+            pcmdev::b64_store_tail(out + g * 16, o, (unsigned)(n_bytes - byte0));      // 2, 4, 6, 8, 10
         }
     }
 }

@@ -442,6 +442,51 @@ int       af_chain_n_launches(const af_chain* c);
 int       af_chain_fused_plan_describe(uint32_t input_rate, uint32_t output_rate, uint32_t channels,
                                        size_t n_fir_taps, int32_t* info);
 
+/* ------------------------------------------------------------------ [R] + [B] */
+/* WireEncoder: the reference's intended capture -> wire path on a batch of clips, in ONE launch:
+ *   interleaved PCM -> AudioFrame::to_mono (modules/audio/capture.rs:30-42) -> AudioResampler::create_48k_to_16k /
+ *   process (modules/audio/resampler.rs:60-93; the polyphase resampler of docs/OPS.md) -> the quantiser of
+ *   WebSocketClient::send_audio, (x.clamp(-1, 1) * 32767.0) as i16, little-endian (modules/network/websocket.rs:246-251)
+ *   -> STANDARD.encode (websocket.rs:254), as wired in specs/0002-design.md:1102-1125.
+ * frame_samples == 0: every clip becomes ONE padded base64 string of af_base64_len(2 * out_samples) characters.
+ * frame_samples == N (even; 320 = the 20 ms send batch of specs/0002-design.md:1543-1546): every N resampled samples
+ * become one padded string of af_wire_message_len() characters, the messages of a clip back to back; a trailing batch of
+ * fewer than N samples is not sent (`if self.batch_buffer.len() < 320 { return None; }`).
+ * The fused launch covers 1- or 2-channel f32 / i16 PCM, every rate pair whose ratio has a single block matrix (48 k /
+ * 32 k -> 16 k, 48 -> 24 k ...) and frame_samples 0 or an even divisor of 3840; the 16 kHz f32 signal and the i16 samples
+ * then exist in LDS only.  Other f32 configurations with 1 or 2 channels (44.1 k input ...) run the same stages as two
+ * launches on equal-length batches; the text is the same bytes either way ("unfused" option: tests compare them).
+ * pcm16 (optional, may be NULL): receives the quantised samples beside the text, clip rows back to back. */
+typedef struct af_wire af_wire;
+typedef struct {
+    uint32_t input_rate;      /* 48000 */
+    uint32_t output_rate;     /* 16000: "pcm_16000", websocket.rs:274 */
+    uint32_t channels;        /* 1 or 2, interleaved */
+    uint32_t sample_format;   /* AF_PCM_F32 | AF_PCM_I16 */
+    uint32_t frame_samples;   /* 0: one string per clip; N: one string per N resampled samples */
+    int32_t  device;
+} af_wire_config;
+void      af_wire_default_config(af_wire_config* cfg);   /* 48 kHz stereo f32 -> 16 kHz, one string per clip */
+af_status af_wire_create(const af_wire_config* cfg, af_wire** out);
+void      af_wire_destroy(af_wire* w);
+size_t    af_wire_out_samples(const af_wire* w, size_t n_frames);   /* resampled samples of a clip of n_frames */
+size_t    af_wire_text_len(const af_wire* w, size_t n_frames);      /* characters of that clip's text */
+size_t    af_wire_message_len(const af_wire* w);                    /* characters per message; 0 with frame_samples == 0 */
+size_t    af_wire_n_messages(const af_wire* w, size_t n_frames);    /* messages of that clip; 0 with frame_samples == 0 */
+af_status af_wire_set_batch_uniform(af_wire* w, size_t n_clips, size_t frames_per_clip, size_t* total_text,
+                                    size_t* total_samples);
+/* ragged batch: clip i = PCM frames [clip_offsets[i], clip_offsets[i+1]); texts (and PCM16 rows) back to back */
+af_status af_wire_set_batch(af_wire* w, const int64_t* clip_offsets, size_t n_clips, size_t* total_text,
+                            size_t* total_samples);
+af_status af_wire_text_offsets(const af_wire* w, int64_t* text_off /* n_clips + 1 */, size_t cap);
+af_status af_wire_run_device(af_wire* w, const void* pcm_dev, char* text_dev, int16_t* pcm16_dev, void* stream);
+/* host buffers; pcm_len counts samples (frames x channels) */
+af_status af_wire_run(af_wire* w, const void* pcm, size_t pcm_len, char* text, size_t text_cap, int16_t* pcm16,
+                      size_t pcm16_cap);
+/* "unfused" 1: the stages as separate launches (diagnostics; equal-length f32 batches) */
+af_status af_wire_set_option(af_wire* w, const char* key, int value);
+int       af_wire_n_launches(const af_wire* w);                     /* 1 with the fused launch, else 2 */
+
 /* ChainStream: the same chain over an unbounded stream (BASELINE config 5 on the full chain).  The handle owns
  * page-locked staging, the input history the resampler, the FIR (K - 1 samples) and the STFT (n_fft - hop
  * samples) need, and ONE captured hipGraph per step: H2D of the new frames, the fused resampler + FIR launch,
