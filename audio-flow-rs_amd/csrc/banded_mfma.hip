@@ -1041,7 +1041,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr bool PAIR = F::kPair;
     constexpr int BPF = F::kBytesPerFrame;
     extern __shared__ __attribute__((aligned(16))) float xs[];
-    unsigned* img = reinterpret_cast<unsigned*>(xs + g.img_off);       // [128 Gv] dwords = 256 Gv little-endian i16
+    // [16 columns][8 Gv + 2] dwords = 256 Gv little-endian i16: a column's 8 Gv dwords and two of padding, so that the 16
+    // columns of a ds_write_b64 start 26 banks apart (16 different bank pairs; unpadded, 120 = 24 mod 32 dwords: four-way)
+    unsigned* img = reinterpret_cast<unsigned*>(xs + g.img_off);
+    const int img_col = 8 * g.Gv;                                   // dwords of samples per column
     constexpr int FULLA = NKA / 16, TAILA = NKA % 16;
     constexpr int nthreads = 512;
     constexpr int kGpw = 2;                                         // one chain pair per wave
@@ -1224,11 +1227,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             };
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             unsigned lo, hi;
+            unsigned* ic = img + col * (img_col + 2) + 8 * wave * kGpw + 2 * g4;
             quads(acc0, y_lane, lo, hi);
-            *reinterpret_cast<u32x2*>(img + (y_lane >> 1)) = u32x2{lo, hi};
+            *reinterpret_cast<u32x2*>(ic) = u32x2{lo, hi};
             if (wave * kGpw + 1 < g.Gv) {                            // wave-uniform: period 15 belongs to the next column
                 quads(acc1, y_lane + 16, lo, hi);
-                *reinterpret_cast<u32x2*>(img + ((y_lane + 16) >> 1)) = u32x2{lo, hi};
+                *reinterpret_cast<u32x2*>(ic + 8) = u32x2{lo, hi};
             }
         }
         __syncthreads();
@@ -1254,8 +1258,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     toff = (y0 / 6 + it) * 16;
                 }
                 if (cnt <= 0) continue;
-                const unsigned* ip = img + (s0 >> 1);                // s0 is even (frame is)
-                unsigned w0 = ip[0], w1 = ip[1], w2 = ip[2];
+                // s0 is even (frame is); a message's group may straddle two columns of the image
+                const int d0 = s0 >> 1;
+                auto at = [&](int d) { return img[d + 2 * (d / img_col)]; };
+                unsigned w0 = at(d0), w1 = at(d0 + 1), w2 = at(d0 + 2);
                 if (g.frame && cnt < 6) {                            // the samples behind a message's end belong to the next one
                     if (cnt <= 4) w2 = 0u;
                     if (cnt <= 2) w1 = 0u;
@@ -1820,7 +1826,7 @@ WirePlan make_wire_plan(const Plan& a, int fmt, int frame_samples)
         w.seg_stride_a = a.seg_stride;
     }
     w.img_off = (kCols * w.seg_stride_a + 3) & ~3;             // 16-byte aligned
-    w.smem = ((size_t)w.img_off + (size_t)128 * w.Gv) * sizeof(float);
+    w.smem = ((size_t)w.img_off + (size_t)kCols * (8 * w.Gv + 2)) * sizeof(float);    // image: padded columns
     if (2 * w.smem > 160 * 1024) return w;                     // two workgroups per CU or not at all
     w.ok = true;
     return w;

@@ -492,6 +492,12 @@ af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, 
     const bool resample = c->cfg.input_rate != c->cfg.output_rate;
     const bool i16 = c->cfg.sample_format == AF_PCM_I16;
     if (fused_applies(c)) {
+        // mono i16 is staged as one dword per frame pair, and the buffer range of a clip is rounded up to whole dwords (an
+        // odd frame count: banded_mfma.hip, resfir_kernel): from a base that is only 2-byte aligned the last dword would
+        // reach 2 bytes into the NEXT aligned dword behind the caller's buffer.  Such a pointer (a slice at an odd
+        // element) is refused rather than read from.
+        if (c->fmt == banded::kFmtMonoI16 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 != 0)
+            return fail(AF_ERR_INVALID_ARG, "af_chain_run_device: mono i16 PCM must start on a 4-byte boundary (got %p)", pcm_dev);
         if (const int chunks = pipeline_chunks(c)) return run_pipelined(c, pcm_dev, mel_dev, as_stream(stream), chunks);
         banded::FusedArgs q;
         q.x = pcm_dev;

@@ -34,6 +34,8 @@ struct af_features {
     bool units_ok = false;
     DevBuf d_tabs3;                  // features_v3.hip: f16-pair fragment tables of the two DFT stages (hop 256, mel output),
     bool v3_ok = false;              // then its mel plan's fragments and slot table (steps of a slot 4 bins apart)
+    bool v3_tried = false;           // build_v3 ran (on af_features_set_option(h, "kernel", 3))
+    std::vector<double> win1024;     // the window of the 1024-point frame (zero behind n_fft): what build_v3 needs later
     Plan plan8b{};
     const float* d_wfrag8b = nullptr;
     const int* d_meta8b = nullptr;
@@ -338,7 +340,8 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
         AF_TRY(p->d_power.reserve(((size_t)p->total_frames * kBins + 16) * sizeof(float)));
     // (dense_mel: the hop-256 kernel only writes power rows, which needs no filterbank plan)
     const bool v2_ok = p->plan8.n_waves == v2::kW || (p->dense_mel && p->cfg.hop == (uint32_t)v2::kHop);
-    if ((v2_ok || p->v3_ok) && aligned4 && p->total_units > 0 && p->total_units < (1ll << 26)) {
+    const bool v3_possible = p->cfg.hop == (uint32_t)v2::kHop && !p->dense_mel && p->cfg.output == AF_OUT_MEL;   // built on request
+    if ((v2_ok || v3_possible) && aligned4 && p->total_units > 0 && p->total_units < (1ll << 26)) {
         std::vector<v2::UnitDesc> units((size_t)p->total_units + 4);   // + zero records: the kernels read a unit ahead
         const bool sep = p->cfg.channel_mode == AF_CH_SEPARATE;
         size_t k = 0;
@@ -453,6 +456,8 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     const auto hann = [frame_len](int i) {
         return i < frame_len ? 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)frame_len) : 0.0;
     };
+    p->win1024.resize(kNfft);
+    for (int i = 0; i < kNfft; ++i) p->win1024[i] = hann(i);
     // constant block: wintab [32][kWinRow] | twtab [32][kTwRow] | wfrag | meta
     // (the two tables are copied verbatim into LDS by every workgroup; rows are
     // padded so that 16 lanes reading 16 rows with ds_read_b128 hit 16 bank groups)
@@ -548,38 +553,7 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
             return fail(AF_ERR_HIP, "uploading the filterbank failed");
         return AF_OK;
     };
-    // hop-256 kernel with the DFT on the matrix cores (features_v3.hip): mel output through an 8-wave banded plan whose
-    // slots walk bins 4 apart per step (its power rows are bin-major)
-    if (cfg->hop == (uint32_t)v2::kHop && !p->dense_mel && cfg->output == AF_OUT_MEL) {
-        std::vector<float> wfrag8b;
-        std::vector<int> meta8b;
-        // groups of whole filter quads first (one 16-byte store per group and lane: the kernel's QUADS instances), then the
-        // finer cut
-        if (build_plan(p->W, (int)cfg->n_mels, v3::kW, 6, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
-            build_plan(p->W, (int)cfg->n_mels, v3::kW, 7, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
-            build_plan(p->W, (int)cfg->n_mels, v3::kW, 8, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
-            build_plan(p->W, (int)cfg->n_mels, v3::kW, 6, 2, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
-            build_plan(p->W, (int)cfg->n_mels, v3::kW, 8, 2, p->plan8b, wfrag8b, meta8b, false) != AF_OK) {
-            std::memset(&p->plan8b, 0, sizeof(p->plan8b));
-            last_error_slot().clear();
-        } else {
-            std::vector<double> win(kNfft);
-            for (int i = 0; i < kNfft; ++i) win[i] = hann(i);
-            std::vector<uint4> tabs3(v3::kTabVec);
-            v3::build_tables(win.data(), tabs3.data());
-            const size_t o_wf = tabs3.size() * sizeof(uint4), o_meta = o_wf + wfrag8b.size() * sizeof(float);
-            st = p->d_tabs3.reserve(o_meta + meta8b.size() * sizeof(int));
-            char* b3 = p->d_tabs3.as<char>();
-            if (st == AF_OK && (hipMemcpy(b3, tabs3.data(), o_wf, hipMemcpyHostToDevice) != hipSuccess ||
-                                hipMemcpy(b3 + o_wf, wfrag8b.data(), wfrag8b.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-                                hipMemcpy(b3 + o_meta, meta8b.data(), meta8b.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
-                st = fail(AF_ERR_HIP, "uploading the DFT fragment tables failed");
-            if (st != AF_OK) { delete p; return st; }
-            p->d_wfrag8b = reinterpret_cast<const float*>(b3 + o_wf);
-            p->d_meta8b = reinterpret_cast<const int*>(b3 + o_meta);
-            p->v3_ok = true;
-        }
-    }
+    // (the matrix-core DFT kernel's tables are built when a handle asks for it: af_features_set_option(h, "kernel", 3))
     if (p->dense_mel) st = upload_bank(p->W, kBins, p->d_W, p->d_band);
     if (st == AF_OK && cfg->n_fft != (uint32_t)kNfft) st = upload_bank(p->Wn, (int)cfg->n_fft / 2 + 1, p->d_Wn, p->d_bandn);
     if (st != AF_OK) { delete p; return st; }
@@ -772,13 +746,29 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     prm.aligned16 = (p->offsets_aligned && (reinterpret_cast<uintptr_t>(pcm_dev) % 16 == 0)) ? 1 : 0;
     const int wg_knob = wg_override > 0 ? wg_override
                         : p->opt_wg_per_cu >= 0 ? p->opt_wg_per_cu : debug_knob(kKnobFeaturesWgPerCu);
-    // which fused kernel: 0 = the best that applies (hop 256: features_v3, then features_v2), 1 = the general kernel,
-    // 2 = features_v2 (the register-FFT kernel of rounds 2-3), 3 = features_v3 or an error
-    const int ksel = p->opt_kernel >= 0 ? p->opt_kernel : debug_knob(kKnobFeaturesKernel);
+    // which fused kernel: 0 = the default (hop 256 on dword-aligned clips: features_v2; else the general kernel), 1 = the
+    // general kernel, 2 = features_v2 where it applies (else the general kernel), 3 = features_v3, the opt-in matrix-core
+    // DFT kernel.  Asked for by THIS handle (af_features_set_option) a 3 that cannot be served is an error that names the
+    // condition; the process-wide switch (af_debug_set) only prefers it: handles it does not fit, or whose tables were
+    // never built, run their default kernel.
+    const bool own = p->opt_kernel >= 0;
+    int ksel = own ? p->opt_kernel : debug_knob(kKnobFeaturesKernel);
     const bool hop256_ok = p->units_ok && p->offsets_aligned4 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 == 0;
     const bool v3_applies = hop256_ok && p->v3_ok && !prm.out_power && !prm.log_mel;
-    if (ksel == 3 && !v3_applies)
-        return fail(AF_ERR_UNSUPPORTED, "features: the matrix-core DFT kernel serves hop 256 with mel output through the banded plan only");
+    if (ksel == 3 && !v3_applies) {
+        if (!own) {
+            ksel = 0;
+        } else {
+            const char* why = p->cfg.hop != (uint32_t)v2::kHop                   ? "the hop is not 256"
+                              : prm.out_power                                     ? "the output is the power spectrogram (or the filterbank takes the dense contraction)"
+                              : prm.log_mel                                       ? "log-mel output is not among its instances"
+                              : !p->v3_ok                                         ? "the filterbank is outside its banded mel plan"
+                              : !(p->offsets_aligned4 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 == 0)
+                                  ? "a clip does not start on a 4-byte boundary (mono i16 clips at odd offsets)"
+                                  : "the batch has no unit table (empty, or beyond 2^26 units)";
+            return fail(AF_ERR_UNSUPPORTED, "features: the matrix-core DFT kernel (kernel = 3) cannot serve this handle: %s", why);
+        }
+    }
     if (v3_applies && ksel == 3) {                       // (opt-in until it is the faster one)
         v3::Params q{};
         q.pcm = pcm_dev;
@@ -791,7 +781,7 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         q.total_units = u_count;
         q.log_mel = prm.log_mel;
         q.stamps = prm.stamps;
-        q.stamp_wave0 = (prm.stamps && std::getenv("AF_V3_STAMP_W0")) ? std::atoi(std::getenv("AF_V3_STAMP_W0")) : 0;   // diagnostics
+        q.stamp_wave0 = (prm.stamps && std::getenv("AF_V3_STAMP_W0") && std::atoi(std::getenv("AF_V3_STAMP_W0")) >= 4) ? 4 : 0;   // diagnostics: waves 0-3 or 4-7
         int64_t grid3 = (int64_t)p->n_cus;               // one 8-wave workgroup per CU (256 registers per lane, 131 KB of LDS)
         if (grid3 > u_count) grid3 = u_count;
         AF_TRY(v3::launch(q, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
@@ -957,10 +947,53 @@ const char* af_features_kernel_name(void) { return "af_features_v2_kernel"; }   
 // diagnostics, host only: the mel plans -- info[81] = {groups, K-steps, slots of wave 0..3} of the
 // general kernel, then {waves (0: not in use), groups, K-steps, slots of wave 0..7} of the hop-256 kernel,
 // then its slot_end words [8 waves][8 slots] (0: the group continues; else 0x10000 | filters << 8 | first filter)
+// The opt-in hop-256 kernel with the DFT on the matrix cores (features_v3.hip): mel output through an 8-wave banded plan
+// whose slots walk bins 4 apart per step (its power rows are bin-major) + the f16-pair fragment tables of the two DFT
+// stages (143 KB).  Built when a handle asks for that kernel, never for the handles that do not (every product handle,
+// the ones inside chains and streams included, used to pay for it at create).
+static af_status build_v3(af_features* p)
+{
+    if (p->v3_tried) return AF_OK;
+    p->v3_tried = true;
+    const af_features_config* cfg = &p->cfg;
+    if (!(cfg->hop == (uint32_t)v2::kHop && !p->dense_mel && cfg->output == AF_OUT_MEL)) return AF_OK;
+    std::vector<float> wfrag8b;
+    std::vector<int> meta8b;
+    // groups of whole filter quads first (one 16-byte store per group and lane: the kernel's QUADS instances), then the
+    // finer cut
+    if (build_plan(p->W, (int)cfg->n_mels, v3::kW, 6, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
+        build_plan(p->W, (int)cfg->n_mels, v3::kW, 7, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
+        build_plan(p->W, (int)cfg->n_mels, v3::kW, 8, 4, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
+        build_plan(p->W, (int)cfg->n_mels, v3::kW, 6, 2, p->plan8b, wfrag8b, meta8b, false) != AF_OK &&
+        build_plan(p->W, (int)cfg->n_mels, v3::kW, 8, 2, p->plan8b, wfrag8b, meta8b, false) != AF_OK) {
+        std::memset(&p->plan8b, 0, sizeof(p->plan8b));
+        last_error_slot().clear();
+        return AF_OK;
+    }
+    std::vector<double> win(kNfft);
+    for (int i = 0; i < kNfft; ++i) win[i] = p->win1024[i];
+    std::vector<uint4> tabs3(v3::kTabVec);
+    v3::build_tables(win.data(), tabs3.data());
+    const size_t o_wf = tabs3.size() * sizeof(uint4), o_meta = o_wf + wfrag8b.size() * sizeof(float);
+    AF_TRY(p->d_tabs3.reserve(o_meta + meta8b.size() * sizeof(int)));
+    char* b3 = p->d_tabs3.as<char>();
+    if (hipMemcpy(b3, tabs3.data(), o_wf, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b3 + o_wf, wfrag8b.data(), wfrag8b.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b3 + o_meta, meta8b.data(), meta8b.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(AF_ERR_HIP, "uploading the DFT fragment tables failed");
+    p->d_wfrag8b = reinterpret_cast<const float*>(b3 + o_wf);
+    p->d_meta8b = reinterpret_cast<const int*>(b3 + o_meta);
+    p->v3_ok = true;
+    return AF_OK;
+}
+
 af_status af_features_set_option(af_features* p, const char* key, int value)
 {
     AF_REQUIRE(p && key, "af_features_set_option: null argument");
-    if (std::strcmp(key, "kernel") == 0) p->opt_kernel = value < 0 ? -1 : value;
+    if (std::strcmp(key, "kernel") == 0) {
+        if (value == 3) AF_TRY(build_v3(p));
+        p->opt_kernel = value < 0 ? -1 : value;
+    }
     else if (std::strcmp(key, "wg_per_cu") == 0) p->opt_wg_per_cu = value < 0 ? -1 : value;
     else return fail(AF_ERR_INVALID_ARG, "af_features_set_option: unknown option '%s'", key);
     return AF_OK;

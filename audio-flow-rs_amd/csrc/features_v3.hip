@@ -838,6 +838,10 @@ static af_status launch_fmt(const Params& p, bool separate, int grid, hipStream_
         }
     }
     if (most > 8) return fail(AF_ERR_UNSUPPORTED, "features v3: %d mel slots on one wave (limit 8)", most);
+    // diagnostics: the one stamping instance is stereo f32, downmix, a quad-aligned plan of at most 7 slots per wave --
+    // anything else would run an instance without stamps and hand back zeros as if they were measurements
+    if (p.stamps && !(CH == 2 && !I16 && !separate && quads && most <= 7))
+        return fail(AF_ERR_UNSUPPORTED, "features v3: in-kernel stamps exist for stereo f32 downmix with a quad-aligned mel plan of <= 7 slots per wave only");
     if constexpr (CH == 2) {
         if (separate) return quads ? launch_k<CH, I16, true, 8, false, true>(p, grid, stream) : launch_k<CH, I16, true, 8, false, false>(p, grid, stream);
     }

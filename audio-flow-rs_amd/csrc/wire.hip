@@ -119,6 +119,8 @@ af_status describe(af_wire* w, const std::vector<int64_t>& off)
     w->n_in = n ? (size_t)(off[1] - off[0]) : 0;
     w->n_res = n ? (size_t)w->res_len[0] : 0;
     w->n_tiles = 0;
+    if (!w->ragged && w->fmt == banded::kFmtMonoI16 && w->plan.ok && (w->n_in & 1) && n > 1)
+        return fail(AF_ERR_UNSUPPORTED, "af_wire: mono i16 clips must start on even frames (equal-length clips of an odd frame count, %zu, do not)", w->n_in);
     if (w->ragged) {
         if (!w->plan.ok)
             return fail(AF_ERR_UNSUPPORTED, "af_wire: ragged batches need the fused launch (a ratio with one block matrix, "
@@ -127,9 +129,11 @@ af_status describe(af_wire* w, const std::vector<int64_t>& off)
         for (size_t i = 0; i < n; ++i) {
             const int64_t len = off[i + 1] - off[i];
             if (!banded::fits(w->plan, len)) return fail(AF_ERR_UNSUPPORTED, "a clip of %lld frames is beyond the wire kernel's offsets", (long long)len);
-            if (w->fmt != banded::kFmtMonoF32 && ((off[i] - off[0]) & 1) && w->fmt != banded::kFmtStereoF32) {
-                // (pair formats load frame pairs as one dword / two dwords: the clip base must keep their alignment)
-            }
+            // mono i16 is staged as one dword per frame pair from the clip's first frame: a clip that starts on an odd frame
+            // of the buffer would put every dword across two aligned ones (and the last one 2 bytes behind the buffer)
+            if (w->fmt == banded::kFmtMonoI16 && ((off[i] - off[0]) & 1) && len > 0)
+                return fail(AF_ERR_UNSUPPORTED, "af_wire: mono i16 clips must start on even frames (clip %zu starts at frame %lld)",
+                            i, (long long)(off[i] - off[0]));
             const int64_t nt = (w->res_len[i] + w->plan.y_per_tile - 1) / w->plan.y_per_tile;
             for (int64_t t = 0; t < nt; ++t) {
                 banded::WireTile r{};
@@ -281,6 +285,8 @@ af_status af_wire_run_device(af_wire* w, const void* pcm_dev, char* text_dev, in
     AF_REQUIRE(pcm_dev && text_dev, "af_wire_run_device: null buffer");
     hipStream_t s = as_stream(stream);
     if (fused(w)) {
+        if (w->fmt == banded::kFmtMonoI16 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 != 0)
+            return fail(AF_ERR_INVALID_ARG, "af_wire_run_device: mono i16 PCM must start on a 4-byte boundary (got %p)", pcm_dev);
         banded::WireArgs q;
         q.x = pcm_dev;
         q.text = text_dev;

@@ -4,7 +4,7 @@
    python3 scripts/make_pmc_json.py [gpurun_out/r04p]"""
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = int(os.environ.get("AF_ROUND_NO", "4"))
+ROUND = int(os.environ.get("AF_ROUND_NO", "5"))
 RT = f"r{ROUND:02d}"
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", RT + "p")
 dst = os.path.join(ROOT, "profiles")
@@ -67,10 +67,15 @@ traffic = {
     "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
     "algorithmic_bytes_per_launch": ALG, "traffic_over_algorithmic": round((rd + wr) / ALG, 4),
     "source": ["profiles/" + RT + "_pmc_fetch.txt", "profiles/" + RT + "_pmc_write.txt", "profiles/" + RT + "_pmc_cal_fetch.txt", "profiles/" + RT + "_pmc_cal_write.txt"],
-    "round2": {k: old[k] for k in ("kernel", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch",
-                                   "traffic_over_algorithmic") if k in old},
-    "round1": old.get("round1"), "banded_kernel_config3": old.get("banded_kernel_config3"),
+    "banded_kernel_config3": old.get("banded_kernel_config3"),
 }
+# history: every earlier roundN record is carried forward unchanged, the previous top level goes under ITS OWN round
+for k, v in old.items():
+    if k.startswith("round") and k != "round" and v is not None:
+        traffic[k] = v
+if old.get("round") is not None and int(old["round"]) != ROUND:
+    traffic[f"round{int(old['round'])}"] = {k: old[k] for k in ("kernel", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch",
+                                                               "hbm_bytes_per_launch", "traffic_over_algorithmic") if k in old}
 # chain
 cfch, cwch = table("pmc_chain_fetch.txt"), table("pmc_chain_write.txt")
 if cfch and cwch:

@@ -90,21 +90,52 @@ def test_v3_non_finite_samples_stay_local(af, po):
         assert err.max() < TOL, (pos, err.max())
 
 
-@pytest.mark.parametrize("kw", [dict(channel_mode=1), dict(n_mels=40), dict(n_mels=128, sample_rate=44100), dict(n_fft=512),
-                                dict(n_fft=256), dict(mel_scale=1, mel_norm=1), dict(n_mels=64, sample_rate=16000, channels=1)])
+# filterbanks / modes the kernel's plan is documented to cover (separate channels, 40-128 filters at
+# 16-48 kHz, HTK and Slaney, n_fft 1024 / 512 / 256): it must serve them, and within the tolerance of the ORACLE
+V3_COVERED = [dict(channel_mode=1), dict(n_mels=40), dict(n_mels=128, sample_rate=44100), dict(n_fft=512), dict(n_fft=256),
+              dict(mel_scale=1, mel_norm=1), dict(n_mels=64, sample_rate=16000, channels=1)]
+
+
+@pytest.mark.parametrize("kw", V3_COVERED)
 def test_v3_other_configurations(af, po, kw):
-    """Separate channels, other filterbanks (those its quad-aligned mel plan covers), shorter frames: same rows as the
-    register-FFT kernel within 2e-6 per frame."""
+    """Separate channels, other filterbanks, shorter frames: the rows meet the float64 oracle's within 1e-5 per frame (the
+    contract), and the register-FFT kernel's within 2e-6.  A configuration on this list that the kernel refused would be a
+    regression of its mel plan, so nothing is skipped."""
     kw = dict(kw)
     ch = kw.pop("channels", 2)
-    x = [synth_clip(40 + i, 20000 + 4096 * i, ch, kw.get("sample_rate", 48000)) for i in range(3)]
-    try:
-        _, a = _run(af, x, ch, 0, 3, **dict(kw))
-    except af.AudioError as e:                          # a filterbank outside its plan: refused, not wrong
-        assert "matrix-core" in str(e)
-        pytest.skip("filterbank outside the kernel's mel plan")
+    sr = kw.get("sample_rate", 48000)
+    x = [synth_clip(40 + i, 20000 + 4096 * i, ch, sr) for i in range(3)]
+    _, a = _run(af, x, ch, 0, 3, **dict(kw))
     _, b = _run(af, x, ch, 0, 2, **dict(kw))
     assert a.shape == b.shape and frame_rel_err(a, np.asarray(b, np.float64)) < 2e-6
+    # the oracle, clip by clip (separate channels: a clip's rows are channel 0's spectrogram, then channel 1's)
+    n_fft = kw.get("n_fft", 1024)
+    W = po.mel_weights(float(sr), n_fft, kw.get("n_mels", 80), scale=kw.get("mel_scale", 0), norm=kw.get("mel_norm", 0))
+
+    def oracle(mono):
+        return po.mel_apply(po.stft_power(mono, n_fft, 256), W)
+
+    row = 0
+    for c in x:
+        if kw.get("channel_mode"):
+            refs = [oracle(np.ascontiguousarray(c.reshape(-1, 2)[:, k])) for k in (0, 1)]
+        else:
+            refs = [oracle(po.to_mono(c, ch))]
+        for ref in refs:
+            nf = ref.shape[0]
+            assert frame_rel_err(a[row:row + nf], ref) < TOL
+            row += nf
+    assert row == a.shape[0]
+
+
+def test_v3_filterbank_outside_its_plan_is_refused_by_name(af):
+    """few, wide filters take the dense contraction (power rows + a second launch): the matrix-core kernel says so"""
+    pipe = af.FeaturePipeline(sample_rate=48000, channels=2, n_mels=16)
+    pipe.set_batch_uniform(1, 30000)
+    assert af.library().af_features_set_option(pipe._h, b"kernel", 3) == 0
+    with pytest.raises(af.AudioError) as e:
+        pipe.run(synth_clip(3, 30000, 2, 48000))
+    assert "kernel = 3" in str(e.value) and ("dense" in str(e.value) or "plan" in str(e.value))
 
 
 def test_v3_refuses_what_it_does_not_serve(af):

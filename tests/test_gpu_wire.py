@@ -89,7 +89,7 @@ def test_wire_nan_inf_and_clamp(af, po):
 @pytest.mark.parametrize("channels,fmt", [(1, F32), (2, I16), (1, I16), (2, F32)])
 @pytest.mark.parametrize("rates", [(48000, 16000), (32000, 16000), (48000, 24000)])
 def test_wire_formats_and_single_block_ratios(af, po, channels, fmt, rates):
-    n_frames, n_clips = 20011, 2
+    n_frames, n_clips = (20011 if not (channels == 1 and fmt == I16) else 20012), 2     # (mono i16 clips start on even frames)
     xf = _clips(n_clips, n_frames, channels, seed=11, gain=1.7)
     x = np.clip(np.round(xf * 20000.0), -32768, 32767).astype(np.int16) if fmt == I16 else xf
     w = af.WireEncoder(input_rate=rates[0], output_rate=rates[1], channels=channels, sample_format=fmt)
@@ -142,6 +142,23 @@ def test_wire_frame_outside_the_fused_tile_runs_the_stages(af, po):
     assert w2.run(x) == b"".join(_b64(po.quantize_pcm16(y2[i])) for i in range(2))
     with pytest.raises(af.AudioError):
         af.WireEncoder(input_rate=44100, sample_format=I16)        # i16 has no stage-by-stage form
+
+
+def test_wire_mono_i16_alignment_is_checked(af):
+    """mono i16 is staged one dword per frame pair: clips on odd frames, or a PCM pointer that is only 2-byte aligned, are
+    refused (AudioError), never read across the end of the buffer"""
+    torch = pytest.importorskip("torch")
+    w = af.WireEncoder(channels=1, sample_format=I16)
+    with pytest.raises(af.AudioError):
+        w.set_batch_uniform(2, 20011)
+    with pytest.raises(af.AudioError):
+        w.set_batch(np.array([0, 7001, 9000], np.int64))
+    w.set_batch_uniform(1, 20011)                                   # one clip of an odd count is fine
+    x = torch.zeros(20011 + 8, dtype=torch.int16, device="cuda:0")
+    text = torch.empty(w.total_text, dtype=torch.uint8, device="cuda:0")
+    w.run_device(x.data_ptr(), text.data_ptr())
+    with pytest.raises(af.AudioError):
+        w.run_device(x.data_ptr() + 2, text.data_ptr())
 
 
 def test_wire_ragged_batch(af, po):
