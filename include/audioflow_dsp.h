@@ -427,6 +427,8 @@ af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, 
 af_status af_chain_run(af_chain* c, const void* pcm, size_t pcm_len, float* mel, size_t mel_cap);
 /* per-handle diagnostics (unlike af_debug_set they touch no other handle):
  *   "unfused"  1: resampler and FIR as separate launches; 0: fused where covered; -1: follow af_debug_set
+ *   "kernel", "wg_per_cu": handed to the chain's STFT / mel stage (af_features_set_option); without them that stage
+ *              follows af_debug_set("features.kernel") like any feature handle
  *   "pipeline" k > 0: equal-length batches run the two launches of the fused form side by side on two internal
  *              streams, in k chunks of clips (same rows; measured slower than one after the other on MI355X,
  *              DESIGN.md section 9 -- hence 0, off, by default) */

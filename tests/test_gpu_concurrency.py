@@ -77,6 +77,7 @@ def test_process_wide_switches_flipped_while_handles_run(af):
     assert not bits_equal(ref2, ref1)               # the two kernels differ in the last bits: the test can tell them apart
     chain = af.ChainPipeline(input_rate=48000, channels=2, output_rate=16000, fir_taps=taps)
     chain.set_option("unfused", 0)
+    chain.set_option("kernel", 2)                   # its STFT / mel stage is a feature handle: pinned too
     chain.set_batch_uniform(1, n)
     ref_chain = chain.run(x)
     stop = threading.Event()
