@@ -3,7 +3,7 @@
 
 Workload = BASELINE.json configs[1]: a batch of 256 x 30 s stereo 48 kHz clips
 (f32 interleaved PCM, resident in HBM) -> to_mono -> 1024-point Hann STFT
-(hop 256) -> |X|^2 -> 80-bin mel, fused in ONE HIP kernel (af_features_kernel).
+(hop 256) -> |X|^2 -> 80-bin mel, fused in ONE HIP kernel (af_features_v2_kernel).
 One "step" = one pass of that kernel over the whole batch.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -25,7 +25,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement):
   roofline  = algorithmic bytes per launch / measured launch time vs 8 TB/s HBM
   cpu_baseline = the oracle's float32 port timed on this host (rank 0, N=1 only)
   check     = three clips of the result against the float64 oracle, after the timed region
-  secondary = BASELINE config 4's chain on the same shard, north_star's own 1024-clip batch, and the resampler
+  secondary = BASELINE config 4's chain on the same shard, north_star's own 1024-clip batch, the reference's wire path
+              (to_mono -> 48 -> 16 kHz -> PCM16 -> base64, af_wire_*) on that batch in one launch, and the resampler
               alone on config 3 and on 48 -> 44.1 kHz (N=1 only; each with its own oracle check, none is `value`)
 """
 from __future__ import annotations
@@ -153,6 +154,19 @@ def time_collectives(torch, dist, dev, mel, pcm, world: int, rank: int) -> dict:
             "scatter_bytes_per_rank": flat.numel() * flat.element_size()}
 
 
+HBM_COPY_GBS = 6300.0          # what a device-to-device copy reaches on these boxes: the achievable line
+
+
+def other_resources(recorded, achieved_gbs: float):
+    """roofline.other: the recorded busy fractions of LDS / VALU / MFMA (profiles/pmc_resources.json, separate rocprofv3
+    --pmc passes) with THIS run's HBM fractions beside them: of the 8 TB/s peak and of the 6.3 TB/s a device copy reaches."""
+    out = dict(recorded) if isinstance(recorded, dict) else {}
+    out["hbm_frac_of_8TBps"] = achieved_gbs / HBM_PEAK_GBS
+    out["hbm_frac_of_6p3TBps"] = achieved_gbs / HBM_COPY_GBS
+    out["hbm_fracs_source"] = "this run (roofline.achieved); the busy fractions beside them are recorded"
+    return out
+
+
 def make_result(m: dict) -> dict:
     """The JSON line from the measurements (pure: tests/test_bench_schema.py builds it on the CPU)."""
     steps = m["steps"]
@@ -192,7 +206,7 @@ def make_result(m: dict) -> dict:
             "algorithmic_bytes_per_launch": alg_bytes,
             # the path is above the ridge (46 flop/B at hop 256): the busy fractions of the other
             # resources, recorded by separate rocprofv3 --pmc passes (profiles/pmc_resources.json)
-            "other": m.get("other"),
+            "other": other_resources(m.get("other"), achieved),
         },
         "prewarm_s": m.get("prewarm_s"),
         # collectives timed apart from the kernel; "not measured" (null) at N = 1
@@ -412,6 +426,51 @@ def launch_ranks(args, argv) -> int:
     return rc
 
 
+def wire_secondary(torch, af, dev, pcm, n_clips: int, n_frames_pcm: int, stream) -> dict:
+    """The reference's wire path on the 1024-clip batch in ONE launch (af_wire_*: to_mono capture.rs:30-42 -> 48 -> 16 kHz
+    resampler.rs:60-93 -> PCM16 websocket.rs:246-251 -> base64 websocket.rs:254), messages of 320 samples
+    (specs/0002-design.md:1543-1546).  HIP events on the launch stream; one clip's messages are decoded and compared with
+    the reference-pinned oracle codec on the product's resampled f32 signal (exact) and with the float64 oracle chain
+    (within one LSB).  Algorithmic bytes: 8 B per stereo frame in + the characters out."""
+    import base64
+    import numpy as np
+    from oracle import pyoracle as po
+    w = af.WireEncoder(input_rate=SR, output_rate=16000, channels=CHANNELS, frame_samples=320)
+    total = w.set_batch_uniform(n_clips, n_frames_pcm)
+    text = torch.empty(total, dtype=torch.uint8, device=dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:
+        w.run_device(pcm.data_ptr(), text.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        w.run_device(pcm.data_ptr(), text.data_ptr(), 0, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg = n_clips * n_frames_pcm * CHANNELS * 4 + total
+    # one clip: decode its messages
+    c = n_clips // 2
+    per_clip = total // n_clips
+    row = text[c * per_clip:(c + 1) * per_clip].cpu().numpy().tobytes()
+    ml = w.message_len()
+    got = np.concatenate([np.frombuffer(base64.b64decode(row[k:k + ml]), "<i2") for k in range(0, len(row), ml)])
+    x = pcm[c].reshape(1, -1).cpu().numpy()
+    y = af.resample_stereo_batch(x, SR, 16000)[0]
+    want = po.quantize_pcm16(y)[:got.size]
+    ref64 = po.quantize_pcm16(po.resample(po.to_mono(x[0], CHANNELS), SR, 16000).astype(np.float32))[:got.size]
+    d = np.abs(got.astype(np.int32) - ref64.astype(np.int32))
+    return {"wire": {"workload": f"{n_clips} x {CLIP_SECONDS} s stereo {SR} Hz f32 -> to_mono -> 16 kHz -> PCM16 -> base64, messages of 320 samples, ONE launch",
+                     "ms": ms, "launches": w.n_launches(), "rtf": n_clips * CLIP_SECONDS / (ms * 1e-3),
+                     "algorithmic_bytes": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9,
+                     "frac_hbm": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "checked_clip": c, "samples_checked": int(got.size),
+                     "bytes_equal_oracle_codec_on_product_resampler": bool(np.array_equal(got, want)),
+                     "max_lsb_diff_vs_float64_oracle_chain": int(d.max()), "ok": bool(np.array_equal(got, want) and d.max() <= 1)}}
+
+
 def northstar_secondary(torch, af, dev, n_clips: int, n_frames_pcm: int, stream, device_index: int) -> dict:
     """north_star's own batch ("1024-clip 48 kHz batch at 1 GPU"): the headline kernel on 1024 x 30 s
     stereo clips (11.8 GB of PCM resident in HBM), HIP events on the launch stream, three sampled clips
@@ -435,7 +494,10 @@ def northstar_secondary(torch, af, dev, n_clips: int, n_frames_pcm: int, stream,
     ms = e0.elapsed_time(e1) / reps
     alg = n_clips * n_frames_pcm * CHANNELS * 4 + total * N_MELS * 4
     chk = oracle_check(pcm, mel, n_frames_pcm, pipe.n_frames(n_frames_pcm), n_clips)
-    return {"northstar_1024": {"workload": f"{n_clips} x {CLIP_SECONDS} s stereo {SR} Hz f32 -> STFT {N_FFT}/{HOP} -> {N_MELS} mel, 1 GPU",
+    del mel
+    wire = wire_secondary(torch, af, dev, pcm, n_clips, n_frames_pcm, stream)
+    return {**wire,
+            "northstar_1024": {"workload": f"{n_clips} x {CLIP_SECONDS} s stereo {SR} Hz f32 -> STFT {N_FFT}/{HOP} -> {N_MELS} mel, 1 GPU",
                                "ms": ms, "frames": total, "frames_per_s": total / (ms * 1e-3),
                                "rtf": n_clips * CLIP_SECONDS / (ms * 1e-3),
                                "frac_hbm": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
