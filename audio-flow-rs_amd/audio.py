@@ -865,7 +865,7 @@ class WireEncoder:
         quantised samples (int16) when asked for."""
         x = np.ascontiguousarray(pcm, self._dtype()).reshape(-1)
         text = np.empty(self.total_text, np.uint8)
-        q = np.empty(self.total_samples, np.int16) if with_pcm16 else None
+        q = np.full(self.total_samples, -21846, np.int16) if with_pcm16 else None
         _check(self._lib.af_wire_run(self._h, _ptr(x), x.size, _ptr(text), text.size,
                                      _ptr(q) if q is not None else None, q.size if q is not None else 0))
         return (text.tobytes(), q) if with_pcm16 else text.tobytes()

@@ -1243,13 +1243,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int it = tid; it < n_items; it += nthreads) {
                 int s0, cnt;                                         // first sample of the group in the tile, real samples
                 int64_t toff;                                        // its first character in the clip's text
+                bool send = true;                                    // the group's characters are part of the text
                 if (g.frame) {
                     const int f = it / g.gpf, j = it - f * g.gpf;
                     s0 = f * g.frame + 6 * j;
-                    const int left = g.frame - 6 * j;
-                    // only whole messages are sent (specs/0002-design.md:1543-1546)
+                    const int left = g.frame - 6 * j, have = y_hi - s0;
+                    cnt = left < 6 ? left : 6;
+                    cnt = have < cnt ? (have < 0 ? 0 : have) : cnt;
+                    // only whole messages are sent (specs/0002-design.md:1543-1546); the samples of a trailing partial
+                    // batch still go to the PCM16 row
                     const int64_t fa = y0 / g.frame + f;
-                    cnt = (fa + 1) * g.frame <= tc.n_res ? (left < 6 ? left : 6) : 0;
+                    send = (fa + 1) * g.frame <= tc.n_res;
                     toff = fa * g.row_len + 16 * j;
                 } else {
                     s0 = 6 * it;
@@ -1268,7 +1272,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
                 const uint4 o = pcmdev::b64_encode_words(w0, w1, w2);
                 char* dst = tc.tp + toff;
-                if (cnt == 6) {
+                if (!send) {
+                } else if (cnt == 6) {
                     if (g.text_align == 16) {
                         *reinterpret_cast<uint4*>(dst) = o;
                     } else if (g.text_align == 8) {

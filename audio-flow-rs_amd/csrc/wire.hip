@@ -51,18 +51,23 @@ __global__ void wire_encode_kernel(const float* __restrict__ y, int64_t y_stride
                                    int gpf, int row_len, char* __restrict__ text, int64_t text_stride, int16_t* __restrict__ pcm16,
                                    int64_t pcm_stride)
 {
-    const int64_t groups = frame ? (n_res / frame) * gpf : (n_res + 5) / 6;
+    // (messages: the trailing partial batch is walked too -- its samples go to the PCM16 row, its text is not sent)
+    const int64_t groups = frame ? ((n_res + frame - 1) / frame) * gpf : (n_res + 5) / 6;
     const int64_t total = groups * n_clips;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
         const int64_t clip = it / groups, gi = it - clip * groups;
         int64_t s0, toff;
         int cnt;
+        bool send = true;
         if (frame) {
             const int64_t f = gi / gpf;
             const int j = (int)(gi - f * gpf);
             s0 = f * frame + 6 * j;
             const int left = frame - 6 * j;
             cnt = left < 6 ? left : 6;
+            const int64_t have = n_res - s0;
+            cnt = have < cnt ? (have < 0 ? 0 : (int)have) : cnt;
+            send = (f + 1) * frame <= n_res;
             toff = f * row_len + 16 * j;
         } else {
             s0 = 6 * gi;
@@ -76,7 +81,9 @@ __global__ void wire_encode_kernel(const float* __restrict__ y, int64_t y_stride
         for (int e = 0; e < 6; ++e) q[e] = e < cnt ? (unsigned)pcmdev::quant1(src[e]) & 0xffffu : 0u;
         const uint4 o = pcmdev::b64_encode_words(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16));
         char* dst = text + clip * text_stride + toff;
-        if (cnt == 6) {
+        if (cnt <= 0) continue;
+        if (!send) {
+        } else if (cnt == 6) {
             const unsigned ow[4] = {o.x, o.y, o.z, o.w};
             if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
                 unsigned* d4 = reinterpret_cast<unsigned*>(dst);
@@ -325,7 +332,7 @@ af_status af_wire_run_device(af_wire* w, const void* pcm_dev, char* text_dev, in
         y = w->d_res.as<float>();
     }
     const int F = (int)w->cfg.frame_samples, gpf = (F + 5) / 6;
-    const int64_t groups = (F ? ((int64_t)w->n_res / F) * gpf : ((int64_t)w->n_res + 5) / 6) * (int64_t)w->n_clips;
+    const int64_t groups = (F ? (((int64_t)w->n_res + F - 1) / F) * gpf : ((int64_t)w->n_res + 5) / 6) * (int64_t)w->n_clips;
     if (groups <= 0) return AF_OK;
     int64_t grid = (groups + 255) / 256;
     if (grid > (1ll << 30)) grid = 1ll << 30;

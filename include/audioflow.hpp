@@ -6,6 +6,7 @@
 // error behaviour as the reference:
 //
 //   AudioFrame::to_mono                 capture.rs:30
+//   WireEncoder (to_mono + 48 -> 16 kHz + PCM16 + base64 in one launch)   capture.rs:30-42, resampler.rs:60-93, websocket.rs:244-254
 //   RingBuffer::{new_, write, read, available, clear}                     capture.rs:93-160
 //   AudioResampler::{new_, create_48k_to_16k, process, input_rate, ...}   resampler.rs:32-108
 //   BatchResampler::{new_, process, flush}                                resampler.rs:121-166
@@ -236,6 +237,16 @@ inline std::vector<int16_t> quantize_pcm16(const std::vector<float>& audio)
 {
     std::vector<int16_t> out(audio.size());
     detail::check(af_quantize_pcm16(audio.data(), audio.size(), out.data()));
+    return out;
+}
+
+// websocket.rs:246-254: the quantiser followed by STANDARD.encode -- the `audio_base_64` payload of send_audio
+inline std::string pcm16_base64(const std::vector<float>& audio)
+{
+    std::string out(af_base64_len(2 * audio.size()), '\0');
+    size_t n = 0;
+    detail::check(af_pcm16_base64(audio.data(), audio.size(), out.empty() ? nullptr : &out[0], out.size(), &n));
+    out.resize(n);
     return out;
 }
 
@@ -561,6 +572,64 @@ public:
 private:
     af_chain_stream* h_ = nullptr;
     uint32_t channels_ = 2;
+};
+
+// The reference's capture -> wire path on a batch of clips in ONE launch (af_wire_*): interleaved PCM ->
+// AudioFrame::to_mono (capture.rs:30-42) -> AudioResampler::create_48k_to_16k / process (resampler.rs:60-93) ->
+// (x.clamp(-1, 1) * 32767.0) as i16, little-endian (websocket.rs:246-251) -> STANDARD.encode (websocket.rs:254).
+// frame_samples = 0: one padded base64 string per clip; 320: one per 20 ms send batch (specs/0002-design.md:1543-1546),
+// a trailing partial batch is not sent.  T = float or int16_t PCM.
+class WireEncoder {
+public:
+    WireEncoder(uint32_t input_rate = 48000, uint32_t output_rate = 16000, uint32_t channels = 2,
+                uint32_t sample_format = AF_PCM_F32, uint32_t frame_samples = 0)
+    {
+        af_wire_config cfg;
+        af_wire_default_config(&cfg);
+        cfg.input_rate = input_rate;
+        cfg.output_rate = output_rate;
+        cfg.channels = channels;
+        cfg.sample_format = sample_format;
+        cfg.frame_samples = frame_samples;
+        detail::check(af_wire_create(&cfg, &h_));
+    }
+    WireEncoder(const WireEncoder&) = delete;
+    WireEncoder& operator=(const WireEncoder&) = delete;
+    ~WireEncoder() { af_wire_destroy(h_); }
+
+    size_t out_samples(size_t n_frames) const { return af_wire_out_samples(h_, n_frames); }
+    size_t text_len(size_t n_frames) const { return af_wire_text_len(h_, n_frames); }
+    size_t message_len() const { return af_wire_message_len(h_); }
+    size_t n_messages(size_t n_frames) const { return af_wire_n_messages(h_, n_frames); }
+    int n_launches() const { return af_wire_n_launches(h_); }
+    void set_option(const char* key, int value) { detail::check(af_wire_set_option(h_, key, value)); }
+    // the batch's text, clips back to back (cut it with text_len / message_len); pcm16 (optional) gets the samples
+    template <class T>
+    std::string run(const std::vector<T>& pcm, size_t n_clips, size_t frames_per_clip, std::vector<int16_t>* pcm16 = nullptr)
+    {
+        size_t total = 0, samples = 0;
+        detail::check(af_wire_set_batch_uniform(h_, n_clips, frames_per_clip, &total, &samples));
+        return run_described(pcm, total, samples, pcm16);
+    }
+    template <class T>
+    std::string run_ragged(const std::vector<T>& pcm, const std::vector<int64_t>& clip_offsets, std::vector<int16_t>* pcm16 = nullptr)
+    {
+        size_t total = 0, samples = 0;
+        detail::check(af_wire_set_batch(h_, clip_offsets.data(), clip_offsets.empty() ? 0 : clip_offsets.size() - 1, &total, &samples));
+        return run_described(pcm, total, samples, pcm16);
+    }
+
+private:
+    template <class T>
+    std::string run_described(const std::vector<T>& pcm, size_t total, size_t samples, std::vector<int16_t>* pcm16)
+    {
+        std::string text(total, '\0');
+        if (pcm16) pcm16->assign(samples, 0);
+        detail::check(af_wire_run(h_, pcm.data(), pcm.size(), text.empty() ? nullptr : &text[0], text.size(),
+                                  pcm16 ? pcm16->data() : nullptr, pcm16 ? pcm16->size() : 0));
+        return text;
+    }
+    af_wire* h_ = nullptr;
 };
 
 }  // namespace audioflow

@@ -53,6 +53,11 @@ pub struct af_chain_config {
     pub sample_format: u32,
 }
 #[repr(C)] #[derive(Clone, Copy, Debug)]
+pub struct af_wire_config {
+    pub input_rate: u32, pub output_rate: u32, pub channels: u32, pub sample_format: u32, pub frame_samples: u32, pub device: i32,
+}
+#[repr(C)] pub struct af_wire { _private: [u8; 0] }
+#[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct af_stream_config { pub features: af_features_config, pub step_frames: usize }
 
 extern "C" {
@@ -157,6 +162,21 @@ extern "C" {
     pub fn af_chain_stream_first_step_frames(s: *const af_chain_stream) -> usize;
     pub fn af_chain_stream_history_frames(s: *const af_chain_stream) -> usize;
     pub fn af_chain_stream_seek(s: *mut af_chain_stream, step: u64, first_frame: *mut u64) -> af_status;
+    // the capture -> wire path in one launch (capture.rs:30-42, resampler.rs:60-93, websocket.rs:244-254)
+    pub fn af_wire_default_config(cfg: *mut af_wire_config);
+    pub fn af_wire_create(cfg: *const af_wire_config, out: *mut *mut af_wire) -> af_status;
+    pub fn af_wire_destroy(w: *mut af_wire);
+    pub fn af_wire_out_samples(w: *const af_wire, n_frames: usize) -> usize;
+    pub fn af_wire_text_len(w: *const af_wire, n_frames: usize) -> usize;
+    pub fn af_wire_message_len(w: *const af_wire) -> usize;
+    pub fn af_wire_n_messages(w: *const af_wire, n_frames: usize) -> usize;
+    pub fn af_wire_set_batch_uniform(w: *mut af_wire, n_clips: usize, frames_per_clip: usize, total_text: *mut usize, total_samples: *mut usize) -> af_status;
+    pub fn af_wire_set_batch(w: *mut af_wire, clip_offsets: *const i64, n_clips: usize, total_text: *mut usize, total_samples: *mut usize) -> af_status;
+    pub fn af_wire_text_offsets(w: *const af_wire, text_off: *mut i64, cap: usize) -> af_status;
+    pub fn af_wire_run_device(w: *mut af_wire, pcm_dev: *const c_void, text_dev: *mut c_char, pcm16_dev: *mut i16, stream: *mut c_void) -> af_status;
+    pub fn af_wire_run(w: *mut af_wire, pcm: *const c_void, pcm_len: usize, text: *mut c_char, text_cap: usize, pcm16: *mut i16, pcm16_cap: usize) -> af_status;
+    pub fn af_wire_set_option(w: *mut af_wire, key: *const c_char, value: c_int) -> af_status;
+    pub fn af_wire_n_launches(w: *const af_wire) -> c_int;
     pub fn af_resample_release_staging();
     // optional cubic mode (what resampler.rs:43-49 configures; docs/OPS.md "Cubic interpolation", parity unpinned)
     pub fn af_resample_cubic_batch(input_rate: u32, output_rate: u32, input: *const f32, n_clips: usize, n_in: usize,

@@ -531,6 +531,65 @@ impl<T: PcmSample> ChainPipeline<T> {
 }
 impl<T: PcmSample> Drop for ChainPipeline<T> { fn drop(&mut self) { unsafe { ffi::af_chain_destroy(self.h) } } }
 
+/// The reference's capture -> wire path on a batch of clips in ONE launch: interleaved PCM -> `AudioFrame::to_mono`
+/// (capture.rs:30-42) -> `AudioResampler::create_48k_to_16k` / `process` (resampler.rs:60-93) ->
+/// `(x.clamp(-1.0, 1.0) * 32767.0) as i16`, little-endian (websocket.rs:246-251) -> `STANDARD.encode` (websocket.rs:254).
+/// `frame_samples == 0`: one padded base64 string per clip; `320`: one per 20 ms send batch
+/// (specs/0002-design.md:1543-1546; a trailing partial batch is not sent, as `AudioBatcher` keeps it buffered).
+pub struct WireEncoder<T: PcmSample = f32> { h: *mut ffi::af_wire, _t: std::marker::PhantomData<T> }
+unsafe impl<T: PcmSample> Send for WireEncoder<T> {}
+
+impl<T: PcmSample> WireEncoder<T> {
+    pub fn new(input_rate: u32, output_rate: u32, channels: u32, frame_samples: u32) -> Result<Self, AudioError> {
+        let mut cfg = ffi::af_wire_config { input_rate: 0, output_rate: 0, channels: 0, sample_format: 0, frame_samples: 0, device: -1 };
+        unsafe { ffi::af_wire_default_config(&mut cfg) };
+        cfg.input_rate = input_rate;
+        cfg.output_rate = output_rate;
+        cfg.channels = channels;
+        cfg.sample_format = T::FORMAT;
+        cfg.frame_samples = frame_samples;
+        let mut h = ptr::null_mut();
+        check(unsafe { ffi::af_wire_create(&cfg, &mut h) })?;
+        Ok(Self { h, _t: std::marker::PhantomData })
+    }
+    /// `AudioResampler::create_48k_to_16k` (resampler.rs:60-62) + the 20 ms batch of specs/0002-design.md:1543-1546
+    pub fn create_48k_to_16k_messages(channels: u32) -> Result<Self, AudioError> { Self::new(48000, 16000, channels, 320) }
+    pub fn out_samples(&self, n_frames: usize) -> usize { unsafe { ffi::af_wire_out_samples(self.h, n_frames) } }
+    pub fn message_len(&self) -> usize { unsafe { ffi::af_wire_message_len(self.h) } }
+    pub fn n_messages(&self, n_frames: usize) -> usize { unsafe { ffi::af_wire_n_messages(self.h, n_frames) } }
+    /// kernels one pass enqueues (1 with the fused launch)
+    pub fn n_launches(&self) -> usize { unsafe { ffi::af_wire_n_launches(self.h) as usize } }
+    /// equal-length clips back to back in `pcm`; returns, per clip, its base64 payloads (one per message, or the one string)
+    pub fn run(&mut self, pcm: &[T], n_clips: usize, frames_per_clip: usize) -> Result<Vec<Vec<String>>, AudioError> {
+        let (mut total, mut samples) = (0usize, 0usize);
+        check(unsafe { ffi::af_wire_set_batch_uniform(self.h, n_clips, frames_per_clip, &mut total, &mut samples) })?;
+        self.run_described(pcm, n_clips, total)
+    }
+    /// ragged batch: clip i = PCM frames [clip_offsets[i], clip_offsets[i + 1]) of `pcm`
+    pub fn run_ragged(&mut self, pcm: &[T], clip_offsets: &[i64]) -> Result<Vec<Vec<String>>, AudioError> {
+        let (mut total, mut samples) = (0usize, 0usize);
+        let n = clip_offsets.len().saturating_sub(1);
+        check(unsafe { ffi::af_wire_set_batch(self.h, clip_offsets.as_ptr(), n, &mut total, &mut samples) })?;
+        self.run_described(pcm, n, total)
+    }
+    fn run_described(&mut self, pcm: &[T], n_clips: usize, total: usize) -> Result<Vec<Vec<String>>, AudioError> {
+        let mut text = vec![0u8; total];
+        check(unsafe { ffi::af_wire_run(self.h, pcm.as_ptr() as *const c_void, pcm.len(), text.as_mut_ptr() as *mut _, text.len(), ptr::null_mut(), 0) })?;
+        let mut off = vec![0i64; n_clips + 1];
+        check(unsafe { ffi::af_wire_text_offsets(self.h, off.as_mut_ptr(), off.len()) })?;
+        let ml = self.message_len();
+        let mut out = Vec::with_capacity(n_clips);
+        for i in 0..n_clips {
+            let row = &text[off[i] as usize..off[i + 1] as usize];
+            // base64 is ASCII: from_utf8_lossy never replaces anything
+            let cut = if ml > 0 { ml } else { row.len().max(1) };
+            out.push(row.chunks(cut).map(|m| String::from_utf8_lossy(m).into_owned()).collect());
+        }
+        Ok(out)
+    }
+}
+impl<T: PcmSample> Drop for WireEncoder<T> { fn drop(&mut self) { unsafe { ffi::af_wire_destroy(self.h) } } }
+
 /// BASELINE config 5 on the whole chain: the handle owns the resampler history, the FIR's K - 1 samples and the
 /// STFT's n_fft - hop carry, and replays one captured hipGraph per step; `push` returns the rows of every step it
 /// completed, `flush` the rest, and all rows in order equal `ChainPipeline::run` on the whole stream bit for bit.

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "audioflow.hpp"
@@ -238,6 +239,40 @@ int main()
         tail_rows.insert(tail_rows.end(), tail_flush.begin(), tail_flush.end());
         const size_t rows0 = 184320 / 3 / 256 * 80;
         CHECK(tail_rows.size() == whole.size() - rows0 && std::equal(tail_rows.begin(), tail_rows.end(), whole.begin() + rows0));
+    }
+    // WireEncoder: the capture -> wire path in one launch (capture.rs:30-42, resampler.rs:60-93, websocket.rs:244-254);
+    // 20 ms messages of 320 samples (specs/0002-design.md:1543-1546): each equals MessageBuilder::audio_message's
+    // payload for the same samples, a trailing partial batch is not sent
+    {
+        const size_t n = 48000 + 601;                         // 16 201 resampled samples: 50 messages + 201 left over
+        std::vector<float> x(2 * n);
+        for (size_t i = 0; i < n; ++i) {
+            x[2 * i] = 2.6f * std::sin(0.013f * (float)i);    // the downmix goes beyond +-1: the quantiser clamps
+            x[2 * i + 1] = 0.3f * std::cos(0.0071f * (float)i);
+        }
+        WireEncoder w(48000, 16000, 2, AF_PCM_F32, 320);
+        std::vector<int16_t> q;
+        const std::string text = w.run(x, 1, n, &q);
+        CHECK(w.n_launches() == 1 && w.message_len() == 856 && w.n_messages(n) == 50);
+        CHECK(text.size() == 50 * 856 && q.size() == w.out_samples(n) && w.out_samples(n) == 16201);
+        // the same samples through the stand-alone stages: to_mono, AudioResampler, quantiser + base64
+        auto mono = AudioFrame::new_(x, 48000, 2, 0).to_mono();
+        auto r = AudioResampler::new_(48000, 16000);
+        auto y = r.process(mono.samples);
+        auto tail = r.flush();
+        y.insert(y.end(), tail.begin(), tail.end());
+        CHECK(y.size() == 16201);
+        const auto q_ref = quantize_pcm16(y);
+        CHECK(std::equal(q.begin(), q.end(), q_ref.begin()));
+        CHECK(*std::max_element(q.begin(), q.end()) == 32767);
+        for (size_t k : {size_t(0), size_t(17), size_t(49)}) {
+            const std::vector<float> frame(y.begin() + 320 * k, y.begin() + 320 * (k + 1));
+            CHECK(text.substr(856 * k, 856) == pcm16_base64(frame));
+        }
+        // one string per clip
+        WireEncoder w0;
+        const std::string whole = w0.run(x, 1, n);
+        CHECK(whole == pcm16_base64(y));
     }
     std::printf(failures ? "%d check(s) failed\n" : "harness ok\n", failures);
     return failures ? 1 : 0;

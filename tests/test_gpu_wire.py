@@ -120,9 +120,19 @@ def test_wire_messages(af, po, frame):
         for k in (0, 1, len(msgs[i]) // 2, len(msgs[i]) - 1):
             assert msgs[i][k] == af.MessageBuilder.audio_base64(y[i, k * frame:(k + 1) * frame])    # websocket.rs:246-254
             assert msgs[i][k].encode() == _b64(po.quantize_pcm16(y[i, k * frame:(k + 1) * frame]))
-    whole = w.run(x)
-    w.set_option("unfused", 1)
-    assert w.run(x) == whole
+    whole, q = w.run(x, with_pcm16=True)
+    # the PCM16 rows hold every resampled sample, those of the unsent trailing batch included
+    assert bits_equal(q, np.concatenate([po.quantize_pcm16(y[i]) for i in range(n_clips)]))
+    # (device buffers poisoned first: a sample the launch does not write would show)
+    import torch
+    xd = torch.from_numpy(x).cuda()
+    for unfused in (0, 1):
+        w.set_option("unfused", unfused)
+        td = torch.full((w.total_text,), 0x23, dtype=torch.uint8, device="cuda")
+        qd = torch.full((w.total_samples,), -21846, dtype=torch.int16, device="cuda")
+        w.run_device(xd.data_ptr(), td.data_ptr(), qd.data_ptr())
+        torch.cuda.synchronize()
+        assert td.cpu().numpy().tobytes() == whole and bits_equal(qd.cpu().numpy(), q)
 
 
 def test_wire_frame_outside_the_fused_tile_runs_the_stages(af, po):
