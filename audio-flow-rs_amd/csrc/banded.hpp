@@ -108,9 +108,18 @@ struct FusedPlan {
     int shift = 0, seg_stride_a = 0;   // x segments in LDS (pair formats: one frame early when the origin is odd)
     int64_t z_per_tile = 0;    // 256 * P2
     size_t smem = 0;
+    // ten block matrices (44.1 k -> 16 k; resfir10_kernel): a tile is 5 120 resampled samples AND 5 120 FIR outputs, the
+    // K - 1 samples in front of it come from the previous tile through LDS (H2 = 0: nothing is recomputed inside a
+    // workgroup's contiguous range of tiles); a range that starts inside a clip runs phase A of `lead_tiles` = 1 tile
+    // in front of it first, so a window of a stream must have that tile's input in its buffer
+    int nbk = 1;               // block matrices of the resampler: 1 (resfir_kernel) or 10 (resfir10_kernel)
+    int lead_tiles = 0;
+    int carry_off = 0;         // floats: the two carry buffers behind the segments
     size_t afrag_b_floats() const { return (size_t)NKB * 64; }
 };
 FusedPlan make_fused_plan(const Plan& resampler, int K, int fmt);
+// x index (frames from sample 0 of the stream) of the first sample tile t of the fused launch stages
+int64_t fused_tile_base(const FusedPlan& f, int64_t t);
 af_status build_fused_fir_afrag(const FusedPlan& f, const float* taps_dev, float* afrag_dev, hipStream_t stream);
 
 // One tile of a ragged batch (32 bytes, one scalar load): which clip, which tile of it.

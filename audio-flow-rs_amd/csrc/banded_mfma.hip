@@ -387,12 +387,16 @@ __device__ __forceinline__ int sload_int(const int* base, int idx)
 // resource its time belongs to: 1 x requests, 2 stores, 4 fragment requests (first tile's stay), 8 MFMAs (one VALU
 // operation each instead), 16 staging writes, 32 barriers, 64 the whole chain arithmetic (memory side only), 128 stores go to the
 // wrong place, 1 KB contiguous per instruction, 256 to the wrong place in 128-byte runs from two consecutive instructions,
-// 512 to the wrong place in 128-byte runs inside one instruction.  Results are garbage; bounds stay checked by the hardware.
+// 512 to the wrong place in 128-byte runs inside one instruction, 1024 all fragment requests go to the first matrix's cache
+// lines.  Results are garbage; bounds stay checked by the hardware.
 #ifndef AF_STREAM_ABL
 #define AF_STREAM_ABL 0
 #endif
 #ifndef AF_STREAM_OB
 #define AF_STREAM_OB 1
+#endif
+#ifndef AF_STREAM_CONTIG
+#define AF_STREAM_CONTIG 1
 #endif
 // largest matrix range of a tile (experiment: 16 = always small enough for the deferred stores)
 #ifndef AF_STREAM_PMAX
@@ -458,7 +462,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if ((AF_STREAM_ABL & 4) && have_a && slot == 0) return;
         if ((AF_STREAM_ABL & 4) && slot == 1) return;
         have_a = true;
-        const f32x4* ap = reinterpret_cast<const f32x4*>(g.afrag) + ((size_t)p * (NK / 4)) * 64 + lane + opaque_zero();
+        // (AF_STREAM_ABL & 1024, diagnostic: every matrix's fragments read from the first matrix's lines -- the table stays in
+        // the nearest cache, so what FETCH_SIZE loses against the product is the table's share of the fetched bytes)
+        const f32x4* ap = reinterpret_cast<const f32x4*>(g.afrag) + ((size_t)((AF_STREAM_ABL & 1024) ? 0 : p) * (NK / 4)) * 64 + lane + opaque_zero();
 #pragma unroll
         for (int t4 = 0; t4 < NK / 4; ++t4) {
             const f32x4 v = ap[t4 * 64];
@@ -517,21 +523,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     };
 
+    // AF_STREAM_CONTIG: a workgroup takes a CONTIGUOUS run of tiles (the matrix ranges of one period group vary fastest
+    // over the tile index): the window halo between neighbouring ranges, 27 % of what a range stages at 48 -> 44.1 kHz, is
+    // then re-read by the workgroup that fetched it a tile ago, from its own XCD's L2.  Dealt round-robin (tile += grid,
+    // rounds 3-4) the ranges of a period group sit on different XCDs and every halo is a second HBM fetch:
+    // FETCH_SIZE 8.64 GB for 5.90 GB of x (profiles/r05_stream_traffic.txt).
+#if AF_STREAM_CONTIG
+    const uint32_t tile_end = (uint32_t)(((uint64_t)n_tiles * (blockIdx.x + 1)) / gridDim.x);
+    uint32_t tile = (uint32_t)(((uint64_t)n_tiles * blockIdx.x) / gridDim.x);
+    constexpr uint32_t kTileStepGrid = 0;
+#else
+    const uint32_t tile_end = n_tiles;
     uint32_t tile = blockIdx.x;
+    constexpr uint32_t kTileStepGrid = 1;
+#endif
     TileQ tq{};
-    if (tile < n_tiles) {
+    if (tile < tile_end) {
         tq = load_q(tile);
         prep_tile(tile, true, tq.q0);
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) issue_load(i);
     }
-    for (; tile < n_tiles;) {
-        const uint32_t next_tile = tile + gridDim.x;
+    for (; tile < tile_end;) {
+        const uint32_t next_tile = tile + (kTileStepGrid ? gridDim.x : 1u);
         const uint32_t clip = tile / tiles_per_clip, r = tile - clip * tiles_per_clip;
         const int64_t pg = g.pg0 + r / (uint32_t)g.n_pr;
         int p0, p_end;
         range_of(tile, p0, p_end);
-        const bool live = next_tile < n_tiles;
+        const bool live = next_tile < tile_end;
         const TileQ cq = tq;                                        // this tile's; the next tile's are requested now
         if (live) tq = load_q(next_tile);
         // matrices p0 + wave + 8 i, i < n_m.  Both fragment slots are free here: the first matrix is requested now and
@@ -694,6 +713,10 @@ struct FusedGeom {
     int shift;                       // pair formats: frames in front of a segment so that frame pairs load aligned
     int H2, pad, P2, seg_len_b, seg_stride_b, ys_off;
     float inv_colz;                  // 1 / (16 P2)
+    // resfir10_kernel (ratios with ten block matrices) only:
+    uint32_t L, M;                   // q(16 p) = floor(16 p M / L) per wave
+    int K;                           // FIR taps: the K - 1 resampled samples in front of a tile are carried in LDS
+    int carry_off;                   // floats from the start of LDS: two carry buffers of kCarry floats
 };
 
 // What a tile needs to know about its clip (wave-uniform: SGPRs).
@@ -1003,6 +1026,277 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+
+// ---- resampler + FIR in one launch for ratios with TEN block matrices (44.1 k -> 16 k: L / M = 160 / 441) -------------
+// The everyday device rate (capture.rs:60-80 takes what the device offers; BASELINE config 3's ratio).  Ten waves, wave p
+// owns block matrix p for the whole launch (its fragments and the FIR's stay in registers: one workgroup per CU leaves
+// 168 registers per lane); a tile is 16 columns x 2 block periods x 10 matrices x 16 = 5 120 resampled samples (phase A,
+// banded_kernel's ten-wave shape) and the SAME 5 120 FIR outputs (phase B: 20 block periods per column, one chain pair per
+// wave) -- nothing is recomputed: the K - 1 resampled samples in front of a tile are the previous tile's last ones and stay
+// in LDS.  For that a workgroup takes a CONTIGUOUS range of tiles; where a range starts inside a clip, phase A of the tile
+// in front of it runs first ("warm": no FIR, no output), once per range.  Block alignment, k-slot mapping and chain
+// order are those of the stand-alone kernels, tiles are anchored at absolute output 0 (5 120 = 32 rounds of the ten
+// matrices), so the bits do not depend on how a batch or a stream was cut.
+constexpr int kCarry = 128;           // K - 1 <= 128 resampled samples carried between consecutive tiles
+
+template <int NKA, int NKB, int FMT>
+__global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) void resfir10_kernel(const FusedGeom g)
+{
+    using F = FusedFmt<FMT>;
+    constexpr bool PAIR = F::kPair;
+    constexpr int BPF = F::kBytesPerFrame;
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    float* ys = xs + g.ys_off;
+    float* cw = xs + g.carry_off;
+    constexpr int FULLA = NKA / 16, TAILA = NKA % 16, FULLB = NKB / 16, TAILB = NKB % 16;
+    constexpr int nthreads = 640, NB = 10, kG = 2, P2 = 20, colz = 16 * P2, y_per_tile = 256 * P2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = block matrix p
+    const int col = lane & 15, g4 = lane >> 4;
+    const int qp = (int)(((int64_t)16 * wave * g.M) / g.L);          // q(16 p)
+
+    const int base_full_a = col * g.seg_stride + 16 * g4 + qp + g.shift;
+    const int base_tail_a = col * g.seg_stride + TAILA * g4 + 64 * FULLA + qp + g.shift;
+    const int wave_off_b = wave * 2 * 16;
+    const int base_full_b = col * g.seg_stride_b + 16 * g4 + wave_off_b;
+    const int base_tail_b = col * g.seg_stride_b + TAILB * g4 + 64 * FULLB + wave_off_b;
+    const int y_lane = 16 * NB * (kG * col) + 16 * wave + 4 * g4;     // tile-relative resampled index of acc0[0]; acc1: + 160
+    const int z_lane = 16 * (col * P2 + wave * 2) + 4 * g4;          // tile-relative FIR output of acc0[0]
+    const int col_span = kG * g.S;
+    const int km1 = g.K - 1;
+    const bool first = PAIR ? 2 * tid < g.seg_len + g.shift : tid < g.seg_len;
+    const bool second = !PAIR && tid + nthreads < g.seg_len;
+    const uint32_t tpc = (uint32_t)g.tiles_per_clip, n_tiles = (uint32_t)g.n_tiles;
+
+    // this workgroup's contiguous range of tiles
+    const uint32_t r0 = (uint32_t)(((uint64_t)n_tiles * blockIdx.x) / gridDim.x);
+    const uint32_t r1 = (uint32_t)(((uint64_t)n_tiles * (blockIdx.x + 1)) / gridDim.x);
+    if (r0 >= r1) return;
+
+    // (tile, warm): warm = phase A of the tile IN FRONT of `tile` (same clip), for its last K - 1 samples
+    auto tile_ctx = [&](uint32_t tile, bool warm) {
+        TileCtx c;
+        if (g.tiles) {
+            typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+            typedef const __attribute__((address_space(4))) u32x8* cptr;
+            const u32x8 r = reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(g.tiles))[__builtin_amdgcn_readfirstlane(tile)];
+            const int64_t x_off = (int64_t)(((unsigned long long)r[1] << 32) | r[0]);
+            const int64_t z_off = (int64_t)(((unsigned long long)r[3] << 32) | r[2]);
+            c.xp = static_cast<const char*>(g.x) + x_off * BPF;
+            c.zp = g.z + z_off;
+            c.x_bytes = r[4] * (uint32_t)BPF;
+            c.n_res = (int64_t)r[5];
+            c.t_abs = (int64_t)r[6];
+            c.m_lo = 0;
+            c.m_hi = c.n_res;
+        } else {
+            const uint32_t clip = tile / tpc;
+            c.xp = static_cast<const char*>(g.x) + (int64_t)clip * g.x_stride * BPF;
+            c.zp = g.z + (int64_t)clip * g.z_stride - g.m0;
+            c.x_bytes = (uint32_t)(g.x_len * BPF);
+            c.n_res = g.n_res;
+            c.t_abs = g.tile0 + (tile - clip * tpc);
+            c.m_lo = g.m0;
+            c.m_hi = g.m0 + g.n_out < g.n_res ? g.m0 + g.n_out : g.n_res;
+        }
+        if (warm) c.t_abs -= 1;
+        return c;
+    };
+    // does `tile` continue the tile before it (same clip, next t)?  Otherwise it starts a clip (or a stream window).
+    auto continues = [&](uint32_t tile) {
+        if (g.tiles) {
+            typedef const __attribute__((address_space(4))) int* cptr;
+            return reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(g.tiles))[8 * (size_t)__builtin_amdgcn_readfirstlane(tile) + 6] != 0;
+        }
+        return tile % tpc != 0;
+    };
+    auto needs_warm = [&](uint32_t tile, bool prev_done) {
+        // the K - 1 samples in front of the tile: zeros at a clip's start, the previous tile's if this workgroup has just
+        // computed it, otherwise a warm pass
+        if (prev_done && continues(tile)) return false;
+        return tile_ctx(tile, false).t_abs > 0;
+    };
+
+    float a1[NKA], a2[NKB];
+#pragma unroll
+    for (int t = 0; t < NKA; ++t) a1[t] = g.afrag_a[((size_t)wave * NKA + t) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < NKB; ++t) a2[t] = g.afrag_b[t * 64 + lane];
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0), visible to the compiler (see wire_kernel)
+#pragma unroll
+    for (int t = 0; t < NKA; ++t) asm volatile("" : "+v"(a1[t]));
+#pragma unroll
+    for (int t = 0; t < NKB; ++t) asm volatile("" : "+v"(a2[t]));
+
+    constexpr uint32_t kOob = 0xFFF00000u;
+    constexpr int kLoads = PAIR ? kCols : kCols * kPfSlots;
+    constexpr int kRegs = kCols * F::kRegsPerCol;
+    float pf[kRegs];
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[kPfSlots];
+    uint32_t x_frames = 0;
+    auto prep_tile = [&](uint32_t tile, bool warm, bool live) {
+        const TileCtx c = tile_ctx(tile, warm);
+        // x index of the first staged sample of the tile: 32 rounds of the ten matrices = 32 S input samples per tile
+        const int64_t base = c.t_abs * (int64_t)(16 * kG) * g.S + g.lo_off - g.shift - g.x_abs0;
+        if constexpr (FMT == 3) x_frames = c.x_bytes >> 1;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.xp), 0, (int)(FMT == 3 ? (c.x_bytes + 2u) & ~3u : c.x_bytes),
+                                                 0x00020000);
+        if constexpr (PAIR) {
+            const uint32_t v0 = ((uint32_t)base + 2u * (uint32_t)(tid + opaque_zero())) * (uint32_t)BPF;
+            voff[0] = live && first ? v0 : kOob;
+        } else {
+            const uint32_t v0 = ((uint32_t)base + (uint32_t)(tid + opaque_zero())) * 4u;
+            voff[0] = live && first ? v0 : kOob;
+            voff[1] = live && second ? v0 + (uint32_t)nthreads * 4u : kOob;
+        }
+    };
+    auto issue_load = [&](int s) {
+        if constexpr (FMT == 0) {                                   // s = h * 16 + cc
+            const int cc = s % kCols, h = s / kCols;
+            pf[cc * kPfSlots + h] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[h] + (uint32_t)(cc * col_span) * 4u), 0, AF_X_AUX));
+        } else if constexpr (FMT == 1) {                            // s = cc
+            const f32x4 v = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 8u), 0, AF_X_AUX));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[s * 4 + i] = v[i];
+        } else if constexpr (FMT == 2) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 v = __builtin_bit_cast(
+                f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 4u), 0, AF_X_AUX));
+            pf[s * 2] = v[0];
+            pf[s * 2 + 1] = v[1];
+        } else {
+            pf[s] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff[0] + (uint32_t)(s * col_span) * 2u), 0, AF_X_AUX));
+        }
+    };
+    auto staged_pair = [&](int cc, float& m0, float& m1) {
+        auto lo16 = [](float w) { return (float)(int16_t)(__float_as_uint(w) & 0xffffu) * (1.0f / 32768.0f); };
+        auto hi16 = [](float w) { return (float)(int16_t)(__float_as_uint(w) >> 16) * (1.0f / 32768.0f); };
+        if constexpr (FMT == 1) {
+            m0 = (pf[cc * 4] + pf[cc * 4 + 1]) * 0.5f;
+            m1 = (pf[cc * 4 + 2] + pf[cc * 4 + 3]) * 0.5f;
+        } else if constexpr (FMT == 2) {
+            m0 = (lo16(pf[cc * 2]) + hi16(pf[cc * 2])) * 0.5f;
+            m1 = (lo16(pf[cc * 2 + 1]) + hi16(pf[cc * 2 + 1])) * 0.5f;
+        } else {
+            m0 = lo16(pf[cc]);
+            const uint32_t b1 = voff[0] + (uint32_t)(cc * col_span) * 2u + 2u;
+            m1 = b1 < 2u * x_frames ? hi16(pf[cc]) : 0.0f;
+        }
+    };
+
+    uint32_t tile = r0;
+    bool warm = needs_warm(r0, false);
+    int par = 0;                                                    // carry buffer phase A of this pass writes
+    prep_tile(tile, warm, true);
+#pragma unroll
+    for (int s2 = 0; s2 < kLoads; ++s2) issue_load(s2);
+    while (tile < r1) {
+        // (no barrier here: xs was last read in phase A, ys in phase B of the previous pass; a wave writes xs before, and
+        // ys after, the next barrier, which every wave reaches after its own phase B)
+        {
+            if constexpr (PAIR) {
+                float* dst = xs + 2 * (tid + opaque_zero());
+                if (first) {
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc) {
+                        float m0, m1;
+                        staged_pair(cc, m0, m1);
+                        dst[cc * g.seg_stride] = m0;
+                        dst[cc * g.seg_stride + 1] = m1;
+                    }
+                }
+            } else {
+                float* dst = xs + tid + opaque_zero();
+                if (first) {
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride] = pf[cc * kPfSlots];
+                }
+                if (second) {
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc) dst[cc * g.seg_stride + nthreads] = pf[cc * kPfSlots + 1];
+                }
+            }
+        }
+        __syncthreads();
+        const TileCtx tc = tile_ctx(tile, warm);
+        // the pass after this one
+        const uint32_t tile_n = warm ? tile : tile + 1;
+        const bool live_n = tile_n < r1;
+        const bool warm_n = warm ? false : (live_n ? needs_warm(tile_n, true) : false);
+        prep_tile(live_n ? tile_n : tile, warm_n, live_n);
+
+        // ---- phase A: resampled samples [y0, y0 + 5 120) into the FIR's column segments ----
+        const int64_t y0 = tc.t_abs * y_per_tile;
+        {
+            // the FIR's history in front of the tile: zeros at a clip's start, else the previous pass's carry
+            if (!warm && tid < km1) ys[tid] = tc.t_abs > 0 ? cw[(par ^ 1) * kCarry + tid] : 0.0f;
+            const int64_t y_left = tc.n_res - y0;
+            const int y_hi = y_left > y_per_tile ? y_per_tile : y_left < 0 ? 0 : (int)y_left;
+            const float* b0p = xs + base_full_a;
+            const float* t0p = xs + base_tail_a;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            chain2<NKA>(a1, b0p, b0p + g.S, t0p, t0p + g.S, acc0, acc1, [&](int t) {
+                constexpr int kSpan = (NKA + 1) / 2;
+                if (t < kSpan) {
+#pragma unroll
+                    for (int s2 = (kLoads * t) / kSpan; s2 < (kLoads * (t + 1)) / kSpan; ++s2) issue_load(s2);
+                }
+            });
+            // branch-free scatter: position s of column segment c holds the FIR input with tile-relative index
+            // c colz - (K - 1) + s; a sample on a segment's first K - 1 positions is the previous segment's tail too; the
+            // tile's last K - 1 samples ("column 16") are the carry.  What belongs nowhere goes to a spare word per lane.
+            const int spare = kCols * g.seg_stride_b + lane;
+            float* cwp = cw + par * kCarry;
+            auto put_y = [&](int yi, float v) {
+                v = yi < y_hi ? v : 0.0f;
+                const int e = yi + km1;
+                const int c = e / colz;
+                const int pos = e - c * colz;
+                const int at = c * g.seg_stride_b + pos;
+                if (c < kCols) ys[at] = v;
+                else cwp[pos] = v;                                     // c == 16: pos < K - 1
+                ys[(c >= 1 && pos + colz < g.seg_len_b) ? at - g.seg_stride_b + colz : spare] = v;
+            };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                put_y(y_lane + j, acc0[j]);
+                put_y(y_lane + 16 * NB + j, acc1[j]);
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: the FIR over the segments, 20 block periods per column ----
+        if (!warm) {
+            float* zc = tc.zp + y0;
+            const int64_t lo_left = tc.m_lo - y0, hi_left = tc.m_hi - y0;
+            const int z_lo = lo_left <= 0 ? 0 : lo_left > y_per_tile ? y_per_tile : (int)lo_left;
+            const int z_hi = hi_left <= 0 ? 0 : hi_left > y_per_tile ? y_per_tile : (int)hi_left;
+            const bool whole = z_lo == 0 && z_hi == y_per_tile && ((reinterpret_cast<uintptr_t>(zc) >> 2) & 3) == 0;
+            const float* b0p = ys + base_full_b;
+            const float* t0p = ys + base_tail_b;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            chain2<NKB>(a2, b0p, b0p + 16, t0p, t0p + 16, acc0, acc1, [&](int) {});
+            const int o0 = z_lane, o1 = o0 + 16;
+            if (whole) {
+                *reinterpret_cast<f32x4*>(zc + o0) = acc0;
+                *reinterpret_cast<f32x4*>(zc + o1) = acc1;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (o0 + j >= z_lo && o0 + j < z_hi) zc[o0 + j] = acc0[j];
+                    if (o1 + j >= z_lo && o1 + j < z_hi) zc[o1 + j] = acc1[j];
+                }
+            }
+        }
+        par ^= 1;
+        tile = tile_n;
+        warm = warm_n;
+    }
+}
 
 // ---- the wire path: resampler -> PCM16 -> base64 in one launch (banded.hpp WirePlan) ----------------------------
 // Phase A is resfir_kernel's (same staging of the four PCM formats, same chain pair per wave), with the columns 15
@@ -1667,6 +1961,28 @@ af_status launch_resfir_b(int nkb, const FusedGeom& g, unsigned grid, size_t sme
     }
 }
 
+template <int NKB, int FMT>
+af_status launch_resfir10(const FusedGeom& g, unsigned grid, size_t smem, hipStream_t s)
+{
+    static LdsAttrFlags attr_set;
+    AF_HIP(allow_big_lds(resfir10_kernel<28, NKB, FMT>, 160 * 1024, attr_set));
+    hipLaunchKernelGGL((resfir10_kernel<28, NKB, FMT>), dim3(grid), dim3(640), smem, s, g);
+    AF_HIP(hipGetLastError());
+    return AF_OK;
+}
+
+af_status launch_resfir10_f(int fmt, int nkb, const FusedGeom& g, unsigned grid, size_t smem, hipStream_t s)
+{
+    if (nkb != 20 && nkb != 36) return fail(AF_ERR_UNSUPPORTED, "no fused kernel for a FIR of %d steps", nkb);
+    switch (fmt) {
+    case kFmtMonoF32: return nkb == 20 ? launch_resfir10<20, 0>(g, grid, smem, s) : launch_resfir10<36, 0>(g, grid, smem, s);
+    case kFmtStereoF32: return nkb == 20 ? launch_resfir10<20, 1>(g, grid, smem, s) : launch_resfir10<36, 1>(g, grid, smem, s);
+    case kFmtStereoI16: return nkb == 20 ? launch_resfir10<20, 2>(g, grid, smem, s) : launch_resfir10<36, 2>(g, grid, smem, s);
+    case kFmtMonoI16: return nkb == 20 ? launch_resfir10<20, 3>(g, grid, smem, s) : launch_resfir10<36, 3>(g, grid, smem, s);
+    default: return fail(AF_ERR_UNSUPPORTED, "fused kernel: unknown input format %d", fmt);
+    }
+}
+
 template <int NKA>
 af_status launch_resfir_f(int fmt, int nkb, const FusedGeom& g, unsigned grid, size_t smem, hipStream_t s)
 {
@@ -1687,7 +2003,36 @@ FusedPlan make_fused_plan(const Plan& a, int K, int fmt)
     f.a = a;
     f.K = K;
     f.fmt = fmt;
-    if (!a.ok || a.nb != 1 || a.nwaves != 8 || K < 1 || fmt < 0 || fmt > 3) return f;
+    if (!a.ok || K < 1 || fmt < 0 || fmt > 3) return f;
+    if (a.nb == 10 && a.wpp == 1 && a.G == 2 && a.NK == 28 && K - 1 <= kCarry) {
+        // ten block matrices, two block periods per column (44.1 k -> 16 k): resfir10_kernel
+        const int need = 16 * ((K + 15) / 64) + (((K + 15) % 64) + 3) / 4;
+        f.NKB = need <= 20 ? 20 : need <= 36 ? 36 : 0;
+        if (!f.NKB) return f;
+        f.nbk = 10;
+        f.lead_tiles = 1;
+        f.H2 = 0;
+        f.pad = 0;
+        f.P2 = 20;                                             // ten waves x one chain pair
+        f.seg_len_b = (f.P2 - 1) * 16 + 4 * f.NKB;
+        f.seg_stride_b = f.seg_len_b | 1;
+        f.z_per_tile = (int64_t)256 * f.P2;                    // = 16 G nb 16: 32 rounds of the ten matrices
+        if (fmt != kFmtMonoF32) {
+            if ((a.G * a.S) % 2) return f;                     // frame pairs need an even tile origin: 32 S per tile, 2 S per column
+            f.shift = (a.c - (a.T - 1)) & 1;
+            if (a.seg_len + f.shift > 2 * 640) return f;       // a thread stages one pair per column
+            f.seg_stride_a = ((a.seg_len + f.shift + 1) / 2 * 2) | 1;
+        } else {
+            if (a.seg_len > kPfSlots * 640) return f;
+            f.seg_stride_a = a.seg_len | 1;
+        }
+        f.carry_off = kCols * (f.seg_stride_a + f.seg_stride_b) + 64;          // behind the spare words
+        f.smem = ((size_t)f.carry_off + 2 * kCarry) * sizeof(float);
+        if (f.smem > 160 * 1024) return f;                     // one workgroup per CU
+        f.ok = true;
+        return f;
+    }
+    if (a.nb != 1 || a.nwaves != 8) return f;
     if (a.NK != 24 && a.NK != 28) return f;                    // the instances built below
     const int need = 16 * ((K + 15) / 64) + (((K + 15) % 64) + 3) / 4;
     f.NKB = need <= 20 ? 20 : need <= 36 ? 36 : 0;
@@ -1719,6 +2064,13 @@ FusedPlan make_fused_plan(const Plan& a, int K, int fmt)
 bool fits(const FusedPlan& f, int64_t x_len)
 {
     return f.ok && x_len * fused_bytes_per_frame(f.fmt) < (int64_t)kMaxClip * 4 && x_len < (1ll << 31);
+}
+
+int64_t fused_tile_base(const FusedPlan& f, int64_t t)
+{
+    const int64_t lo_off = f.a.c - (f.a.T - 1);
+    if (f.nbk == 10) return t * (int64_t)(16 * f.a.G) * f.a.S + lo_off - f.shift;      // 16 columns x G periods of S inputs
+    return (t * 16 * f.P2 - f.H2 / 16) * f.a.S + lo_off - f.shift;
 }
 
 af_status build_fused_fir_afrag(const FusedPlan& f, const float* taps_dev, float* afrag_dev, hipStream_t stream)
@@ -1777,6 +2129,16 @@ af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* af
     g.seg_stride_b = f.seg_stride_b;
     g.ys_off = kCols * f.seg_stride_a;
     g.inv_colz = 1.0f / (float)(16 * f.P2);
+    if (f.nbk == 10) {
+        g.L = f.a.L;
+        g.M = f.a.M;
+        g.K = f.K;
+        g.carry_off = f.carry_off;
+        int64_t grid10 = g.n_tiles;
+        const int64_t cus = (int64_t)device_cu_count(current_device());          // one ten-wave workgroup per CU
+        if (grid10 > cus) grid10 = cus;
+        return launch_resfir10_f(f.fmt, f.NKB, g, (unsigned)grid10, f.smem, stream);
+    }
     int64_t grid = g.n_tiles;
     // (diagnostics: af_debug_set("features.wg_per_cu", 1) also holds this launch to one workgroup per CU)
     const int64_t cap = (debug_knob(kKnobFeaturesWgPerCu) == 1 || q.wg_per_cu == 1 ? 1 : 2) *

@@ -255,6 +255,7 @@ int pipeline_chunks(const af_chain* c)
     // (the pipelined form runs the feature kernel clip range by clip range: one-launch feature configurations only --
     // filterbanks on the dense fallback take two launches over whole batches)
     if (c->ragged || c->opt_pipeline == 0 || !features_one_launch(c->feat)) return 0;
+    if (c->fused.nbk != 1) return 0;                                // (the ten-matrix launch needs its CU to itself)
     if (c->opt_pipeline > 0) return (int)std::min<size_t>((size_t)c->opt_pipeline, c->n_clips);
     return 0;                                                       // (see MEASURED above)
 }
@@ -664,10 +665,11 @@ constexpr int64_t kEndless = (int64_t)1 << 60;
 
 int64_t q_of(const af_chain* c, int64_t m) { return m * (int64_t)c->fused.a.M / (int64_t)c->fused.a.L; }
 
+// first x frame a launch whose first tile is t reads: that tile's staging, or -- the ten-matrix launch, whose tiles take the
+// K - 1 samples in front of them from the tile before -- the staging of the warm pass in front of it (lead_tiles = 1)
 int64_t tile_base(const af_chain* c, int64_t t)
 {
-    const banded::FusedPlan& f = c->fused;
-    return (t * 16 * f.P2 - f.H2 / 16) * f.a.S + (f.a.c - (f.a.T - 1)) - f.shift;
+    return banded::fused_tile_base(c->fused, t - c->fused.lead_tiles);
 }
 
 void cs_free(af_chain_stream* s)
@@ -710,7 +712,9 @@ af_status cs_enqueue_step(af_chain_stream* s)
 {
     char* x = s->d_x.as<char>();
     AF_HIP(hipMemcpyAsync(x + s->carry * s->bpf, s->h_in, (size_t)s->Cx * s->bpf, hipMemcpyHostToDevice, s->stream));
-    AF_TRY(cs_kernels(s, s->chain->feat, s->base1, s->Lx, kEndless, s->chain->fused.z_per_tile, s->Cz + s->H));
+    // ("the stream starts 1 + lead tiles before this step": the warm pass of the ten-matrix launch included)
+    AF_TRY(cs_kernels(s, s->chain->feat, s->base1, s->Lx, kEndless,
+                      (1 + s->chain->fused.lead_tiles) * s->chain->fused.z_per_tile, s->Cz + s->H));
     // the last `carry` frames are the next step's history (carry <= Cx: the regions do not overlap)
     AF_HIP(hipMemcpyAsync(x, x + (size_t)s->Cx * s->bpf, (size_t)s->carry * s->bpf, hipMemcpyDeviceToDevice, s->stream));
     AF_HIP(hipMemcpyAsync(s->h_out, s->d_rows.p, s->rows_per_step * s->row_len * sizeof(float), hipMemcpyDeviceToHost,
@@ -766,7 +770,7 @@ af_status af_chain_stream_create(const af_chain_config* cfg, size_t step_frames,
         cs_free(s);
         return fail(AF_ERR_UNSUPPORTED,
                     "af_chain_stream: %u -> %u Hz with %zu FIR taps has no fused resampler + FIR launch (needs a ratio "
-                    "with one block matrix, e.g. 48 / 32 k -> 16 k, and 1..129 taps); stream the stages with "
+                    "with one block matrix, e.g. 48 / 32 k -> 16 k, or 44.1 k -> 16 k, and 1..129 taps); stream the stages with "
                     "af_resampler_*, af_fir_* and af_stream_* instead", cfg->input_rate, cfg->output_rate, cfg->n_fir_taps);
     }
     const int64_t hop = cfg->hop, n_fft = 1024;
@@ -781,7 +785,7 @@ af_status af_chain_stream_create(const af_chain_config* cfg, size_t step_frames,
     s->Cx = nq * qx;
     s->bpf = c->bpf;
     s->need0 = q_of(c, s->Cz + s->H - 1) + f.a.c + 1;
-    s->base1 = tile_base(c, 1);
+    s->base1 = tile_base(c, 1 + f.lead_tiles);                      // x index of d_x[0] in a steady step's fixed coordinates
     const int64_t t01 = s->Cz / f.z_per_tile;
     s->carry = s->need0 - tile_base(c, t01);
     s->Lx = s->carry + s->Cx;

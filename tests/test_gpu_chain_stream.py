@@ -431,6 +431,7 @@ def test_chain_ragged_without_a_fused_plan(af, po, fi, fo, ch, fmt, with_fir):
     if fmt:
         clips = [_as_i16(x) for x in clips]
     chain = af.ChainPipeline(input_rate=fi, channels=ch, output_rate=fo, fir_taps=taps, sample_format=fmt)
+    chain.set_option("unfused", 1)              # (44.1 k -> 16 k with a FIR has a fused launch since round 5: the strip is what is tested here)
     chain.set_batch(np.concatenate([[0], np.cumsum(lens)]))
     resample = fi != fo
     assert chain.n_launches() == 2 + (2 if resample and with_fir else 1 if resample else 0) + (1 if with_fir else 0)
@@ -458,6 +459,7 @@ def test_chain_ragged_strip_many_clips(af):
     gen = torch.Generator().manual_seed(9)
     x = (torch.rand(sum(lens), 2, generator=gen) * 2 - 1).mul_(0.4).numpy()
     chain = af.ChainPipeline(input_rate=44100, channels=2, output_rate=16000, fir_taps=taps)
+    chain.set_option("unfused", 1)
     offs = np.concatenate([[0], np.cumsum(lens)])
     chain.set_batch(offs)
     assert chain.n_launches() == 5
@@ -537,6 +539,7 @@ def test_chain_ragged_strip_more_clips_than_a_grid_dimension(af):
     x = (torch.rand(int(offs[-1]), 2, generator=gen) * 2 - 1).mul_(0.4).numpy()
     taps = lowpass_taps()
     chain = af.ChainPipeline(input_rate=44100, channels=2, output_rate=16000, fir_taps=taps)
+    chain.set_option("unfused", 1)
     total = chain.set_batch(offs)
     assert chain.n_launches() == 6 and total == sum(chain.n_frames(int(n)) for n in lens[[7, 40000, 65999]])
     mel = chain.run(x.reshape(-1))
@@ -562,6 +565,7 @@ def test_chain_ragged_strip_in_groups_beyond_2_30_samples(af):
     pcm = (torch.rand(int(offs[-1]), device=dev, generator=gen) * 2 - 1) * 0.4
     taps = lowpass_taps()
     chain = af.ChainPipeline(input_rate=44100, channels=1, output_rate=16000, fir_taps=taps)
+    chain.set_option("unfused", 1)
     total = chain.set_batch(offs)
     assert chain.n_launches() == 1 + 1 + 2 + 1 + 2                    # features, gather, 2 x resampler, gap zeroing, 2 x FIR
     mel = torch.empty(total, 80, device=dev)
@@ -695,9 +699,127 @@ def test_chain_stream_time_sharded_equals_one_shot(af, ch, fmt, world):
     assert bits_equal(r0, full[:r0.shape[0]])
 
 
+# ---- 44.1 kHz input: the ten-matrix fused launch (resfir10_kernel) and the chain stream on top of it ------------------
+@pytest.mark.parametrize("ch,fmt", [(2, 0), (1, 0), (2, 1), (1, 1)])
+@pytest.mark.parametrize("K", [129, 100, 65])
+def test_chain_44k1_fused_equals_separate_launches(af, po, ch, fmt, K):
+    """44.1 k -> 16 k (capture.rs:60-80 takes whatever rate the device offers; BASELINE config 3's ratio): downmix +
+    resampler + FIR as ONE launch -- ten block matrices, the K - 1 resampled samples in front of a tile carried in LDS,
+    a warm pass where a workgroup's range starts inside a clip -- against the stand-alone kernels, bit for bit (FIRs of
+    34-65 and 98-129 taps share the stand-alone chains' step layout); uniform and ragged batches, clips that end on /
+    one over / one under a tile edge (5 120 outputs = 14 112 input frames), a clip shorter than the FIR history."""
+    taps = lowpass_taps()[:K].copy()
+    for lens in ([44100 * 2 + 17] * 3, [14112 * 2] * 2, [14112 * 2 + 3, 14112 * 2 - 3, 5, 0, 70001, 300, 1, 14113 * 4]):
+        if ch == 1 and fmt == 1:
+            lens = [n + (n & 1) for n in lens]                 # mono i16 clips start on even frames
+        clips = [synth_clip(700 + i, n, ch, 44100) for i, n in enumerate(lens)]
+        if fmt:
+            clips = [_as_i16(x) for x in clips]
+        x = np.concatenate([c.reshape(-1) for c in clips])
+        rows = []
+        for unfused in (0, 1):
+            c = af.ChainPipeline(input_rate=44100, channels=ch, output_rate=16000, fir_taps=taps, sample_format=fmt)
+            c.set_option("unfused", unfused)
+            if len(set(lens)) == 1:
+                c.set_batch_uniform(len(lens), lens[0])
+            else:
+                c.set_batch(np.concatenate([[0], np.cumsum(lens)]))
+            assert c.n_launches() == 2 if not unfused else c.n_launches() >= 3
+            rows.append(c.run(x))
+        assert bits_equal(rows[0], rows[1])
+    # the last batch against the float64 oracle, clip by clip
+    row = 0
+    for cx, n in zip(clips, lens):
+        nf = c.n_frames(n)
+        if nf:
+            xf = cx.astype(np.float32) / np.float32(32768.0) if fmt else cx
+            assert frame_rel_err(rows[0][row:row + nf], oracle_chain(po, xf, ch, 44100, 16000, taps)) < 2e-5
+        row += nf
+
+
+def test_chain_44k1_full_size_fused_equals_stages(af):
+    """256 x 30 s stereo 44.1 kHz (2.7 GB of PCM): every workgroup of the fused launch owns one clip's 94 tiles; rows equal
+    the three-launch form, identical clips give identical rows."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    n_clips, n = 256, 44100 * 30
+    x = (torch.rand(n_clips, n, 2, device=dev) * 2 - 1) * 0.5
+    x[200] = x[3]
+    out = []
+    for unfused in (0, 1):
+        c = af.ChainPipeline(input_rate=44100, channels=2, output_rate=16000, fir_taps=lowpass_taps())
+        c.set_option("unfused", unfused)
+        total = c.set_batch_uniform(n_clips, n)
+        mel = torch.empty(total, 80, device=dev)
+        c.run_device(x.data_ptr(), mel.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out.append(mel)
+    assert bits_equal(out[0], out[1]) and bool(torch.isfinite(out[0]).all())
+    m = out[0].view(n_clips, -1, 80)
+    assert bits_equal(m[200], m[3]) and not bits_equal(m[200], m[4])
+
+
+@pytest.mark.parametrize("ch,fmt,n", [(2, 0, 56448 * 9 + 50001), (1, 0, 56448 * 5 + 7), (2, 1, 56448 * 4 + 2200), (1, 1, 56448 * 6 + 12),
+                                      (2, 0, 60000), (1, 0, 2000)])
+def test_chain_stream_44k1_equals_one_shot(af, po, ch, fmt, n):
+    """af_chain_stream_* at 44.1 kHz (the carry / flush contract of BatchResampler, resampler.rs:132-166, on the whole
+    chain): ragged pushes over several steps (the smallest step: 56 448 input frames = 20 480 FIR outputs = 4 tiles of
+    the ten-matrix launch = 5 units of the feature kernel; every replayed step begins with the warm pass of the tile in
+    front of it), a partial last step, streams shorter than a step: rows of pushes + flush == ChainPipeline.run on the
+    whole stream, bit for bit."""
+    taps = lowpass_taps()
+    x = synth_clip(950 + ch + fmt, n, ch, 44100)
+    if fmt:
+        x = _as_i16(x)
+    st = af.ChainStream(step_frames=1, input_rate=44100, channels=ch, fir_taps=taps, sample_format=fmt)
+    assert st.step_frames == 56448 and st.rows_per_step == 80
+    rng = np.random.default_rng(n % 89)
+    rows, pos = [], 0
+    while pos < n:
+        k = int(rng.integers(0, 90000))
+        rows.append(st.push(x[pos * ch:(pos + k) * ch]))
+        pos += k
+    rows.append(st.flush())
+    got = np.concatenate(rows)
+    one = af.ChainPipeline(input_rate=44100, channels=ch, fir_taps=taps, sample_format=fmt)
+    one.set_batch_uniform(1, n)
+    assert one.n_launches() == 2
+    assert got.shape[0] == st.total_rows(n) == one.n_frames(n)
+    full = one.run(x)
+    assert bits_equal(got, full)
+    if got.shape[0]:
+        xf = x.astype(np.float32) / np.float32(32768.0) if fmt else x
+        assert frame_rel_err(got, oracle_chain(po, xf, ch, 44100, 16000, taps)) < 2e-5
+
+
+def test_chain_stream_44k1_time_sharded_equals_one_shot(af):
+    """the steps of a 44.1 kHz recording dealt to 3 ranks (seek: history first, then the rank's own steps): rows in rank
+    order == af_chain_run on the whole recording, bit for bit"""
+    torch = pytest.importorskip("torch")
+    from audio_flow_rs_amd.shard import chain_stream_shards
+    taps = lowpass_taps()
+    st = af.ChainStream(step_frames=56448 * 3, input_rate=44100, channels=2, fir_taps=taps)
+    n = st.first_step_frames + 7 * st.step_frames + 40001
+    gen = torch.Generator().manual_seed(44)
+    x = (torch.rand(n, 2, generator=gen) * 2 - 1).mul_(0.4).numpy()
+    one = af.ChainPipeline(input_rate=44100, channels=2, fir_taps=taps)
+    one.set_batch_uniform(1, n)
+    full = one.run(x.reshape(-1))
+    rows = []
+    for k0, k1, lo, hi, flush in chain_stream_shards(n, 3, st.first_step_frames, st.step_frames, st.history_frames):
+        if k0 == k1 and not flush:
+            continue
+        assert st.seek(k0) == lo
+        rows.append(st.push(x[lo:hi]))
+        if flush:
+            rows.append(st.flush())
+    got = np.concatenate(rows)
+    assert got.shape == full.shape and bits_equal(got, full)
+
+
 def test_chain_stream_needs_the_fused_launch(af):
     with pytest.raises(af.AudioError, match="no fused"):
-        af.ChainStream(input_rate=44100, fir_taps=lowpass_taps())
+        af.ChainStream(input_rate=48000, output_rate=44100, fir_taps=lowpass_taps())      # 147 streamed block matrices
     with pytest.raises(af.AudioError, match="no fused"):
         af.ChainStream()                                          # no FIR
 

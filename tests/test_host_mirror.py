@@ -220,6 +220,16 @@ def test_chain_fused_plan_invariants(af):
     assert covered == 110
     # not covered: long FIRs, ratios with several block matrices or another tile shape, no resampling, no FIR
     assert plan(48000, 16000, 2, 130)["ok"] == 0 and plan(48000, 16000, 1, 1024)["ok"] == 0
-    assert plan(44100, 16000, 1, 129)["ok"] == 0 and plan(48000, 32000, 2, 129)["ok"] == 0
+    assert plan(48000, 32000, 2, 129)["ok"] == 0 and plan(48000, 44100, 1, 129)["ok"] == 0
+    # ten block matrices (44.1 k -> 16 k; resfir10_kernel, round 5): a tile is 5 120 resampled samples AND 5 120 FIR outputs
+    # (20 block periods per column), nothing is recomputed (H2 = 0: the K - 1 samples in front of a tile are carried in LDS)
+    for ch in (1, 2):
+        for K in (1, 17, 65, 66, 129):
+            p = plan(44100, 16000, ch, K)
+            assert (p["ok"], p["NKA"], p["H2"], p["pad"], p["P2"], p["z_per_tile"]) == (1, 28, 0, 0, 20, 5120), (ch, K)
+            assert p["NKB"] == (20 if K <= 65 else 36) and 4 * p["NKB"] >= K + 15
+            assert p["seg_len_b"] == 16 * (p["P2"] - 1) + 4 * p["NKB"] and p["seg_stride_b"] % 2 == 1
+            assert p["seg_len_b"] - 16 * p["P2"] >= K - 1 and p["smem"] <= 160 * 1024      # a segment's head holds the whole history
+    assert plan(44100, 16000, 1, 130)["ok"] == 0
     assert plan(16000, 48000, 1, 129)["ok"] == 0
     assert plan(16000, 16000, 1, 129)["ok"] == 0 and plan(48000, 16000, 2, 0)["ok"] == 0
