@@ -395,8 +395,9 @@ __device__ __forceinline__ int sload_int(const int* base, int idx)
 #ifndef AF_STREAM_OB
 #define AF_STREAM_OB 1
 #endif
+// 1 (experiment, round 5): a workgroup takes a contiguous run of tiles instead of every gridDim-th one
 #ifndef AF_STREAM_CONTIG
-#define AF_STREAM_CONTIG 1
+#define AF_STREAM_CONTIG 0
 #endif
 // largest matrix range of a tile (experiment: 16 = always small enough for the deferred stores)
 #ifndef AF_STREAM_PMAX
@@ -523,11 +524,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     };
 
-    // AF_STREAM_CONTIG: a workgroup takes a CONTIGUOUS run of tiles (the matrix ranges of one period group vary fastest
-    // over the tile index): the window halo between neighbouring ranges, 27 % of what a range stages at 48 -> 44.1 kHz, is
-    // then re-read by the workgroup that fetched it a tile ago, from its own XCD's L2.  Dealt round-robin (tile += grid,
-    // rounds 3-4) the ranges of a period group sit on different XCDs and every halo is a second HBM fetch:
-    // FETCH_SIZE 8.64 GB for 5.90 GB of x (profiles/r05_stream_traffic.txt).
+    // AF_STREAM_CONTIG (experiment): a workgroup takes a CONTIGUOUS run of tiles (the matrix ranges of one period group vary
+    // fastest over the tile index), so that the window halo between neighbouring ranges -- 27 % of what a range stages at
+    // 48 -> 44.1 kHz, every bit of it an L2 miss: FETCH_SIZE 8.64 GB for 5.90 GB of x -- is re-read by the workgroup that
+    // fetched it a tile ago.  Measured (profiles/r05_stream_traffic.txt): FETCH_SIZE does not move (4.23e6 against 4.22e6
+    // units): an XCD's 64 resident workgroups stage and store 7.7 MB per tile time through a 4 MB L2, the halo is gone
+    // before its second reader comes; 16 -> 44.1 kHz is 6 % slower.  The default stays round-robin.
 #if AF_STREAM_CONTIG
     const uint32_t tile_end = (uint32_t)(((uint64_t)n_tiles * (blockIdx.x + 1)) / gridDim.x);
     uint32_t tile = (uint32_t)(((uint64_t)n_tiles * blockIdx.x) / gridDim.x);
