@@ -221,8 +221,9 @@ SIGNATURES = {
     "af_wire_set_batch_uniform": (_st, [_vp, _sz, _sz, _szp, _szp]),
     "af_wire_set_batch": (_st, [_vp, _vp, _sz, _szp, _szp]),
     "af_wire_text_offsets": (_st, [_vp, _vp, _sz]),
-    "af_wire_run_device": (_st, [_vp, _vp, _vp, _vp, _vp]),
-    "af_wire_run": (_st, [_vp, _vp, _sz, _vp, _sz, _vp, _sz]),
+    "af_wire_total_messages": (_sz, [_vp]),
+    "af_wire_run_device": (_st, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "af_wire_run": (_st, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz]),
     "af_wire_set_option": (_st, [_vp, C.c_char_p, C.c_int]),
     "af_wire_n_launches": (C.c_int, [_vp]),
     # RingBuffer (capture.rs:84-161)

@@ -856,19 +856,36 @@ class WireEncoder:
     def n_launches(self) -> int:
         return int(self._lib.af_wire_n_launches(self._h))
 
-    def run_device(self, pcm_ptr: int, text_ptr: int, pcm16_ptr: int = 0, stream: int = 0) -> None:
-        _check(self._lib.af_wire_run_device(self._h, C.c_void_p(pcm_ptr), C.c_void_p(text_ptr),
-                                            C.c_void_p(pcm16_ptr) if pcm16_ptr else None, C.c_void_p(stream)))
+    def total_messages(self) -> int:
+        return int(self._lib.af_wire_total_messages(self._h))
 
-    def run(self, pcm, with_pcm16: bool = False):
-        """Host buffers -> the batch's text as ``bytes`` (cut it with ``text_offsets()`` / ``message_len()``), and the
-        quantised samples (int16) when asked for."""
+    def run_device(self, pcm_ptr: int, text_ptr: int, pcm16_ptr: int = 0, stream: int = 0, energy_ptr: int = 0,
+                   peak_ptr: int = 0) -> None:
+        _check(self._lib.af_wire_run_device(self._h, C.c_void_p(pcm_ptr), C.c_void_p(text_ptr),
+                                            C.c_void_p(pcm16_ptr) if pcm16_ptr else None,
+                                            C.c_void_p(energy_ptr) if energy_ptr else None,
+                                            C.c_void_p(peak_ptr) if peak_ptr else None, C.c_void_p(stream)))
+
+    def run(self, pcm, with_pcm16: bool = False, with_level: bool = False):
+        """Host buffers -> the batch's text as ``bytes`` (cut it with ``text_offsets()`` / ``message_len()``); with
+        ``with_pcm16`` also the quantised samples (int16); with ``with_level`` also ``(energy, peak)`` per message --
+        the mean-square energy ``VoiceActivityDetector::calculate_energy`` would compute on the message (vad.rs:157-168)
+        and max |x| (the ``peak`` of the ``audio_level`` event, events/mod.rs:73-75)."""
         x = np.ascontiguousarray(pcm, self._dtype()).reshape(-1)
         text = np.empty(self.total_text, np.uint8)
         q = np.full(self.total_samples, -21846, np.int16) if with_pcm16 else None
+        nm = self.total_messages() if with_level else 0
+        en = np.full(nm, np.nan, np.float32) if with_level else None
+        pk = np.full(nm, np.nan, np.float32) if with_level else None
         _check(self._lib.af_wire_run(self._h, _ptr(x), x.size, _ptr(text), text.size,
-                                     _ptr(q) if q is not None else None, q.size if q is not None else 0))
-        return (text.tobytes(), q) if with_pcm16 else text.tobytes()
+                                     _ptr(q) if q is not None else None, q.size if q is not None else 0,
+                                     _ptr(en) if with_level else None, _ptr(pk) if with_level else None, nm))
+        out = (text.tobytes(),)
+        if with_pcm16:
+            out += (q,)
+        if with_level:
+            out += (en, pk)
+        return out if len(out) > 1 else out[0]
 
     def messages(self, pcm) -> List[List[str]]:
         """``frame_samples > 0``: per clip, the base64 payloads of its messages (what ``send_audio`` puts into

@@ -166,8 +166,9 @@ struct WirePlan {
     int row_len = 0;           // characters per message: 4 ceil(2 frame / 3)
     int shift = 0, seg_stride_a = 0;
     int img_off = 0;           // floats from the start of LDS: the tile's samples as i16
+    int fimg_off = 0;          // ... and as f32 (only the instances that also emit the messages' energy / peak use it)
     int64_t y_per_tile = 0;    // 256 Gv
-    size_t smem = 0;
+    size_t smem = 0, smem_level = 0;   // without / with the f32 image
 };
 WirePlan make_wire_plan(const Plan& resampler, int fmt, int frame_samples);
 // characters of one clip's text: frame == 0: af_base64_len(2 n_res); else (n_res / frame) messages of row_len (a trailing
@@ -184,13 +185,20 @@ struct WireTile {
     int32_t x_len;             // frames of the clip
     int32_t n_res;             // resampled samples of the clip
     int32_t t;                 // tile of the clip
-    int32_t pad[7];
+    uint32_t msg_lo, msg_hi;   // first message of the clip in the batch's energy / peak rows (64 bits)
+    int32_t pad[5];
 };
 static_assert(sizeof(WireTile) == 64, "WireTile is read with two s_load_dwordx8");
 struct WireArgs {
     const void* x = nullptr;   // device PCM; uniform: clip i starts x_stride frames behind clip i - 1
     char* text = nullptr;      // device; uniform: row i starts text_stride bytes behind row i - 1
     int16_t* pcm16 = nullptr;  // device, optional: the quantised samples beside the text (row i at pcm_stride samples)
+    // device, optional (messages only): per message the mean-square energy of VoiceActivityDetector::calculate_energy
+    // (vad.rs:157-168: the f32 left fold over the message's resampled samples, bit for bit) and max |x| (the `peak` of the
+    // audio_level event, events/mod.rs:73-75); clip i's messages start at msg_stride * i
+    float* energy = nullptr;
+    float* peak = nullptr;
+    int64_t msg_stride = 0;
     int64_t x_len = 0, x_stride = 0, text_stride = 0, pcm_stride = 0;
     int64_t n_res = 0;         // resampled samples per clip
     int64_t n_clips = 0;

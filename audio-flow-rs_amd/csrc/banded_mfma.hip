@@ -1320,17 +1320,24 @@ struct WireGeom {
     int Gv, frame, gpf, row_len;     // gpf = groups per message (ceil(frame / 6)); frame == 0: one string per clip
     int img_off;                     // floats
     int text_align;                  // 16, 8, 4 or 1
+    float* energy;                   // optional (LEVEL instances): per message, vad.rs:157-168 / max |x|
+    float* peak;
+    int64_t msg_stride;
+    int fimg_off;                    // floats: the tile's samples as f32, [16 columns][16 Gv + 4]
 };
 
 struct WireCtx {
     const char* xp;
     char* tp;                        // the clip's first character
     int16_t* pp;                     // the clip's first PCM16 sample (or null)
-    int64_t n_res, t_abs;
+    int64_t n_res, t_abs, msg0;
     uint32_t x_bytes;
 };
 
-template <int NKA, int FMT>
+// LEVEL: also the messages' VAD energy and peak, from an f32 image of the tile beside the PCM16 one.  The reference's energy
+// is a LEFT fold in f32 (`frame.iter().map(|&x| x * x).sum()`, vad.rs:163-165): one lane folds one message, in order, no FMA.
+// In the fused path the 16 kHz f32 signal exists nowhere else, so this is the only place a VAD can look at it.
+template <int NKA, int FMT, bool LEVEL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void wire_kernel(const WireGeom g)
 {
     using F = FusedFmt<FMT>;
@@ -1373,7 +1380,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             c.pp = g.pcm16 ? g.pcm16 + p_off : nullptr;
             c.x_bytes = r[6] * (uint32_t)BPF;
             c.n_res = (int64_t)r[7];
-            c.t_abs = (int64_t)rec[1][0];
+            const u32x8 r2 = rec[1];
+            c.t_abs = (int64_t)r2[0];
+            c.msg0 = (int64_t)(((unsigned long long)r2[2] << 32) | r2[1]);
         } else {
             const uint32_t clip = tile / tpc;
             c.xp = static_cast<const char*>(g.x) + (int64_t)clip * g.x_stride * BPF;
@@ -1382,6 +1391,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             c.x_bytes = (uint32_t)(g.x_len * BPF);
             c.n_res = g.n_res;
             c.t_abs = tile - clip * tpc;
+            c.msg0 = (int64_t)clip * g.msg_stride;
         }
         return c;
     };
@@ -1530,8 +1540,51 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 quads(acc1, y_lane + 16, lo, hi);
                 *reinterpret_cast<u32x2*>(ic + 8) = u32x2{lo, hi};
             }
+            if constexpr (LEVEL) {
+                // the same samples as f32 (zero behind the clip's end); columns 16 Gv + 4 floats apart: the eight lanes of a
+                // ds_write_b128 group start 20 banks apart, no two on the same four
+                float* fc = xs + g.fimg_off + col * (16 * g.Gv + 4) + 16 * wave * kGpw + 4 * g4;
+                auto masked = [&](const f32x4& acc, int yi) {
+                    return f32x4{yi < y_hi ? acc[0] : 0.f, yi + 1 < y_hi ? acc[1] : 0.f, yi + 2 < y_hi ? acc[2] : 0.f,
+                                 yi + 3 < y_hi ? acc[3] : 0.f};
+                };
+                *reinterpret_cast<f32x4*>(fc) = masked(acc0, y_lane);
+                if (wave * kGpw + 1 < g.Gv) *reinterpret_cast<f32x4*>(fc + 16) = masked(acc1, y_lane + 16);
+            }
         }
         __syncthreads();
+
+        if constexpr (LEVEL) {
+            // ---- the messages' energy and peak: message f of the tile on lane f / 8 of wave f % 8 ----
+#pragma clang fp contract(off)
+            const int n_msg = y_per_tile / g.frame;
+            const int f = wave + 8 * lane;
+            const int64_t fa = y0 / g.frame + f;
+            if (f < n_msg && (fa + 1) * g.frame <= tc.n_res) {
+                const float* fi = xs + g.fimg_off;
+                const int colf = 16 * g.Gv;
+                const int s0 = f * g.frame;
+                int c = s0 / colf, r = s0 - c * colf;                // column and position of the running sample
+                float e = 0.0f, m = 0.0f;
+                for (int i = 0; i < g.frame; i += 8) {               // (frame is a multiple of 8 here: launch_wire checks)
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        v[k] = fi[c * (colf + 4) + r];
+                        r += 1;
+                        if (r == colf) { r = 0; c += 1; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float p = v[k] * v[k];                 // vad.rs:163-165: one rounding per product and per add
+                        e = e + p;
+                        m = fmaxf(m, fabsf(v[k]));
+                    }
+                }
+                if (g.energy) g.energy[tc.msg0 + fa] = e / (float)g.frame;      // vad.rs:167
+                if (g.peak) g.peak[tc.msg0 + fa] = m;
+            }
+        }
 
         // ---- base64: whole groups of 6 samples per thread ----
         {
@@ -2154,7 +2207,7 @@ af_status launch_fused(const FusedPlan& f, const float* afrag_a, const float* af
 // ---- the wire launch ---------------------------------------------------------------------------------------------
 namespace {
 template <int NKA>
-af_status launch_wire_f(int fmt, const WireGeom& g, unsigned grid, size_t smem, hipStream_t s)
+af_status launch_wire_f(int fmt, bool level, const WireGeom& g, unsigned grid, size_t smem, hipStream_t s)
 {
     auto go = [&](auto kern) -> af_status {
         static LdsAttrFlags attr_set;
@@ -2164,10 +2217,10 @@ af_status launch_wire_f(int fmt, const WireGeom& g, unsigned grid, size_t smem, 
         return AF_OK;
     };
     switch (fmt) {
-    case kFmtMonoF32: return go(wire_kernel<NKA, 0>);
-    case kFmtStereoF32: return go(wire_kernel<NKA, 1>);
-    case kFmtStereoI16: return go(wire_kernel<NKA, 2>);
-    case kFmtMonoI16: return go(wire_kernel<NKA, 3>);
+    case kFmtMonoF32: return level ? go(wire_kernel<NKA, 0, true>) : go(wire_kernel<NKA, 0>);
+    case kFmtStereoF32: return level ? go(wire_kernel<NKA, 1, true>) : go(wire_kernel<NKA, 1>);
+    case kFmtStereoI16: return level ? go(wire_kernel<NKA, 2, true>) : go(wire_kernel<NKA, 2>);
+    case kFmtMonoI16: return level ? go(wire_kernel<NKA, 3, true>) : go(wire_kernel<NKA, 3>);
     default: return fail(AF_ERR_UNSUPPORTED, "wire kernel: unknown input format %d", fmt);
     }
 }
@@ -2196,6 +2249,8 @@ WirePlan make_wire_plan(const Plan& a, int fmt, int frame_samples)
     }
     w.img_off = (kCols * w.seg_stride_a + 3) & ~3;             // 16-byte aligned
     w.smem = ((size_t)w.img_off + (size_t)kCols * (8 * w.Gv + 2)) * sizeof(float);    // image: padded columns
+    w.fimg_off = (w.img_off + kCols * (8 * w.Gv + 2) + 3) & ~3;
+    w.smem_level = ((size_t)w.fimg_off + (size_t)kCols * (16 * w.Gv + 4)) * sizeof(float);
     if (2 * w.smem > 160 * 1024) return w;                     // two workgroups per CU or not at all
     w.ok = true;
     return w;
@@ -2243,11 +2298,22 @@ af_status launch_wire(const WirePlan& w, const float* afrag_a, const WireArgs& q
     g.row_len = w.row_len;
     g.img_off = w.img_off;
     g.text_align = q.text_align;
+    const bool level = q.energy || q.peak;
+    if (level) {
+        if (!w.frame || w.frame % 8 != 0 || w.y_per_tile / w.frame > 8 * 64)
+            return fail(AF_ERR_UNSUPPORTED, "banded::launch_wire: energy / peak rows need messages of a multiple of 8 samples (frame_samples %d)", w.frame);
+        if (2 * w.smem_level > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "banded::launch_wire: no room for the f32 image beside two workgroups per CU");
+        g.energy = q.energy;
+        g.peak = q.peak;
+        g.msg_stride = q.msg_stride;
+        g.fimg_off = w.fimg_off;
+    }
     int64_t grid = g.n_tiles;
     const int64_t cap = 2 * (int64_t)device_cu_count(current_device());
     if (grid > cap) grid = cap;
-    if (w.a.NK == 24) return launch_wire_f<24>(w.fmt, g, (unsigned)grid, w.smem, stream);
-    return launch_wire_f<28>(w.fmt, g, (unsigned)grid, w.smem, stream);
+    const size_t smem = level ? w.smem_level : w.smem;
+    if (w.a.NK == 24) return launch_wire_f<24>(w.fmt, level, g, (unsigned)grid, smem, stream);
+    return launch_wire_f<28>(w.fmt, level, g, (unsigned)grid, smem, stream);
 }
 
 }  // namespace banded

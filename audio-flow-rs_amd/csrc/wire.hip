@@ -32,7 +32,7 @@ struct af_wire {
     int64_t total_in = 0, total_text = 0, total_samples = 0, n_tiles = 0;
     DevBuf d_tiles;
     DevBuf d_mono, d_res;             // unfused: intermediates
-    DevBuf d_pcm, d_text, d_pcm16;    // host-buffer entry point
+    DevBuf d_pcm, d_text, d_pcm16, d_level;    // host-buffer entry point
 };
 
 namespace {
@@ -102,6 +102,28 @@ __global__ void wire_encode_kernel(const float* __restrict__ y, int64_t y_stride
     }
 }
 
+// The stand-alone form of wire_kernel's LEVEL part: per message the reference's mean-square energy (vad.rs:157-168: f32 left
+// fold, no FMA) and max |x|, one lane per message, from the resampled f32 rows.  Equal-length clips.
+__global__ void wire_level_kernel(const float* __restrict__ y, int64_t y_stride, int64_t msgs_per_clip, int64_t n_clips, int frame,
+                                  float* __restrict__ energy, float* __restrict__ peak)
+{
+#pragma clang fp contract(off)
+    const int64_t total = msgs_per_clip * n_clips;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t clip = it / msgs_per_clip, f = it - clip * msgs_per_clip;
+        const float* src = y + clip * y_stride + f * frame;
+        float e = 0.0f, m = 0.0f;
+        for (int i = 0; i < frame; ++i) {
+            const float v = src[i];
+            const float p = v * v;
+            e = e + p;
+            m = fmaxf(m, fabsf(v));
+        }
+        if (energy) energy[it] = e / (float)frame;
+        if (peak) peak[it] = m;
+    }
+}
+
 af_status describe(af_wire* w, const std::vector<int64_t>& off)
 {
     const size_t n = off.size() - 1;
@@ -150,6 +172,9 @@ af_status describe(af_wire* w, const std::vector<int64_t>& off)
                 r.x_len = (int32_t)len;
                 r.n_res = (int32_t)w->res_len[i];
                 r.t = (int32_t)t;
+                const uint64_t msg0 = w->row_len ? (uint64_t)(w->text_off[i] / w->row_len) : 0;
+                r.msg_lo = (uint32_t)msg0;
+                r.msg_hi = (uint32_t)(msg0 >> 32);
                 tiles.push_back(r);
             }
         }
@@ -284,12 +309,19 @@ int af_wire_n_launches(const af_wire* w)
     return fused(w) ? 1 : 2;
 }
 
-af_status af_wire_run_device(af_wire* w, const void* pcm_dev, char* text_dev, int16_t* pcm16_dev, void* stream)
+size_t af_wire_total_messages(const af_wire* w)
+{
+    return w && w->row_len ? (size_t)(w->total_text / w->row_len) : 0;
+}
+
+af_status af_wire_run_device(af_wire* w, const void* pcm_dev, char* text_dev, int16_t* pcm16_dev, float* energy_dev,
+                             float* peak_dev, void* stream)
 {
     AF_REQUIRE(w, "af_wire_run_device: null handle");
     AF_REQUIRE(w->described, "af_wire_run_device: describe the batch first (af_wire_set_batch*)");
     if (w->n_clips == 0 || w->total_in == 0 || w->total_samples == 0) return AF_OK;
     AF_REQUIRE(pcm_dev && text_dev, "af_wire_run_device: null buffer");
+    AF_REQUIRE(!(energy_dev || peak_dev) || w->cfg.frame_samples, "af_wire_run_device: energy / peak rows are per message (frame_samples > 0)");
     hipStream_t s = as_stream(stream);
     if (fused(w)) {
         if (w->fmt == banded::kFmtMonoI16 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 != 0)
@@ -298,6 +330,9 @@ af_status af_wire_run_device(af_wire* w, const void* pcm_dev, char* text_dev, in
         q.x = pcm_dev;
         q.text = text_dev;
         q.pcm16 = pcm16_dev;
+        q.energy = energy_dev;
+        q.peak = peak_dev;
+        q.msg_stride = w->cfg.frame_samples ? (int64_t)(w->n_res / w->cfg.frame_samples) : 0;
         int al = align_of(reinterpret_cast<uintptr_t>(text_dev));
         if (w->cfg.frame_samples) al = std::min(al, align_of((uintptr_t)w->row_len));
         if (w->ragged) {
@@ -340,10 +375,19 @@ af_status af_wire_run_device(af_wire* w, const void* pcm_dev, char* text_dev, in
                        (int64_t)w->n_clips, F, gpf, w->row_len, text_dev, text_len_of(w, (int64_t)w->n_res), pcm16_dev,
                        (int64_t)w->n_res);
     AF_HIP(hipGetLastError());
+    if ((energy_dev || peak_dev) && F && w->n_res / F > 0) {
+        const int64_t msgs = (int64_t)(w->n_res / F);
+        int64_t gl = (msgs * (int64_t)w->n_clips + 63) / 64;
+        if (gl > (1ll << 30)) gl = 1ll << 30;
+        hipLaunchKernelGGL(wire_level_kernel, dim3((unsigned)gl), dim3(64), 0, s, y, (int64_t)w->n_res, msgs, (int64_t)w->n_clips, F,
+                           energy_dev, peak_dev);
+        AF_HIP(hipGetLastError());
+    }
     return AF_OK;
 }
 
-af_status af_wire_run(af_wire* w, const void* pcm, size_t pcm_len, char* text, size_t text_cap, int16_t* pcm16, size_t pcm16_cap)
+af_status af_wire_run(af_wire* w, const void* pcm, size_t pcm_len, char* text, size_t text_cap, int16_t* pcm16, size_t pcm16_cap,
+                      float* energy, float* peak, size_t level_cap)
 {
     AF_REQUIRE(w, "af_wire_run: null handle");
     AF_REQUIRE(w->described, "af_wire_run: describe the batch first (af_wire_set_batch*)");
@@ -352,14 +396,22 @@ af_status af_wire_run(af_wire* w, const void* pcm, size_t pcm_len, char* text, s
     if (text_cap < (size_t)w->total_text) return fail(AF_ERR_BUFFER_TOO_SMALL, "text buffer holds %zu characters, need %zu", text_cap, (size_t)w->total_text);
     if (pcm16 && pcm16_cap < (size_t)w->total_samples)
         return fail(AF_ERR_BUFFER_TOO_SMALL, "pcm16 buffer holds %zu samples, need %zu", pcm16_cap, (size_t)w->total_samples);
+    const size_t n_msg = af_wire_total_messages(w);
+    if ((energy || peak) && level_cap < n_msg)
+        return fail(AF_ERR_BUFFER_TOO_SMALL, "energy / peak buffers hold %zu messages, need %zu", level_cap, n_msg);
     if (w->n_clips == 0 || w->total_in == 0 || w->total_samples == 0) return AF_OK;
     AF_REQUIRE(pcm && text, "af_wire_run: null buffer");
     const size_t in_bytes = (size_t)w->total_in * w->bpf;
     AF_TRY(w->d_pcm.reserve(in_bytes));
     AF_TRY(w->d_text.reserve((size_t)w->total_text + 16));
     if (pcm16) AF_TRY(w->d_pcm16.reserve((size_t)w->total_samples * sizeof(int16_t) + 16));
+    if (energy || peak) AF_TRY(w->d_level.reserve(2 * (n_msg + 4) * sizeof(float)));
+    float* d_en = energy ? w->d_level.as<float>() : nullptr;
+    float* d_pk = peak ? w->d_level.as<float>() + n_msg + 4 : nullptr;
     AF_HIP(hipMemcpy(w->d_pcm.p, pcm, in_bytes, hipMemcpyHostToDevice));
-    AF_TRY(af_wire_run_device(w, w->d_pcm.p, w->d_text.as<char>(), pcm16 ? w->d_pcm16.as<int16_t>() : nullptr, nullptr));
+    AF_TRY(af_wire_run_device(w, w->d_pcm.p, w->d_text.as<char>(), pcm16 ? w->d_pcm16.as<int16_t>() : nullptr, d_en, d_pk, nullptr));
+    if (energy && n_msg) AF_HIP(hipMemcpy(energy, d_en, n_msg * sizeof(float), hipMemcpyDeviceToHost));
+    if (peak && n_msg) AF_HIP(hipMemcpy(peak, d_pk, n_msg * sizeof(float), hipMemcpyDeviceToHost));
     if (w->total_text) AF_HIP(hipMemcpy(text, w->d_text.p, (size_t)w->total_text, hipMemcpyDeviceToHost));
     if (pcm16) AF_HIP(hipMemcpy(pcm16, w->d_pcm16.p, (size_t)w->total_samples * sizeof(int16_t), hipMemcpyDeviceToHost));
     return AF_OK;

@@ -603,6 +603,9 @@ public:
     size_t n_messages(size_t n_frames) const { return af_wire_n_messages(h_, n_frames); }
     int n_launches() const { return af_wire_n_launches(h_); }
     void set_option(const char* key, int value) { detail::check(af_wire_set_option(h_, key, value)); }
+    // messages only: the next run also fills these with, per message, VoiceActivityDetector::calculate_energy of the message
+    // (vad.rs:157-168, bit for bit) and max |x| (the `peak` of the audio_level event, events/mod.rs:73-75); nullptr: off
+    void want_level(std::vector<float>* energy, std::vector<float>* peak) { energy_ = energy; peak_ = peak; }
     // the batch's text, clips back to back (cut it with text_len / message_len); pcm16 (optional) gets the samples
     template <class T>
     std::string run(const std::vector<T>& pcm, size_t n_clips, size_t frames_per_clip, std::vector<int16_t>* pcm16 = nullptr)
@@ -625,11 +628,19 @@ private:
     {
         std::string text(total, '\0');
         if (pcm16) pcm16->assign(samples, 0);
+        std::vector<float>* en = energy_;
+        std::vector<float>* pk = peak_;
+        const size_t nm = (en || pk) ? af_wire_total_messages(h_) : 0;
+        if (en) en->assign(nm, 0.0f);
+        if (pk) pk->assign(nm, 0.0f);
         detail::check(af_wire_run(h_, pcm.data(), pcm.size(), text.empty() ? nullptr : &text[0], text.size(),
-                                  pcm16 ? pcm16->data() : nullptr, pcm16 ? pcm16->size() : 0));
+                                  pcm16 ? pcm16->data() : nullptr, pcm16 ? pcm16->size() : 0, en ? en->data() : nullptr,
+                                  pk ? pk->data() : nullptr, nm));
         return text;
     }
     af_wire* h_ = nullptr;
+    std::vector<float>* energy_ = nullptr;
+    std::vector<float>* peak_ = nullptr;
 };
 
 }  // namespace audioflow

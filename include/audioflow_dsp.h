@@ -458,7 +458,12 @@ int       af_chain_fused_plan_describe(uint32_t input_rate, uint32_t output_rate
  * 32 k -> 16 k, 48 -> 24 k ...) and frame_samples 0 or an even divisor of 3840; the 16 kHz f32 signal and the i16 samples
  * then exist in LDS only.  Other f32 configurations with 1 or 2 channels (44.1 k input ...) run the same stages as two
  * launches on equal-length batches; the text is the same bytes either way ("unfused" option: tests compare them).
- * pcm16 (optional, may be NULL): receives the quantised samples beside the text, clip rows back to back. */
+ * pcm16 (optional, may be NULL): receives the quantised samples beside the text, clip rows back to back.
+ * energy, peak (optional, messages only): per message the mean-square energy of VoiceActivityDetector::calculate_energy
+ * (modules/audio/vad.rs:157-168: f32 left fold over the message's resampled samples, bit for bit -- feed it to
+ * af_vad_detect_batch*) and max |x| (the `peak` of the audio_level event, events/mod.rs:73-75,112-115), clips' messages back to
+ * back (af_wire_total_messages() entries).  In the fused launch the 16 kHz f32 signal exists nowhere else: this is where a VAD
+ * gets to see it.  Needs frame_samples to be a multiple of 8. */
 typedef struct af_wire af_wire;
 typedef struct {
     uint32_t input_rate;      /* 48000 */
@@ -481,10 +486,12 @@ af_status af_wire_set_batch_uniform(af_wire* w, size_t n_clips, size_t frames_pe
 af_status af_wire_set_batch(af_wire* w, const int64_t* clip_offsets, size_t n_clips, size_t* total_text,
                             size_t* total_samples);
 af_status af_wire_text_offsets(const af_wire* w, int64_t* text_off /* n_clips + 1 */, size_t cap);
-af_status af_wire_run_device(af_wire* w, const void* pcm_dev, char* text_dev, int16_t* pcm16_dev, void* stream);
-/* host buffers; pcm_len counts samples (frames x channels) */
+size_t    af_wire_total_messages(const af_wire* w);                 /* messages of the batch described; 0 with frame_samples == 0 */
+af_status af_wire_run_device(af_wire* w, const void* pcm_dev, char* text_dev, int16_t* pcm16_dev, float* energy_dev,
+                             float* peak_dev, void* stream);
+/* host buffers; pcm_len counts samples (frames x channels); energy / peak hold level_cap messages each */
 af_status af_wire_run(af_wire* w, const void* pcm, size_t pcm_len, char* text, size_t text_cap, int16_t* pcm16,
-                      size_t pcm16_cap);
+                      size_t pcm16_cap, float* energy, float* peak, size_t level_cap);
 /* "unfused" 1: the stages as separate launches (diagnostics; equal-length f32 batches) */
 af_status af_wire_set_option(af_wire* w, const char* key, int value);
 int       af_wire_n_launches(const af_wire* w);                     /* 1 with the fused launch, else 2 */

@@ -173,8 +173,9 @@ extern "C" {
     pub fn af_wire_set_batch_uniform(w: *mut af_wire, n_clips: usize, frames_per_clip: usize, total_text: *mut usize, total_samples: *mut usize) -> af_status;
     pub fn af_wire_set_batch(w: *mut af_wire, clip_offsets: *const i64, n_clips: usize, total_text: *mut usize, total_samples: *mut usize) -> af_status;
     pub fn af_wire_text_offsets(w: *const af_wire, text_off: *mut i64, cap: usize) -> af_status;
-    pub fn af_wire_run_device(w: *mut af_wire, pcm_dev: *const c_void, text_dev: *mut c_char, pcm16_dev: *mut i16, stream: *mut c_void) -> af_status;
-    pub fn af_wire_run(w: *mut af_wire, pcm: *const c_void, pcm_len: usize, text: *mut c_char, text_cap: usize, pcm16: *mut i16, pcm16_cap: usize) -> af_status;
+    pub fn af_wire_total_messages(w: *const af_wire) -> usize;
+    pub fn af_wire_run_device(w: *mut af_wire, pcm_dev: *const c_void, text_dev: *mut c_char, pcm16_dev: *mut i16, energy_dev: *mut f32, peak_dev: *mut f32, stream: *mut c_void) -> af_status;
+    pub fn af_wire_run(w: *mut af_wire, pcm: *const c_void, pcm_len: usize, text: *mut c_char, text_cap: usize, pcm16: *mut i16, pcm16_cap: usize, energy: *mut f32, peak: *mut f32, level_cap: usize) -> af_status;
     pub fn af_wire_set_option(w: *mut af_wire, key: *const c_char, value: c_int) -> af_status;
     pub fn af_wire_n_launches(w: *const af_wire) -> c_int;
     pub fn af_resample_release_staging();

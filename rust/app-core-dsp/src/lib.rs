@@ -536,7 +536,13 @@ impl<T: PcmSample> Drop for ChainPipeline<T> { fn drop(&mut self) { unsafe { ffi
 /// `(x.clamp(-1.0, 1.0) * 32767.0) as i16`, little-endian (websocket.rs:246-251) -> `STANDARD.encode` (websocket.rs:254).
 /// `frame_samples == 0`: one padded base64 string per clip; `320`: one per 20 ms send batch
 /// (specs/0002-design.md:1543-1546; a trailing partial batch is not sent, as `AudioBatcher` keeps it buffered).
-pub struct WireEncoder<T: PcmSample = f32> { h: *mut ffi::af_wire, _t: std::marker::PhantomData<T> }
+pub struct WireEncoder<T: PcmSample = f32> {
+    h: *mut ffi::af_wire,
+    /// of the last run, per message (messages only): mean-square energy (vad.rs:157-168) and peak (events/mod.rs:73-75)
+    pub energy: Vec<f32>,
+    pub peak: Vec<f32>,
+    _t: std::marker::PhantomData<T>,
+}
 unsafe impl<T: PcmSample> Send for WireEncoder<T> {}
 
 impl<T: PcmSample> WireEncoder<T> {
@@ -550,7 +556,7 @@ impl<T: PcmSample> WireEncoder<T> {
         cfg.frame_samples = frame_samples;
         let mut h = ptr::null_mut();
         check(unsafe { ffi::af_wire_create(&cfg, &mut h) })?;
-        Ok(Self { h, _t: std::marker::PhantomData })
+        Ok(Self { h, energy: Vec::new(), peak: Vec::new(), _t: std::marker::PhantomData })
     }
     /// `AudioResampler::create_48k_to_16k` (resampler.rs:60-62) + the 20 ms batch of specs/0002-design.md:1543-1546
     pub fn create_48k_to_16k_messages(channels: u32) -> Result<Self, AudioError> { Self::new(48000, 16000, channels, 320) }
@@ -574,7 +580,12 @@ impl<T: PcmSample> WireEncoder<T> {
     }
     fn run_described(&mut self, pcm: &[T], n_clips: usize, total: usize) -> Result<Vec<Vec<String>>, AudioError> {
         let mut text = vec![0u8; total];
-        check(unsafe { ffi::af_wire_run(self.h, pcm.as_ptr() as *const c_void, pcm.len(), text.as_mut_ptr() as *mut _, text.len(), ptr::null_mut(), 0) })?;
+        // per message: `VoiceActivityDetector::calculate_energy` of the message (vad.rs:157-168) and max |x|
+        let nm = unsafe { ffi::af_wire_total_messages(self.h) };
+        self.energy = vec![0.0f32; nm];
+        self.peak = vec![0.0f32; nm];
+        let (ep, pp) = if nm > 0 { (self.energy.as_mut_ptr(), self.peak.as_mut_ptr()) } else { (ptr::null_mut(), ptr::null_mut()) };
+        check(unsafe { ffi::af_wire_run(self.h, pcm.as_ptr() as *const c_void, pcm.len(), text.as_mut_ptr() as *mut _, text.len(), ptr::null_mut(), 0, ep, pp, nm) })?;
         let mut off = vec![0i64; n_clips + 1];
         check(unsafe { ffi::af_wire_text_offsets(self.h, off.as_mut_ptr(), off.len()) })?;
         let ml = self.message_len();

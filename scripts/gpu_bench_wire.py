@@ -14,6 +14,7 @@ ap.add_argument("--clips", type=int, default=1024); ap.add_argument("--frame", t
 ap.add_argument("--reps", type=int, default=20); ap.add_argument("--warm_s", type=float, default=0.3)
 ap.add_argument("--fmt", default="f32"); ap.add_argument("--json", default="")
 ap.add_argument("--only", default="", help="fused: time only the fused launch (profiling runs)")
+ap.add_argument("--level", action="store_true", help="also emit the messages' energy and peak (frame > 0)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n = 1440000
@@ -44,6 +45,11 @@ alg = pcm.numel() * pcm.element_size() + total
 res = {"workload": f"{a.clips} x 30 s stereo 48 kHz {a.fmt} -> 16 kHz PCM16 base64" + (f", messages of {a.frame} samples" if a.frame else ", one string per clip"),
        "algorithmic_bytes": alg, "text_bytes": total, "launches_fused": w.n_launches()}
 ms = timed(lambda: w.run_device(pcm.data_ptr(), text.data_ptr(), 0, s))
+if a.level and a.frame:
+    en = torch.empty(w.total_messages(), device=dev); pk = torch.empty_like(en)
+    ms_l = timed(lambda: w.run_device(pcm.data_ptr(), text.data_ptr(), 0, s, en.data_ptr(), pk.data_ptr()))
+    res["fused_with_energy_and_peak_ms"] = ms_l
+    res["fused_with_energy_and_peak_frac_of_8TBps"] = (alg + 2 * en.numel() * 4) / ms_l / 1e9 / 8.0
 res["fused_ms"] = ms; res["fused_TBps"] = alg / ms / 1e9; res["fused_frac_of_8TBps"] = alg / ms / 1e9 / 8.0
 res["rtf"] = a.clips * 30.0 / (ms * 1e-3)
 if a.only != "fused" and a.fmt == "f32":

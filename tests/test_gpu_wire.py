@@ -135,6 +135,70 @@ def test_wire_messages(af, po, frame):
         assert td.cpu().numpy().tobytes() == whole and bits_equal(qd.cpu().numpy(), q)
 
 
+@pytest.mark.parametrize("frame", [320, 160, 480, 8])
+def test_wire_message_energy_and_peak(af, po, frame):
+    """Per message, beside the text: the mean-square energy VoiceActivityDetector::calculate_energy computes on the
+    message (vad.rs:157-168 -- an f32 LEFT fold: bits equal to the oracle's and to af_vad_energy on the stand-alone
+    resampler's signal) and max |x| (the audio_level event's peak, events/mod.rs:73-75).  In the fused launch the 16 kHz
+    f32 signal exists in LDS only, so this is where a VAD gets its input; the text does not change."""
+    n_frames, n_clips = 48000 * 2 + 1234, 3
+    x = _clips(n_clips, n_frames, 2, seed=61, gain=1.3)
+    x[1, :9000] = 0.0                                               # silence: energy exactly 0
+    w = af.WireEncoder(frame_samples=frame)
+    w.set_batch_uniform(n_clips, n_frames)
+    plain = w.run(x)
+    text, en, pk = w.run(x, with_level=True)
+    assert text == plain
+    y = af.resample_stereo_batch(x, 48000, 16000)
+    nm = w.n_messages(n_frames)
+    assert en.size == pk.size == n_clips * nm == w.total_messages()
+    for i in range(n_clips):
+        msgs = y[i, :nm * frame].reshape(nm, frame)
+        assert bits_equal(en[i * nm:(i + 1) * nm], af.vad_energy(msgs.reshape(-1), frame))          # the stand-alone kernel
+        want = np.array([po.vad_energy(m) for m in msgs[:40]], np.float32)                          # the oracle's left fold
+        assert bits_equal(en[i * nm:i * nm + want.size], want)
+        assert bits_equal(pk[i * nm:(i + 1) * nm], np.abs(msgs).max(axis=1))
+    assert (en[nm:nm + 9000 // 2 // 3 // frame - 1] == 0.0).all()       # (9 000 interleaved samples = 4 500 frames = 1 500 resampled)
+    w.set_option("unfused", 1)
+    text2, en2, pk2 = w.run(x, with_level=True)
+    assert text2 == text and bits_equal(en2, en) and bits_equal(pk2, pk)
+    # ragged batch: the clips' messages back to back
+    lens = [7000, 48000, 5, 33333]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    xr = _clips(1, int(off[-1]), 2, seed=62)[0]
+    w2 = af.WireEncoder(frame_samples=frame)
+    w2.set_batch(off)
+    _, en_r, pk_r = w2.run(xr, with_level=True)
+    k = 0
+    for i, n in enumerate(lens):
+        yi = af.resample_stereo_batch(xr.reshape(-1, 2)[off[i]:off[i + 1]].reshape(1, -1), 48000, 16000)[0]
+        m = yi.size // frame
+        if m:
+            assert bits_equal(en_r[k:k + m], af.vad_energy(yi[:m * frame], frame))
+            assert bits_equal(pk_r[k:k + m], np.abs(yi[:m * frame].reshape(m, frame)).max(axis=1))
+        k += m
+    assert k == en_r.size
+
+
+def test_wire_energy_feeds_the_batched_vad(af, po):
+    """the energies of the fused launch through the reference's state machine (vad.rs:97-151, af_vad_detect_batch on the
+    stand-alone resampler's signal as the comparison): identical states"""
+    n_frames = 48000 * 4
+    x = _clips(2, n_frames, 2, seed=71, gain=1.0).reshape(2, n_frames, 2)
+    x[0, 40000:90000] *= np.float32(1e-4)                            # a stretch below the threshold
+    x[1, :60000] = 0.0
+    x = x.reshape(2, -1)
+    w = af.WireEncoder(frame_samples=320)
+    w.set_batch_uniform(2, n_frames)
+    _, en, _ = w.run(x, with_level=True)
+    y = af.resample_stereo_batch(x, 48000, 16000)
+    nm = w.n_messages(n_frames)
+    want = af.VoiceActivityDetector.detect_batch(y[:, :nm * 320], 320)
+    got = po.vad_scan_batch(en.reshape(2, nm))
+    assert np.array_equal(np.asarray(want).reshape(2, nm), np.asarray(got).reshape(2, nm))
+    assert len(set(np.asarray(got).reshape(-1).tolist())) >= 2      # both silence and speech occur
+
+
 def test_wire_frame_outside_the_fused_tile_runs_the_stages(af, po):
     """a message length that does not divide the tile (300) / a ratio with ten block matrices (44.1 k): two launches"""
     x = _clips(2, 30000, 2, seed=31)
