@@ -1054,16 +1054,9 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     constexpr int nthreads = 640, NB = 10, kG = 2, P2 = 20, colz = 16 * P2, y_per_tile = 256 * P2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = block matrix p
-    const int col = lane & 15, g4 = lane >> 4;
     const int qp = (int)(((int64_t)16 * wave * g.M) / g.L);          // q(16 p)
 
-    const int base_full_a = col * g.seg_stride + 16 * g4 + qp + g.shift;
-    const int base_tail_a = col * g.seg_stride + TAILA * g4 + 64 * FULLA + qp + g.shift;
     const int wave_off_b = wave * 2 * 16;
-    const int base_full_b = col * g.seg_stride_b + 16 * g4 + wave_off_b;
-    const int base_tail_b = col * g.seg_stride_b + TAILB * g4 + 64 * FULLB + wave_off_b;
-    const int y_lane = 16 * NB * (kG * col) + 16 * wave + 4 * g4;     // tile-relative resampled index of acc0[0]; acc1: + 160
-    const int z_lane = 16 * (col * P2 + wave * 2) + 4 * g4;          // tile-relative FIR output of acc0[0]
     const int col_span = kG * g.S;
     const int km1 = g.K - 1;
     const bool first = PAIR ? 2 * tid < g.seg_len + g.shift : tid < g.seg_len;
@@ -1233,6 +1226,16 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
         // ---- phase A: resampled samples [y0, y0 + 5 120) into the FIR's column segments ----
         const int64_t y0 = tc.t_abs * y_per_tile;
+        // (the lane's offsets, from a lane index the compiler cannot see through: hoisted out of the tile loop they cost
+        // twenty registers next to 64 + 64 of fragments and staging -- 23 spilled, every reload behind the x requests)
+        const int lz = lane + opaque_zero();
+        const int colz_l = lz & 15, g4z = lz >> 4;
+        const int base_full_a = colz_l * g.seg_stride + 16 * g4z + qp + g.shift;
+        const int base_tail_a = colz_l * g.seg_stride + TAILA * g4z + 64 * FULLA + qp + g.shift;
+        const int base_full_b = colz_l * g.seg_stride_b + 16 * g4z + wave_off_b;
+        const int base_tail_b = colz_l * g.seg_stride_b + TAILB * g4z + 64 * FULLB + wave_off_b;
+        const int y_lane = 16 * NB * (kG * colz_l) + 16 * wave + 4 * g4z;  // tile-relative resampled index of acc0[0]; acc1: + 160
+        const int z_lane = 16 * (colz_l * P2 + wave * 2) + 4 * g4z;       // tile-relative FIR output of acc0[0]
         {
             // the FIR's history in front of the tile: zeros at a clip's start, else the previous pass's carry
             if (!warm && tid < km1) ys[tid] = tc.t_abs > 0 ? cw[(par ^ 1) * kCarry + tid] : 0.0f;
@@ -1259,8 +1262,8 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const int c = e / colz;
                 const int pos = e - c * colz;
                 const int at = c * g.seg_stride_b + pos;
-                if (c < kCols) ys[at] = v;
-                else cwp[pos] = v;                                     // c == 16: pos < K - 1
+                float* own = c < kCols ? ys + at : cwp + pos;           // c == 16 (pos < K - 1): the carry
+                *own = v;
                 ys[(c >= 1 && pos + colz < g.seg_len_b) ? at - g.seg_stride_b + colz : spare] = v;
             };
 #pragma unroll
@@ -1337,6 +1340,7 @@ struct WireCtx {
 // LEVEL: also the messages' VAD energy and peak, from an f32 image of the tile beside the PCM16 one.  The reference's energy
 // is a LEFT fold in f32 (`frame.iter().map(|&x| x * x).sum()`, vad.rs:163-165): one lane folds one message, in order, no FMA.
 // In the fused path the 16 kHz f32 signal exists nowhere else, so this is the only place a VAD can look at it.
+constexpr int kLevelWave = 7;         // its second chain (block period 15) is dropped anyway: the lightest wave folds
 template <int NKA, int FMT, bool LEVEL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void wire_kernel(const WireGeom g)
 {
@@ -1353,12 +1357,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr int kGpw = 2;                                         // one chain pair per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 15, g4 = lane >> 4;
-
     const int wave_off_a = wave * kGpw * g.S;
-    const int base_full_a = col * g.seg_stride + 16 * g4 + wave_off_a + g.shift;
-    const int base_tail_a = col * g.seg_stride + TAILA * g4 + 64 * FULLA + wave_off_a + g.shift;
-    const int y_lane = 16 * (col * g.Gv + wave * kGpw) + 4 * g4;    // tile-relative resampled index of acc0[0]
     const int y_per_tile = 256 * g.Gv;
     const int col_span = g.Gv * g.S;
     const bool first = PAIR ? 2 * tid < g.seg_len + g.shift : tid < g.seg_len;
@@ -1467,6 +1466,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     };
 
+    if constexpr (LEVEL) {
+        if (tid < 64) reinterpret_cast<unsigned*>(xs + g.fimg_off + kCols * (16 * g.Gv + 4))[tid] = 0u;    // (visible behind the first barrier)
+    }
     uint32_t tile = blockIdx.x;
     if (tile < n_tiles) {
         prep_tile(tile, true);
@@ -1511,6 +1513,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int64_t y0 = tc.t_abs * y_per_tile;
         const int64_t y_left = tc.n_res - y0;
         const int y_hi = y_left > y_per_tile ? y_per_tile : y_left < 0 ? 0 : (int)y_left;
+        // (the lane's offsets from a lane index the compiler cannot see through: hoisted out of the tile loop they sit next
+        // to 28 fragment and 64 staging registers and spill -- every reload then waits behind the x requests in flight)
+        const int lz = lane + opaque_zero();
+        const int col = lz & 15, g4 = lz >> 4;
+        const int base_full_a = col * g.seg_stride + 16 * g4 + wave_off_a + g.shift;
+        const int base_tail_a = col * g.seg_stride + TAILA * g4 + 64 * FULLA + wave_off_a + g.shift;
+        const int y_lane = 16 * (col * g.Gv + wave * kGpw) + 4 * g4;    // tile-relative resampled index of acc0[0]
         {
             const float* b0p = xs + base_full_a;
             const float* t0p = xs + base_tail_a;
@@ -1541,55 +1550,82 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 *reinterpret_cast<u32x2*>(ic + 8) = u32x2{lo, hi};
             }
             if constexpr (LEVEL) {
-                // the same samples as f32 (zero behind the clip's end); columns 16 Gv + 4 floats apart: the eight lanes of a
-                // ds_write_b128 group start 20 banks apart, no two on the same four
+                // The samples' SQUARES as f32 (zero behind the clip's end) -- the products of vad.rs:163-165, one rounding
+                // each, computed by every lane for its own samples; what is left to the fold is the sum.  Columns 16 Gv + 4
+                // floats apart: the eight lanes of a ds_write_b128 group start 20 banks apart, no two on the same four.
                 float* fc = xs + g.fimg_off + col * (16 * g.Gv + 4) + 16 * wave * kGpw + 4 * g4;
-                auto masked = [&](const f32x4& acc, int yi) {
-                    return f32x4{yi < y_hi ? acc[0] : 0.f, yi + 1 < y_hi ? acc[1] : 0.f, yi + 2 < y_hi ? acc[2] : 0.f,
-                                 yi + 3 < y_hi ? acc[3] : 0.f};
+                unsigned* pkb = reinterpret_cast<unsigned*>(xs + g.fimg_off + kCols * (16 * g.Gv + 4));   // [64] max |x| bits per message
+                auto squares = [&](const f32x4& acc, int yi, float& m) {
+                    f32x4 p;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = yi + j < y_hi ? acc[j] : 0.0f;
+                        p[j] = v * v;
+                        m = fmaxf(m, fabsf(v));
+                    }
+                    return p;
                 };
-                *reinterpret_cast<f32x4*>(fc) = masked(acc0, y_lane);
-                if (wave * kGpw + 1 < g.Gv) *reinterpret_cast<f32x4*>(fc + 16) = masked(acc1, y_lane + 16);
+                // peak: the 16 outputs of a block (the four g4 lanes of a column) lie in one message (frame % 16 == 0):
+                // max over those lanes, then one LDS atomic per block (|x| >= 0: its bits order like unsigned integers)
+                auto block_peak = [&](float m, int yi, bool on) {
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    if (on && g4 == 0 && yi < y_hi) atomicMax(pkb + yi / g.frame, __float_as_uint(m));
+                };
+                float m0 = 0.0f, m1 = 0.0f;
+                *reinterpret_cast<f32x4*>(fc) = squares(acc0, y_lane, m0);
+                const bool second_on = wave * kGpw + 1 < g.Gv;
+                const f32x4 p1 = squares(acc1, y_lane + 16, m1);
+                if (second_on) *reinterpret_cast<f32x4*>(fc + 16) = p1;
+                block_peak(m0, y_lane, true);
+                block_peak(m1, y_lane + 16, second_on);
             }
         }
         __syncthreads();
 
         if constexpr (LEVEL) {
-            // ---- the messages' energy and peak: message f of the tile on lane f / 8 of wave f % 8 ----
-#pragma clang fp contract(off)
-            const int n_msg = y_per_tile / g.frame;
-            const int f = wave + 8 * lane;
-            const int64_t fa = y0 / g.frame + f;
-            if (f < n_msg && (fa + 1) * g.frame <= tc.n_res) {
-                const float* fi = xs + g.fimg_off;
-                const int colf = 16 * g.Gv;
-                const int s0 = f * g.frame;
-                int c = s0 / colf, r = s0 - c * colf;                // column and position of the running sample
-                float e = 0.0f, m = 0.0f;
-                for (int i = 0; i < g.frame; i += 8) {               // (frame is a multiple of 8 here: launch_wire checks)
-                    float v[8];
+            // ---- the messages' energy: ONE wave, message f of the tile on lane f, a left fold over the message's squares
+            // (vad.rs:163-165 `.sum()`: in order, f32).  The other waves go on to the base64 groups and the next tile's staging.
+            if (wave == kLevelWave) {
+                const int n_msg = y_per_tile / g.frame;
+                const int f = lane;
+                const int64_t fa = y0 / g.frame + f;
+                unsigned* pkb = reinterpret_cast<unsigned*>(xs + g.fimg_off + kCols * (16 * g.Gv + 4));
+                if (f < n_msg) {
+                    // A message and a column (240 samples) both start on multiples of 80 samples (frame % 80 == 0): the fold
+                    // walks chunks of 20 quads that never cross a column's padding, five 16-byte reads in flight at a time
+                    // (one read per iteration left every add waiting for an LDS round trip: 8.2 ms for the launch).
+                    const int colf = 16 * g.Gv;
+                    const int s0 = f * g.frame;
+                    float e = 0.0f;
+                    for (int i = 0; i < g.frame; i += 80) {
+                        const int s = s0 + i, c = s / colf;
+                        const f32x4* q = reinterpret_cast<const f32x4*>(xs + g.fimg_off + c * (colf + 4) + (s - c * colf));
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        v[k] = fi[c * (colf + 4) + r];
-                        r += 1;
-                        if (r == colf) { r = 0; c += 1; }
+                        for (int h = 0; h < 4; ++h) {                 // (five reads = 20 registers: the next tile's 64 staging registers are live)
+                            f32x4 p[5];
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) p[k] = q[5 * h + k];
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) { e = e + p[k][0]; e = e + p[k][1]; e = e + p[k][2]; e = e + p[k][3]; }
+                        }
                     }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float p = v[k] * v[k];                 // vad.rs:163-165: one rounding per product and per add
-                        e = e + p;
-                        m = fmaxf(m, fabsf(v[k]));
+                    const unsigned mb = pkb[f];
+                    pkb[f] = 0u;                                     // for the next tile (its atomics come behind the next barrier)
+                    if ((fa + 1) * g.frame <= tc.n_res) {             // only whole messages exist (specs/0002-design.md:1543-1546)
+                        if (g.energy) g.energy[tc.msg0 + fa] = e / (float)g.frame;      // vad.rs:167
+                        if (g.peak) g.peak[tc.msg0 + fa] = __uint_as_float(mb);
                     }
                 }
-                if (g.energy) g.energy[tc.msg0 + fa] = e / (float)g.frame;      // vad.rs:167
-                if (g.peak) g.peak[tc.msg0 + fa] = m;
             }
         }
 
         // ---- base64: whole groups of 6 samples per thread ----
         {
             const int n_items = g.frame ? (y_per_tile / g.frame) * g.gpf : y_per_tile / 6;
-            for (int it = tid; it < n_items; it += nthreads) {
+            // (LEVEL: the folding wave, the last one, leaves the groups to the other seven)
+            constexpr int kEncThreads = LEVEL ? nthreads - 64 : nthreads;
+            for (int it = tid; it < n_items && tid < kEncThreads; it += kEncThreads) {
                 int s0, cnt;                                         // first sample of the group in the tile, real samples
                 int64_t toff;                                        // its first character in the clip's text
                 bool send = true;                                    // the group's characters are part of the text
@@ -2250,7 +2286,7 @@ WirePlan make_wire_plan(const Plan& a, int fmt, int frame_samples)
     w.img_off = (kCols * w.seg_stride_a + 3) & ~3;             // 16-byte aligned
     w.smem = ((size_t)w.img_off + (size_t)kCols * (8 * w.Gv + 2)) * sizeof(float);    // image: padded columns
     w.fimg_off = (w.img_off + kCols * (8 * w.Gv + 2) + 3) & ~3;
-    w.smem_level = ((size_t)w.fimg_off + (size_t)kCols * (16 * w.Gv + 4)) * sizeof(float);
+    w.smem_level = ((size_t)w.fimg_off + (size_t)kCols * (16 * w.Gv + 4) + 64) * sizeof(float);   // + the messages' peak words
     if (2 * w.smem > 160 * 1024) return w;                     // two workgroups per CU or not at all
     w.ok = true;
     return w;
@@ -2300,8 +2336,9 @@ af_status launch_wire(const WirePlan& w, const float* afrag_a, const WireArgs& q
     g.text_align = q.text_align;
     const bool level = q.energy || q.peak;
     if (level) {
-        if (!w.frame || w.frame % 8 != 0 || w.y_per_tile / w.frame > 8 * 64)
-            return fail(AF_ERR_UNSUPPORTED, "banded::launch_wire: energy / peak rows need messages of a multiple of 8 samples (frame_samples %d)", w.frame);
+        if (!w.frame || w.frame % 80 != 0 || w.y_per_tile / w.frame > 64)
+            return fail(AF_ERR_UNSUPPORTED, "banded::launch_wire: energy / peak rows need messages of a multiple of 80 samples, at most 64 per tile of %lld (frame_samples %d)",
+                        (long long)w.y_per_tile, w.frame);
         if (2 * w.smem_level > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "banded::launch_wire: no room for the f32 image beside two workgroups per CU");
         g.energy = q.energy;
         g.peak = q.peak;

@@ -323,7 +323,15 @@ af_status af_wire_run_device(af_wire* w, const void* pcm_dev, char* text_dev, in
     AF_REQUIRE(pcm_dev && text_dev, "af_wire_run_device: null buffer");
     AF_REQUIRE(!(energy_dev || peak_dev) || w->cfg.frame_samples, "af_wire_run_device: energy / peak rows are per message (frame_samples > 0)");
     hipStream_t s = as_stream(stream);
-    if (fused(w)) {
+    // the fused launch folds a tile's messages on the 64 lanes of one wave, 16-byte reads: messages of a multiple of 16
+    // samples, at most 64 per tile; other message lengths take the stage-by-stage form for this call where that exists
+    const bool want_level = energy_dev || peak_dev;
+    const bool level_fused = !want_level || (w->cfg.frame_samples % 80 == 0 && w->plan.y_per_tile / (int64_t)w->cfg.frame_samples <= 64);
+    const bool stages_possible = !w->ragged && w->cfg.sample_format == AF_PCM_F32 && w->cfg.channels <= 2;
+    if (fused(w) && !level_fused && !stages_possible)
+        return fail(AF_ERR_UNSUPPORTED, "af_wire: energy / peak rows in the fused launch need messages of a multiple of 80 samples, at "
+                    "most 64 per 3840 (frame_samples %u)", w->cfg.frame_samples);
+    if (fused(w) && level_fused) {
         if (w->fmt == banded::kFmtMonoI16 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 != 0)
             return fail(AF_ERR_INVALID_ARG, "af_wire_run_device: mono i16 PCM must start on a 4-byte boundary (got %p)", pcm_dev);
         banded::WireArgs q;
