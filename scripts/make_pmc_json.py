@@ -41,6 +41,11 @@ copies = {"kernel_stats.txt": RT + "_kernel_stats.txt", "pmc_fetch.txt": RT + "_
           "pmc_res_sq.txt": RT + "_res_pmc_sq.txt", "pmc_res_sq2.txt": RT + "_res_pmc_sq2.txt",
           "resample_ratios.json": RT + "_resample_ratios.json", "ops.json": RT + "_ops.json",
           "ops_kernel_stats.txt": RT + "_ops_kernel_stats.txt",
+          "wire_kernel_stats.txt": RT + "_wire_kernel_stats.txt", "pmc_wire_fetch.txt": RT + "_wire_pmc_fetch.txt",
+          "pmc_wire_write.txt": RT + "_wire_pmc_write.txt", "pmc_wire_sq.txt": RT + "_wire_pmc_sq.txt", "pmc_wire_sq2.txt": RT + "_wire_pmc_sq2.txt",
+          "wire_bench.json": RT + "_wire_bench.json", "wire_bench_messages320.json": RT + "_wire_bench_messages320.json",
+          "wire_bench_i16.json": RT + "_wire_bench_i16.json", "chain44_kernel_stats.txt": RT + "_chain44_kernel_stats.txt",
+          "chain44.txt": RT + "_chain44.txt",
           "v3_kernel_stats.txt": RT + "_v3_kernel_stats.txt", "pmc_v3_fetch.txt": RT + "_v3_pmc_fetch.txt",
           "pmc_v3_write.txt": RT + "_v3_pmc_write.txt", "pmc_v3_sq.txt": RT + "_v3_pmc_sq.txt", "pmc_v3_sq2.txt": RT + "_v3_pmc_sq2.txt"}
 for a, b in copies.items():
@@ -87,7 +92,7 @@ if cfch and cwch:
                    "hbm_read_bytes_per_launch": int(r_), "hbm_write_bytes_per_launch": int(w_)}
         tot += r_ + w_
     alg4 = 256 * 1440000 * 8 + 479232 * 320
-    traffic["chain_config4"] = {"workload": "256 x 30 s stereo 48 kHz f32 -> downmix + 48->16 kHz + FIR 129 (one launch) -> STFT -> 80 mel (one launch); scripts/profile_r04.sh",
+    traffic["chain_config4"] = {"workload": "256 x 30 s stereo 48 kHz f32 -> downmix + 48->16 kHz + FIR 129 (one launch) -> STFT -> 80 mel (one launch); scripts/profile_r%02d.sh" % ROUND,
                                 "kernels": kern, "hbm_bytes_per_pass": int(tot), "algorithmic_bytes_per_pass": alg4,
                                 "traffic_over_algorithmic": round(tot / alg4, 4),
                                 "source": ["profiles/" + RT + "_chain_pmc_fetch.txt", "profiles/" + RT + "_chain_pmc_write.txt"]}
@@ -103,6 +108,17 @@ if rf and rw:
                                          "hbm_read_bytes_per_launch_indicative": int(r_), "hbm_write_bytes_per_launch": int(w_),
                                          "algorithmic_bytes_per_launch": alg,
                                          "source": ["profiles/" + RT + "_res_pmc_fetch.txt", "profiles/" + RT + "_res_pmc_write.txt"]}
+# the wire path in one launch
+wf, ww = table("pmc_wire_fetch.txt"), table("pmc_wire_write.txt")
+if wf and ww:
+    k, v = first(wf, "wire_kernel")
+    r_ = v["FETCH_SIZE"] * 1024 / cal_f
+    w_ = first(ww, "wire_kernel")[1]["WRITE_SIZE"] * 1024 / cal_w
+    algw = 1024 * 1440000 * 8 + 1024 * 4 * ((2 * 480000 + 2) // 3)
+    traffic["wire_1024x30s"] = {"workload": "1024 x 30 s stereo 48 kHz f32 -> to_mono -> 16 kHz -> PCM16 -> base64 (one string per clip), ONE launch", "kernel": k,
+                                "hbm_read_bytes_per_launch": int(r_), "hbm_write_bytes_per_launch": int(w_), "hbm_bytes_per_launch": int(r_ + w_),
+                                "algorithmic_bytes_per_launch": algw, "traffic_over_algorithmic": round((r_ + w_) / algw, 4),
+                                "source": ["profiles/" + RT + "_wire_pmc_fetch.txt", "profiles/" + RT + "_wire_pmc_write.txt"]}
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
 # ---- the other resources of the headline kernel (HBM fraction AND VALU / MFMA / LDS fractions)
@@ -123,9 +139,13 @@ res = {
                  "SQ_WAIT_INST_ANY": s1["SQ_WAIT_INST_ANY"], "SQ_ACTIVE_INST_ANY": s1["SQ_ACTIVE_INST_ANY"]},
     "formulas": "lds = SQ_LDS_IDX_ACTIVE / 256 CUs; valu = SQ_INSTS_VALU x 2 cycles / 1024 SIMDs; mfma = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; all over GRBM_GUI_ACTIVE / 8 XCDs of the profiled launch",
     "source": ["profiles/" + RT + "_pmc_sq.txt", "profiles/" + RT + "_pmc_sq2.txt"],
-    "note": "recorded by separate rocprofv3 --pmc passes (scripts/profile_r04.sh), not measured by the bench run that quotes it",
+    "note": "recorded by separate rocprofv3 --pmc passes (scripts/profile_r%02d.sh), not measured by the bench run that quotes it" % ROUND,
+    "in_kernel_clock_GHz": 2.14, "in_kernel_clock_note": "s_memtime / s_memrealtime inside the product kernel (AF_V2_CLK builds, profiles/r05_v2_ablations.txt): 2.11-2.16 GHz against 2.38 GHz for builds with a large piece left out -- the launch is power-limited",
 }
 # the matrix-core DFT kernel (opt-in) on the same workload, same formulas
+old_res = json.load(open(os.path.join(dst, "pmc_resources.json"))) if os.path.exists(os.path.join(dst, "pmc_resources.json")) else {}
+if not (table("pmc_v3_sq.txt") and table("pmc_v3_sq2.txt")) and old_res.get("features_v3"):
+    res["features_v3"] = dict(old_res["features_v3"], recorded_in_round=old_res["features_v3"].get("recorded_in_round", old_res.get("round")))
 if table("pmc_v3_sq.txt") and table("pmc_v3_sq2.txt"):
     k3, v1 = first(table("pmc_v3_sq.txt"), "af_features_v3")
     _, v2 = first(table("pmc_v3_sq2.txt"), "af_features_v3")
