@@ -400,7 +400,7 @@ af_status af_chain_set_option(af_chain* c, const char* key, int value)
     }
     // the STFT / mel stage is a feature handle of its own: its kernel choice follows af_debug_set("features.kernel") unless
     // the chain pins it here (tests/test_gpu_concurrency.py flips the process-wide switch under a running chain)
-    if (std::strcmp(key, "kernel") == 0 || std::strcmp(key, "wg_per_cu") == 0) return af_features_set_option(c->feat, key, value);
+    if (std::strcmp(key, "kernel") == 0 || std::strcmp(key, "wg_per_cu") == 0 || std::strcmp(key, "mel4") == 0) return af_features_set_option(c->feat, key, value);
     return fail(AF_ERR_INVALID_ARG, "af_chain_set_option: unknown option '%s'", key);
 }
 

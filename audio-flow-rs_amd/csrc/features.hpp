@@ -101,6 +101,22 @@ struct Params {
     int64_t total_units;
     int out_power, log_mel;
     unsigned long long* stamps;   // diagnostics only: [4 waves][8] summed phase cycles, or null
+    // mel phase on v_mfma_f32_4x4x1_16b_f32 (round 5; Plan4 below): null = the 16 x 16 x 4 plan above
+    const float* wfrag4;      // [2 groups][kM4Quads][64][4]
+    const int* lane4;         // [2 groups][64]: k_start | quad << 10 | owner << 17 | add1 << 18 | add2 << 19 | (lane & 3) << 20
+    int m4_quads[2];          // 16-byte operand quads (= 4 steps) of each group
+};
+
+// The mel phase on 16 blocks of 4 x 4 x 1 (round 5).  The banded filterbank touches two filters per bin; a 16-filter
+// tile multiplies every bin of its band with all 16 rows, a 4-filter tile wastes a quarter of that.  A tile = one filter
+// quad x one frame quad, accumulating over the quad's band; wave w takes frame quad w & 3 and the filter quads of group
+// w >> 2; its 16 block slots hold the group's tiles, long bands cut into up to four pieces that sit side by side in
+// one row of four blocks (summed at the end by two DPP row shifts).  All pieces of a group run `steps` bins.
+constexpr int kM4Quads = 8;               // at most 32 steps per wave
+struct Plan4 {
+    bool ok = false;
+    int quads[2] = {0, 0};                // steps / 4 per group
+    int n_pieces[2] = {0, 0};
 };
 
 af_status launch(const Params& p, int channels, bool i16, bool separate, int grid, hipStream_t stream);

@@ -2,6 +2,7 @@
 // builds the constant tables (window, twiddles, banded mel plan), the per-batch
 // clip tables, and launches the fused kernel of features_kernel.hip.
 #include <algorithm>
+#include <numeric>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +34,9 @@ struct af_features {
     DevBuf d_units;                  // v2::UnitDesc per 16-frame unit (hop 256 only)
     bool units_ok = false;
     DevBuf d_tabs3;                  // features_v3.hip: f16-pair fragment tables of the two DFT stages (hop 256, mel output),
+    v2::Plan4 plan4;                  // hop-256 kernel: the mel phase on 4 x 4 x 1 blocks (ok: used instead of plan8)
+    DevBuf d_mel4;                   // its fragments [2][kM4Quads][64][4] | lane words [2][64]
+    int opt_mel4 = -1;               // af_features_set_option("mel4"): 0 forces the 16 x 16 x 4 plan, -1 the default
     bool v3_ok = false;              // then its mel plan's fragments and slot table (steps of a slot 4 bins apart)
     bool v3_tried = false;           // build_v3 ran (on af_features_set_option(h, "kernel", 3))
     std::vector<double> win1024;     // the window of the 1024-point frame (zero behind n_fft): what build_v3 needs later
@@ -260,6 +264,94 @@ af_status build_plan(const std::vector<float>& W, int n_mels, int kWaves, int ma
     return AF_OK;
 }
 
+// Plan of the mel phase on 16 blocks of 4 x 4 x 1 (features.hpp, v2::Plan4).  Returns !ok where the filterbank does not
+// fit (n_mels not a multiple of 4, more than 16 pieces per group at 32 steps): the 16 x 16 x 4 plan serves those.
+v2::Plan4 build_plan4(const std::vector<float>& W, int n_mels, std::vector<float>& wfrag4, std::vector<int>& lane4)
+{
+    v2::Plan4 pl;
+    wfrag4.assign((size_t)2 * v2::kM4Quads * 64 * 4, 0.0f);
+    lane4.assign(2 * 64, 0);
+    if (n_mels % 4 != 0 || n_mels <= 0) return pl;
+    const int nq = n_mels / 4;
+    struct Band { int q, k0, len; };
+    std::vector<Band> bands;
+    for (int q = 0; q < nq; ++q) {
+        int lo = kBins, hi = -1;
+        for (int m = 4 * q; m < 4 * q + 4; ++m)
+            for (int k = 0; k < kBins; ++k)
+                if (W[(size_t)m * kBins + k] != 0.0f) { lo = std::min(lo, k); hi = std::max(hi, k); }
+        if (hi < lo) { lo = 0; hi = 0; }                     // an all-zero quad: one harmless step
+        const int k0 = lo & ~3;
+        bands.push_back({q, k0, hi - k0 + 1});
+    }
+    // the quads dealt to the two groups, longest first, to the lighter group
+    std::vector<Band> order = bands;
+    std::sort(order.begin(), order.end(), [](const Band& a, const Band& b) { return a.len > b.len || (a.len == b.len && a.q < b.q); });
+    std::vector<Band> grp[2];
+    int sum[2] = {0, 0};
+    for (const Band& b : order) {
+        const int g = sum[0] <= sum[1] ? 0 : 1;
+        grp[g].push_back(b);
+        sum[g] += b.len;
+    }
+    for (int g = 0; g < 2; ++g) {
+        // the fewest steps S (a multiple of 4) at which every band fits <= 4 pieces and the pieces fit 4 rows of 4 blocks
+        int S = 0;
+        std::vector<int> pcs;
+        for (int cand = 4; cand <= 4 * v2::kM4Quads && !S; cand += 4) {
+            pcs.clear();
+            bool ok = true;
+            for (const Band& b : grp[g]) {
+                const int pc = (b.len + cand - 1) / cand;
+                if (pc > 4) { ok = false; break; }
+                pcs.push_back(pc);
+            }
+            if (!ok) continue;
+            // first fit, largest first (exact for sizes 1..4 in rows of 4)
+            std::vector<int> idx(pcs.size());
+            std::iota(idx.begin(), idx.end(), 0);
+            std::sort(idx.begin(), idx.end(), [&](int a, int b) { return pcs[a] > pcs[b] || (pcs[a] == pcs[b] && a < b); });
+            int cap[4] = {4, 4, 4, 4};
+            std::vector<int> row(pcs.size(), -1);
+            for (int i : idx) {
+                for (int r = 0; r < 4 && row[i] < 0; ++r)
+                    if (cap[r] >= pcs[i]) { row[i] = r; cap[r] -= pcs[i]; }
+                if (row[i] < 0) { ok = false; break; }
+            }
+            if (!ok) continue;
+            S = cand;
+            // lay the tiles out: within a row in the order they were placed
+            int used[4] = {0, 0, 0, 0};
+            for (int i : idx) {
+                const Band& b = grp[g][i];
+                for (int pi = 0; pi < pcs[i]; ++pi) {
+                    const int blk = 4 * row[i] + used[row[i]] + pi;
+                    int lo = b.k0 + pi * S, hi = std::min(lo + S, b.k0 + b.len);      // the piece's bins [lo, hi)
+                    int ks = lo;
+                    if (ks + S > kBins + 3) ks = (kBins + 3) - S;                       // never read past the row's three zero bins
+                    if (ks < 0) ks = 0;
+                    const int owner = pi == 0, add1 = (pi % 2 == 0 && pi + 1 < pcs[i]), add2 = (pi == 0 && pcs[i] > 2);
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const int lane = 4 * blk + i4;
+                        lane4[g * 64 + lane] = ks | (b.q << 10) | (owner << 17) | (add1 << 18) | (add2 << 19) | (i4 << 20);
+                        for (int t = 0; t < S; ++t) {
+                            const int bin = ks + t;
+                            const float w = (bin >= lo && bin < hi && bin < kBins) ? W[(size_t)(4 * b.q + i4) * kBins + bin] : 0.0f;
+                            wfrag4[(((size_t)g * v2::kM4Quads + t / 4) * 64 + lane) * 4 + t % 4] = w;
+                        }
+                    }
+                }
+                used[row[i]] += pcs[i];
+                pl.n_pieces[g] += pcs[i];
+            }
+        }
+        if (!S) return pl;
+        pl.quads[g] = S / 4;
+    }
+    pl.ok = true;
+    return pl;
+}
+
 size_t bytes_per_frame(const af_features_config& c)
 {
     return (size_t)c.channels * (c.sample_format == AF_PCM_I16 ? 2 : 4);
@@ -456,6 +548,20 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     const auto hann = [frame_len](int i) {
         return i < frame_len ? 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)frame_len) : 0.0;
     };
+    // the same kernel with its mel phase on 4 x 4 x 1 blocks (a third of the matrix work; features.hpp Plan4)
+    if (p->plan8.n_waves == v2::kW && cfg->output == AF_OUT_MEL) {
+        std::vector<float> wfrag4;
+        std::vector<int> lane4;
+        p->plan4 = build_plan4(p->W, (int)cfg->n_mels, wfrag4, lane4);
+        if (p->plan4.ok) {
+            const size_t o_l = wfrag4.size() * sizeof(float);
+            st = p->d_mel4.reserve(o_l + lane4.size() * sizeof(int));
+            if (st == AF_OK && (hipMemcpy(p->d_mel4.p, wfrag4.data(), o_l, hipMemcpyHostToDevice) != hipSuccess ||
+                                hipMemcpy(p->d_mel4.as<char>() + o_l, lane4.data(), lane4.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
+                st = fail(AF_ERR_HIP, "uploading the 4 x 4 x 1 mel plan failed");
+            if (st != AF_OK) { delete p; return st; }
+        }
+    }
     p->win1024.resize(kNfft);
     for (int i = 0; i < kNfft; ++i) p->win1024[i] = hann(i);
     // constant block: wintab [32][kWinRow] | twtab [32][kTwRow] | wfrag | meta
@@ -802,6 +908,12 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         q.out_power = prm.out_power;
         q.log_mel = prm.log_mel;
         q.stamps = prm.stamps;
+        if (p->plan4.ok && p->opt_mel4 != 0 && !prm.out_power) {   // (the per-phase stamps build has no 4 x 4 x 1 instance: launch_fmt)
+            q.wfrag4 = p->d_mel4.as<float>();
+            q.lane4 = reinterpret_cast<const int*>(p->d_mel4.as<char>() + (size_t)2 * v2::kM4Quads * 64 * 4 * sizeof(float));
+            q.m4_quads[0] = p->plan4.quads[0];
+            q.m4_quads[1] = p->plan4.quads[1];
+        }
         int64_t grid2 = (int64_t)p->n_cus * 2;
         if (wg_knob == 1) grid2 = (int64_t)p->n_cus;
         if (grid2 > u_count) grid2 = u_count;
@@ -995,6 +1107,7 @@ af_status af_features_set_option(af_features* p, const char* key, int value)
         p->opt_kernel = value < 0 ? -1 : value;
     }
     else if (std::strcmp(key, "wg_per_cu") == 0) p->opt_wg_per_cu = value < 0 ? -1 : value;
+    else if (std::strcmp(key, "mel4") == 0) p->opt_mel4 = value < 0 ? -1 : (value != 0);    // 0: the 16 x 16 x 4 mel plan (diagnostics)
     else return fail(AF_ERR_INVALID_ARG, "af_features_set_option: unknown option '%s'", key);
     return AF_OK;
 }

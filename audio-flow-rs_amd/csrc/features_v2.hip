@@ -42,7 +42,7 @@
 // phase table of profiles/r05_v2_ablations.txt.  Results are garbage; every guard that bounds a global access stays in.
 //   1 arithmetic of FFT part 1 (window, radix-16, first twiddle)   2 arithmetic of FFT part 2 (radix-16, T2, radix-4, split)
 //   4 mel MFMAs   8 workgroup barriers   16 global stores   32 PCM prefetch loads   64 filterbank fragment loads
-//   128 the whole mel block (operand reads, MFMAs, stores)
+//   128 the whole mel block (operand reads, MFMAs, stores)   256 every mel MFMA replaced by a v_mfma_f32_4x4x1_16b_f32 (a quarter of the MACs)
 #ifndef AF_V2_PH
 #define AF_V2_PH 0
 #endif
@@ -67,6 +67,14 @@
 // phase and the whole of unit u + 1) instead of at the top of unit u + 1; 0: round 2-4's placement
 #ifndef AF_V2_PF_AHEAD
 #define AF_V2_PF_AHEAD 0
+#endif
+// 1: the split's partner-lane addresses start from lane_now() (0: from the hoisted lane number; experiment)
+#ifndef AF_V2_LANE_NOW
+#define AF_V2_LANE_NOW 1
+#endif
+// (ablation, MEL4 instances) 1: no mel MFMAs, 2: no mel stores, 4: no piece combine
+#ifndef AF_V2_M4
+#define AF_V2_M4 0
 #endif
 // issue priority of the kernel's waves outside their raised sections (experiment: 1 when it shares CUs with another kernel)
 #ifndef AF_V2_BASE_PRIO
@@ -183,6 +191,16 @@ __device__ __forceinline__ int opaque_tid(int tid)
     int z;
     asm volatile("v_mov_b32 %0, 0" : "=v"(z));
     return tid + z;
+}
+
+// The lane number, recomputed where it is asked for (two VALU instructions, no memory): lane-derived addresses built
+// from it cannot be hoisted out of the unit loop, where they would sit in registers -- or in scratch, whose reload
+// in the middle of the FFT waits for the PCM prefetch requested before it (vector memory returns in order).
+__device__ __forceinline__ int lane_now()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
+    return l;
 }
 
 // MS consecutive samples (idx a multiple of MS = 2, 4 or 8: they stay inside one 32-sample block)
@@ -416,8 +434,9 @@ __device__ __forceinline__ void fft_pair_2(float* wb, const WaveBuf& wv, int lan
         addtid_store1<576 * 4 + 8 * 256>(wv, ZI(0));
         }
         lds_order();
-        const int pl = (64 - lane) & 63;
-        const int d = lane == 0 ? 1 : 0;
+        const int ln = AF_V2_LANE_NOW ? lane_now() : lane;
+        const int pl = (64 - ln) & 63;
+        const int d = ln == 0 ? 1 : 0;
         const float* ex = wb + pl + 64 * d;
         float pa[9], pb[9];
 #pragma unroll
@@ -497,7 +516,10 @@ __device__ __forceinline__ UnitDesc load_desc(const UnitDesc* units, unsigned u)
 // fragment loads sat in one `if (!out_power)` and the MFMAs that consume them in another; hipcc's wait-count
 // pass joins the paths, kept the six fragment loads "pending" around the loop, and made the next unit's first
 // LDS reads -- which reuse their registers -- wait for vmcnt(5..0): for the PCM prefetch requested just before.
-template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS, bool POWER>
+// MEL4 (round 5): the mel phase on 16 blocks of 4 x 4 x 1 (v_mfma_f32_4x4x1_16b_f32; features.hpp Plan4) instead of
+// 16 x 16 x 4 tiles: a third of the multiply-adds for the banded filterbank, and the launch is power-limited
+// (DESIGN.md section 9, round 5).  NSLOT then counts 16-byte operand quads (4 steps each) per wave.
+template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS, bool POWER, bool MEL4 = false>
 __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
 {
     using St = Stage<CH, I16>;
@@ -543,6 +565,9 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     const float* pbase = wbufs + ((lane & 15) >> 1) * kWb + (lane & 1) * kProw2 + (kBinMajor ? 4 : 1) * (lane >> 4);
     const unsigned row_off = (unsigned)(lane & 15) * (unsigned)n_mels + 4u * (unsigned)(lane >> 4);
 
+    // MEL4: this lane's block slot (first bin of its piece, filter quad, combine flags) and the group's step count
+    // (the lane word is fetched with the fragments in every unit: a register, or a scratch slot, less across the FFT)
+    const int m4q = MEL4 ? p.m4_quads[w >> 2] : 0;                    // wave-uniform
     // this lane's stage-2 twiddles, in registers for the whole launch
     float ltw[kLaneTw];
     {
@@ -598,7 +623,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             if (wanted && LO < HI) {
                 // (lane offsets from an opaque copy of tid: hoisted out of the unit loop they end up in scratch,
                 // and a scratch reload waits for every outstanding vector memory operation)
-                const int t0 = opaque_tid(tid);
+                const int t0 = (w << 6) + lane_now();
                 if (d.n_avail >= kTile + 16 * kHop) {  // wave-uniform: the new region lies inside the clip
                     const char* src = static_cast<const char*>(p.pcm) +
                                       (d.pcm0 + kTile) * St::kBytesPerFrame;
@@ -625,6 +650,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         issue_prefetch(ud, has_next && !pf_ready, std::integral_constant<int, 0>{}, std::integral_constant<int, kPfEarly>{});
 
         float wf[NSLOT * kSlotSteps];
+        int l4 = 0;
         {
             float ur[16], ui[16];
             // The issue arbiter prefers the older wave: waves 4..7 of a workgroup share their SIMDs with waves
@@ -643,12 +669,23 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             if constexpr (!POWER && (AF_V2_PH & (64 | 128))) {
 #pragma unroll
                 for (int q = 0; q < NSLOT * kSlotSteps; ++q) wf[q] = abl_val(lane, q);
+            } else if constexpr (MEL4) {
+                int opaque_zero;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+                const float4* wbase = reinterpret_cast<const float4*>(p.wfrag4) + (size_t)(w >> 2) * kM4Quads * 64;
+                const unsigned wo = (unsigned)lane_now() + (unsigned)opaque_zero;
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) {
+                    const float4 v = wbase[wo + q * 64];
+                    wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+                }
+                l4 = (p.lane4 + (w >> 2) * 64)[wo];
             } else if constexpr (!POWER) {
                 int opaque_zero;                     // pins the loads here (and defeats hoisting)
                 asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
                 // (scalar base + 32-bit lane offset: a hoisted 64-bit lane pointer is one more loop-carried register pair)
                 const float4* wbase = reinterpret_cast<const float4*>(p.wfrag) + (size_t)w * kMaxSlotsW * 64;
-                const unsigned wo = (unsigned)(lane + opaque_zero);
+                const unsigned wo = (unsigned)lane_now() + (unsigned)opaque_zero;
 #pragma unroll
                 for (int q = 0; q < NSLOT; ++q) {
                     const float4 v = wbase[wo + q * 64];
@@ -678,7 +715,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             // The next tile is this one shifted by 16 hops: the last kTail samples move to the front,
             // the new samples follow.  A staging unit that lands on part of the old tail is handled by
             // one thread: read the old samples, store the new ones there, store the old ones at the front.
-            const int t0 = opaque_tid(tid);
+            const int t0 = (w << 6) + lane_now();
 #pragma unroll
             for (int i = 0; i < PFU; ++i) {
                 const int v = t0 + i * kT;
@@ -712,6 +749,72 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
 
         if constexpr (!POWER && (AF_V2_PH & 128)) {
             abl_use(wf[0]);
+        } else if constexpr (MEL4) {
+            // mel on 4 x 4 x 1 blocks: lane (block b, j) supplies frame 4 (w & 3) + j of the piece's bins (B) and filter
+            // 4 q + j of them (A, registers); the accumulator of block b is its piece's 4 filters x 4 frames.  Operands in two
+            // halves of at most 16 steps (the whole set would be 32 more live registers next to the fragments).
+            // (everything derived from the lane word starts from an opaque copy: hoisted out of the unit loop the row
+            // pointer, the frame number and the output offset end up in scratch, reloaded here in every unit)
+            const int l4o = l4;
+            const int fr = 4 * (w & 3) + ((l4o >> 20) & 3);
+            const float4* prow = reinterpret_cast<const float4*>(wbufs + (fr >> 1) * kWb + (fr & 1) * kProw2 + (l4o & 1023));
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hh = 0; hh < NSLOT; hh += 4) {
+                float4 bq[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bq[k] = hh + k < NSLOT ? prow[hh + k] : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (hh + k < NSLOT && hh + k < m4q) {                 // wave-uniform
+                        const int st = 4 * (hh + k);
+                        if constexpr (AF_V2_M4 & 1) {
+                            abl_use(wf[st]); abl_use(wf[st + 1]); abl_use(wf[st + 2]); abl_use(wf[st + 3]);
+                            abl_use(bq[k].x); abl_use(bq[k].y); abl_use(bq[k].z); abl_use(bq[k].w);
+                            continue;
+                        }
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[st], bq[k].x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[st + 1], bq[k].y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[st + 2], bq[k].z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[st + 3], bq[k].w, acc1, 0, 0, 0);
+                    }
+                }
+            }
+            f32x4 r = acc0 + acc1;
+            // the pieces of a band lie side by side in one row of four blocks: piece 0 += piece 1 and piece 2 += piece 3
+            // (row_shl:4 = the value of the lane four to the right), then piece 0 += piece 2 (row_shl:8)
+            const bool add1 = (l4o >> 18) & 1, add2 = (l4o >> 19) & 1;
+            if constexpr (!(AF_V2_M4 & 4)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // (a copy first: __builtin_bit_cast of the vector ELEMENT r[i] reads element 0 with this compiler)
+                const float ri = r[i];
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ri), 0x104, 0xF, 0xF, true));
+                r[i] = add1 ? ri + v : ri;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ri = r[i];
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ri), 0x108, 0xF, 0xF, true));
+                r[i] = add2 ? ri + v : ri;
+            }
+            }
+            if (p.log_mel) {                                            // wave-uniform: log10(max(mel, 1e-10))
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = __log10f(fmaxf(r[i], 1e-10f));
+            }
+            if (((l4o >> 17) & 1) && fr < ud.n_rows) {                  // the band's first piece holds its sums
+                // uniform base + 32-bit lane offset
+                float* o = p.out + ud.out0 * n_mels + (unsigned)(fr * n_mels + 4 * ((l4o >> 10) & 127));
+                if constexpr (AF_V2_M4 & 2) {
+                    abl_use(r[0]); abl_use(r[1]); abl_use(r[2]); abl_use(r[3]);
+                } else
+                if (vec_ok) {
+                    *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
+                } else {
+                    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+                }
+            }
         } else if constexpr (!POWER) {
             // mel: banded W (A, registers) x P^T (B, bins x 16 frames from the power rows) on
             // v_mfma_f32_16x16x4_f32; all B operands first, then the chain; a slot that ends a group
@@ -753,6 +856,11 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
                         if constexpr (AF_V2_PH & 4) {
                             acc0[st & 3] += wf[st] + bop[st];
                             acc1[st & 3] += wf[st + 1] + bop[st + 1];
+                            continue;
+                        }
+                        if constexpr (AF_V2_PH & 256) {      // proxy: a quarter of the matrix work per step (16 blocks of 4 x 4 x 1)
+                            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[st], bop[st], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[st + 1], bop[st + 1], acc1, 0, 0, 0);
                             continue;
                         }
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st], bop[st], acc0, 0, 0, 0);
@@ -838,12 +946,36 @@ static af_status launch_k(const Params& p, int grid, hipStream_t stream)
     return launch_kp<CH, I16, SEP, NSLOT, STAMPS, false>(p, grid, stream);
 }
 
+// the mel phase on 4 x 4 x 1 blocks: instances by operand quads per wave (7 or 8 = 28 / 32 steps)
+template <int CH, bool I16, bool SEP>
+static af_status launch_m4(const Params& p, int grid, hipStream_t stream)
+{
+    const int most = p.m4_quads[0] > p.m4_quads[1] ? p.m4_quads[0] : p.m4_quads[1];
+    auto go = [&](auto kern) -> af_status {
+        constexpr size_t smem = sizeof(float) * kLdsFloats;
+        static LdsAttrFlags attr_set;
+        AF_HIP(allow_big_lds(kern, (int)smem, attr_set));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kT), smem, stream, p);
+        AF_HIP(hipGetLastError());
+        return AF_OK;
+    };
+    if (most <= 6) return go(af_features_v2_kernel<CH, I16, SEP, 6, false, false, true>);
+    if (most <= 7) return go(af_features_v2_kernel<CH, I16, SEP, 7, false, false, true>);
+    return go(af_features_v2_kernel<CH, I16, SEP, 8, false, false, true>);
+}
+
 template <int CH, bool I16>
 static af_status launch_fmt(const Params& p, bool separate, int grid, hipStream_t stream)
 {
     int most = 0;
     for (int w = 0; w < kW; ++w) most = p.plan.wave_nslots[w] > most ? p.plan.wave_nslots[w] : most;
     if (most > 8) return fail(AF_ERR_UNSUPPORTED, "features v2: %d mel slots on one wave (limit 8)", most);
+    if (p.wfrag4 && !p.out_power && (!p.stamps || AF_V2_CLK)) {
+        if constexpr (CH == 2) {
+            if (separate) return launch_m4<CH, I16, true>(p, grid, stream);
+        }
+        return launch_m4<CH, I16, false>(p, grid, stream);
+    }
     if constexpr (CH == 2) {
         if (separate) return launch_k<CH, I16, true, 8>(p, grid, stream);
     }

@@ -311,7 +311,10 @@ af_status af_features_set_batch_spans(af_features* p, const int64_t* starts,
                                       size_t* total_frames_out);
 /* per-handle diagnostics (unlike af_debug_set they touch no other handle); value -1: follow af_debug_set
  *   "kernel"     1: the general fused kernel also where the hop-256 kernel applies
- *   "wg_per_cu"  workgroups per CU of the fused kernels */
+ *   "wg_per_cu"  workgroups per CU of the fused kernels
+ *   "mel4"       0: the hop-256 kernel's mel phase on 16 x 16 x 4 matrix tiles also where the plan on 16 blocks of
+ *                4 x 4 x 1 fits (n_mels a multiple of 4, <= 16 pieces per half of the bands); same rows within the
+ *                float32 summation order */
 af_status af_features_set_option(af_features* p, const char* key, int value);
 /* enqueue the fused kernel on `stream` for the batch set above */
 af_status af_features_run_device(af_features* p, const void* pcm_dev, float* mel_dev,
@@ -427,7 +430,7 @@ af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, 
 af_status af_chain_run(af_chain* c, const void* pcm, size_t pcm_len, float* mel, size_t mel_cap);
 /* per-handle diagnostics (unlike af_debug_set they touch no other handle):
  *   "unfused"  1: resampler and FIR as separate launches; 0: fused where covered; -1: follow af_debug_set
- *   "kernel", "wg_per_cu": handed to the chain's STFT / mel stage (af_features_set_option); without them that stage
+ *   "kernel", "wg_per_cu", "mel4": handed to the chain's STFT / mel stage (af_features_set_option); without them that stage
  *              follows af_debug_set("features.kernel") like any feature handle
  *   "pipeline" k > 0: equal-length batches run the two launches of the fused form side by side on two internal
  *              streams, in k chunks of clips (same rows; measured slower than one after the other on MI355X,

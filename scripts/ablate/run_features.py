@@ -13,6 +13,7 @@ ap.add_argument("--reps", type=int, default=20); ap.add_argument("--warm", type=
 ap.add_argument("--clips", type=int, default=256); ap.add_argument("libs", nargs="+")
 ap.add_argument("--clk", action="store_true", help="AF_V2_CLK builds: also print the in-kernel clock (s_memtime / s_memrealtime)")
 ap.add_argument("--kernel", type=int, default=-1, help="af_features_set_option kernel (1 general, 2 features_v2, 3 features_v3)")
+ap.add_argument("--mel4", type=int, default=-1, help="af_features_set_option mel4 (0: the 16 x 16 x 4 mel plan)")
 a = ap.parse_args()
 n = 1440000
 dev = torch.device("cuda:0")
@@ -28,6 +29,7 @@ for path in a.libs:
     cfg = ffi.FeaturesConfig(); lib.af_features_default_config(C.byref(cfg))
     h = C.c_void_p(); assert lib.af_features_create(C.byref(cfg), C.byref(h)) == 0
     if a.kernel >= 0: assert lib.af_features_set_option(h, b"kernel", a.kernel) == 0
+    if a.mel4 >= 0: assert lib.af_features_set_option(h, b"mel4", a.mel4) == 0
     tot = C.c_size_t(); assert lib.af_features_set_batch_uniform(h, a.clips, n, C.byref(tot)) == 0
     mel = torch.empty(tot.value, 80, device=dev)
     for _ in range(a.warm): assert lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), s) == 0

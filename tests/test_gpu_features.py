@@ -344,3 +344,45 @@ def test_hop256_kernel_on_clips_off_16_byte_boundaries(af, po, ch, fmt):
         if not (ch == 1 and fmt == 1):
             assert bits_equal(alone.run(x), got[row:row + nf])
         row += nf
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_mels=64, sample_rate=16000), dict(mel_scale=1, mel_norm=1), dict(n_fft=512),
+                                dict(sample_format=1), dict(channel_mode=1), dict(log_mel=True),
+                                dict(n_mels=40), dict(n_mels=128, sample_rate=44100), dict(n_mels=23, sample_rate=8000)],
+                         ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()) or "default")
+def test_hop256_mel_plans_agree(af, po, kw):
+    """The hop-256 kernel has two mel phases: 16 blocks of 4 x 4 x 1 (the default where the plan fits: n_mels a multiple
+    of 4 and <= 16 pieces per half of the bands) and 16 x 16 x 4 tiles (`af_features_set_option(h, "mel4", 0)`, and every
+    other filterbank).  Same rows within float32 summation order, both inside the oracle tolerance; ragged clips (one
+    ends 8 samples short of a unit, one is a single frame, one is shorter than n_fft)."""
+    lib = af.library()
+    sr, ch = kw.get("sample_rate", 48000), 2
+    lens = [20000, 1024 + 256 * 16 - 8, 1024, 900, 50000]
+    clips = [synth_clip(300 + i, n, ch, sr) for i, n in enumerate(lens)]
+    if kw.get("sample_format"):
+        clips = [np.round(c * 32767.0).astype(np.int16) for c in clips]
+    x = np.concatenate([c.reshape(-1) for c in clips])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    out = []
+    for m4 in (-1, 0):
+        p = af.FeaturePipeline(channels=ch, **kw)
+        assert lib.af_features_set_option(p._h, b"mel4", m4) == 0
+        p.set_batch(off)
+        out.append(p.run(x))
+    assert np.isfinite(out[0]).all() and out[0].shape == out[1].shape
+    if kw.get("log_mel"):
+        assert float(np.abs(out[0] - out[1]).max()) < 2e-5          # log10 of sums that differ in the last bits
+        return
+    assert frame_rel_err(out[0], np.asarray(out[1], np.float64)) < 2e-6
+    if kw.get("channel_mode"):
+        return
+    W = po.mel_weights(float(sr), kw.get("n_fft", 1024), kw.get("n_mels", 80), scale=kw.get("mel_scale", 0), norm=kw.get("mel_norm", 0))
+    row = 0
+    for c, n in zip(clips, lens):
+        cf = c.astype(np.float32) / np.float32(32768.0) if kw.get("sample_format") else c
+        ref = po.mel_apply(po.stft_power(po.to_mono(cf, ch), kw.get("n_fft", 1024), 256), W)
+        if ref.shape[0]:
+            for o in out:
+                assert frame_rel_err(o[row:row + ref.shape[0]], ref) < TOL
+        row += ref.shape[0]
+    assert row == out[0].shape[0]
