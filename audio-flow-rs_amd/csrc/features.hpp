@@ -122,6 +122,33 @@ struct Plan4 {
 af_status launch(const Params& p, int channels, bool i16, bool separate, int grid, hipStream_t stream);
 }  // namespace v2
 
+// ---- any other frame length (features_dft.hip, round 5) ------------------------------------------
+// n_fft outside {1024, 512, 256} (400 = 25 ms at 16 kHz, the usual speech frame; websocket.rs:274 names the 16 kHz
+// format) has no power-of-two factorisation to hand to the register FFT.  The frame's DFT is taken as what it is, a
+// matrix product, on v_mfma_f32_16x16x4_f32: D[bin][frame] = sum_k T[k][bin] x[frame * hop + k], T = window x
+// (cos | -sin), 16 frames x 16 bins per tile, f32 throughout.  The accumulator layout (rows = bins 4 kq + i, column =
+// frame) is the B-operand layout of the mel product that follows (mel^T[filter][frame] += W[filter][bin] P[bin][frame]),
+// so the power values never leave their registers.  One wave = one 16-frame unit (the unit records of the hop-256
+// kernel, with the handle's hop), a signal tile of 15 hop + K samples in wave-private LDS; the waves of a workgroup
+// walk the fragment stream together (one barrier per bin tile) so that it is read from L2 once per workgroup.
+namespace dft {
+constexpr int kMaxMelTiles = 8;           // n_mels <= 128
+struct Params {
+    const void* pcm;
+    float* out;               // mel rows [total_frames][n_mels] or power rows [total_frames][n_fft / 2 + 1]
+    const float* tfrag;       // [bin tile][k group][re, im][64 lanes][4]: T[16 g + 4 kq + j][16 bt + (lane & 15)]
+    const float* wfrag;       // [bin tile][mel tile][64 lanes][4]: W[16 mt + (lane & 15)][16 bt + 4 kq + i]
+    const uint32_t* wmask;    // [bin tile]: bit mt set = that tile of W has a non-zero weight
+    const v2::UnitDesc* units;
+    int64_t total_units;
+    int hop, kg, nb, n_bins, n_mels, nmt;   // kg = K groups of 16 samples, nb = bin tiles of 16
+    int tile_stride;          // floats of LDS per wave (>= 15 hop + 16 kg, a multiple of 8)
+    int out_power, log_mel;
+};
+// `waves` 64-lane waves per workgroup (1, 2 or 4: what the LDS holds), `grid` workgroups
+af_status launch(const Params& p, int channels, bool i16, bool separate, int waves, int grid, hipStream_t stream);
+}  // namespace dft
+
 // ---- hop-256 kernel, DFT on the matrix cores (features_v3.hip) ---------------------------------
 // The 1024-point transform of 16 frames at once as two stages of 32-point DFTs written as matrix products
 // (n = 32 n1 + n2, k = k1 + 32 k2): stage 1 contracts n1 with a per-n2 matrix that carries the Hann window AND the

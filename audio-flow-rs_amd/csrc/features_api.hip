@@ -77,6 +77,11 @@ struct af_features {
     DevBuf d_pcm, d_mel;
     DevBuf d_stamps;                 // diagnostics: per-phase cycle sums (af_features_debug_stamps)
     int opt_kernel = -1, opt_wg_per_cu = -1;   // af_features_set_option; -1: the process-wide af_debug_set switch
+    // n_fft outside {1024, 512, 256}: the DFT as a matrix product (features_dft.hip); none of the FFT kernels' tables exist
+    bool dft = false;
+    DevBuf d_dft;                    // tfrag | wfrag | wmask
+    size_t dft_off_w = 0, dft_off_mask = 0;
+    int dft_kg = 0, dft_nb = 0, dft_nmt = 0, dft_tile_stride = 0, dft_waves = 0;
 };
 
 namespace {
@@ -352,6 +357,84 @@ v2::Plan4 build_plan4(const std::vector<float>& W, int n_mels, std::vector<float
     return pl;
 }
 
+// Tables of the matrix-product DFT (features.hpp, namespace dft) for a frame length the FFT kernels do not factor.
+af_status upload_bank_of(const std::vector<float>& w, int n_mels, int row_len, DevBuf& d_w, DevBuf& d_b);
+af_status build_dft(af_features* p)
+{
+    const af_features_config& c = p->cfg;
+    const int n_fft = (int)c.n_fft, n_bins = n_fft / 2 + 1, nm = (int)c.n_mels;
+    const int kg = (n_fft + 15) / 16, nb = (n_bins + 15) / 16, nmt = (nm + 15) / 16;
+    p->W.clear();                                       // (the 513-bin grid means nothing here)
+    p->dft = true;
+    p->dft_kg = kg; p->dft_nb = nb; p->dft_nmt = nmt;
+    const int tile_len = 15 * (int)c.hop + 16 * kg;
+    p->dft_tile_stride = (tile_len + 7) & ~7;
+    // waves per workgroup: what 64 KB of LDS hold (three workgroups of four waves per CU at hop 160 / n_fft 400)
+    const size_t per_wave = (size_t)p->dft_tile_stride * sizeof(float);
+    p->dft_waves = per_wave * 4 <= 64 * 1024 ? 4 : per_wave * 2 <= 80 * 1024 ? 2 : 1;
+    if (per_wave > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "features: hop %u with n_fft %u needs %zu bytes of LDS per wave", c.hop, c.n_fft, per_wave);
+    // window x (cos | -sin), the angle reduced in integers first
+    std::vector<double> win(n_fft), cs(n_fft), sn(n_fft);
+    for (int i = 0; i < n_fft; ++i) {
+        win[i] = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)n_fft);
+        cs[i] = std::cos(2.0 * kPi * (double)i / (double)n_fft);
+        sn[i] = std::sin(2.0 * kPi * (double)i / (double)n_fft);
+    }
+    std::vector<float> tfrag((size_t)nb * kg * 2 * 64 * 4, 0.0f);
+    for (int bt = 0; bt < nb; ++bt)
+        for (int g = 0; g < kg; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 16 * g + 4 * (lane >> 4) + j, bin = 16 * bt + (lane & 15);
+                    if (k >= n_fft || bin >= n_bins) continue;
+                    const int r = (int)(((int64_t)k * bin) % n_fft);
+                    const size_t o = ((((size_t)bt * kg + g) * 2) * 64 + lane) * 4 + j;
+                    tfrag[o] = (float)(win[k] * cs[r]);
+                    tfrag[o + 64 * 4] = (float)(-win[k] * sn[r]);
+                }
+    std::vector<float> wfrag((size_t)nb * nmt * 64 * 4, 0.0f);
+    std::vector<uint32_t> wmask(nb, 0u);
+    for (int bt = 0; bt < nb; ++bt)
+        for (int mt = 0; mt < nmt; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                    const int m = 16 * mt + (lane & 15), bin = 16 * bt + 4 * (lane >> 4) + i;
+                    if (m >= nm || bin >= n_bins) continue;
+                    const float v = p->Wn[(size_t)m * n_bins + bin];
+                    wfrag[(((size_t)bt * nmt + mt) * 64 + lane) * 4 + i] = v;
+                    if (v != 0.0f) wmask[bt] |= 1u << mt;
+                }
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    p->dft_off_w = up16(tfrag.size() * sizeof(float));
+    p->dft_off_mask = up16(p->dft_off_w + wfrag.size() * sizeof(float));
+    AF_TRY(p->d_dft.reserve(p->dft_off_mask + wmask.size() * sizeof(uint32_t)));
+    char* b = p->d_dft.as<char>();
+    if (hipMemcpy(b, tfrag.data(), tfrag.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b + p->dft_off_w, wfrag.data(), wfrag.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b + p->dft_off_mask, wmask.data(), wmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(AF_ERR_HIP, "uploading the DFT tables failed");
+    // the filterbank on its own grid for af_mel_apply
+    return upload_bank_of(p->Wn, nm, n_bins, p->d_Wn, p->d_bandn);
+}
+
+af_status upload_bank_of(const std::vector<float>& w, int n_mels, int row_len, DevBuf& d_w, DevBuf& d_b)
+{
+    std::vector<int> band(2 * (size_t)n_mels, 0);
+    for (int m = 0; m < n_mels; ++m) {
+        int lo = row_len, hi = 0;
+        for (int k = 0; k < row_len; ++k)
+            if (w[(size_t)m * row_len + k] != 0.0f) { lo = std::min(lo, k); hi = k + 1; }
+        band[2 * m] = lo < hi ? lo : 0;
+        band[2 * m + 1] = lo < hi ? hi : 0;
+    }
+    AF_TRY(d_w.reserve(w.size() * sizeof(float)));
+    AF_TRY(d_b.reserve(band.size() * sizeof(int)));
+    if (hipMemcpy(d_w.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_b.p, band.data(), band.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(AF_ERR_HIP, "uploading the filterbank failed");
+    return AF_OK;
+}
+
 size_t bytes_per_frame(const af_features_config& c)
 {
     return (size_t)c.channels * (c.sample_format == AF_PCM_I16 ? 2 : 4);
@@ -428,12 +511,15 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     AF_HIP(hipMemcpy(p->d_tables.p, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     // hop-256 kernel: one 32-byte record per 16-frame unit
     p->units_ok = false;
-    if ((p->dense_mel && p->cfg.output != AF_OUT_POWER) || (p->cfg.output == AF_OUT_POWER && p->cfg.n_fft != (uint32_t)kNfft))
+    if (!p->dft && ((p->dense_mel && p->cfg.output != AF_OUT_POWER) || (p->cfg.output == AF_OUT_POWER && p->cfg.n_fft != (uint32_t)kNfft)))
         AF_TRY(p->d_power.reserve(((size_t)p->total_frames * kBins + 16) * sizeof(float)));
     // (dense_mel: the hop-256 kernel only writes power rows, which needs no filterbank plan)
-    const bool v2_ok = p->plan8.n_waves == v2::kW || (p->dense_mel && p->cfg.hop == (uint32_t)v2::kHop);
-    const bool v3_possible = p->cfg.hop == (uint32_t)v2::kHop && !p->dense_mel && p->cfg.output == AF_OUT_MEL;   // built on request
-    if ((v2_ok || v3_possible) && aligned4 && p->total_units > 0 && p->total_units < (1ll << 26)) {
+    const bool v2_ok = !p->dft && (p->plan8.n_waves == v2::kW || (p->dense_mel && p->cfg.hop == (uint32_t)v2::kHop));
+    const bool v3_possible = !p->dft && p->cfg.hop == (uint32_t)v2::kHop && !p->dense_mel && p->cfg.output == AF_OUT_MEL;   // built on request
+    // (the matrix-product DFT kernel walks the same records with the handle's own hop and takes any alignment)
+    const int64_t unit_hop = p->dft ? (int64_t)p->cfg.hop : (int64_t)v2::kHop;
+    if (p->dft && p->total_units >= (1ll << 31)) return fail(AF_ERR_UNSUPPORTED, "features: more than 2^31 units in one batch");
+    if (((v2_ok || v3_possible) && aligned4 || p->dft) && p->total_units > 0 && (p->dft || p->total_units < (1ll << 26))) {
         std::vector<v2::UnitDesc> units((size_t)p->total_units + 4);   // + zero records: the kernels read a unit ahead
         const bool sep = p->cfg.channel_mode == AF_CH_SEPARATE;
         size_t k = 0;
@@ -442,7 +528,7 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
             const int64_t nu = unit_off[c + 1] - unit_off[c];
             for (int64_t i = 0; i < nu; ++i, ++k) {
                 v2::UnitDesc& d = units[k];
-                const int64_t first = i * kFramesPerIter * (int64_t)v2::kHop;
+                const int64_t first = i * kFramesPerIter * unit_hop;
                 d.pcm0 = t_start[c] + first;
                 d.out0 = out_off[c] + i * kFramesPerIter;
                 const int64_t left = t_len[c] - first;
@@ -486,8 +572,8 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
 {
     AF_REQUIRE(cfg && out, "af_features_create: null argument");
     *out = nullptr;
-    AF_REQUIRE(cfg->n_fft == 1024u || cfg->n_fft == 512u || cfg->n_fft == 256u, "n_fft must be 1024, 512 or 256 (got %u)",
-               cfg->n_fft);
+    AF_REQUIRE(cfg->n_fft >= 32u && cfg->n_fft <= 1024u, "n_fft must be in [32, 1024] (got %u)", cfg->n_fft);
+    const bool dft = !(cfg->n_fft == 1024u || cfg->n_fft == 512u || cfg->n_fft == 256u);
     AF_REQUIRE(cfg->channels >= 1 && cfg->channels <= 16, "channels must be in [1, 16] (got %u)", cfg->channels);
     if (cfg->channels > 2 && cfg->sample_format != AF_PCM_F32)
         return fail(AF_ERR_UNSUPPORTED, "more than two channels are supported for f32 PCM only");
@@ -514,6 +600,12 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     p->n_cus = device_cu_count(p->device);
 
     build_mel(*cfg, f_max, p->W, p->Wn);
+    if (dft) {
+        const af_status ds = build_dft(p);
+        if (ds != AF_OK) { delete p; return ds; }
+        *out = p;
+        return AF_OK;
+    }
     std::vector<float> wfrag;
     std::vector<int> meta;
     af_status st = build_plan(p->W, (int)cfg->n_mels, kWaves, kMaxSlotsW, 4, p->plan, wfrag, meta);
@@ -644,20 +736,7 @@ af_status af_features_create(const af_features_config* cfg, af_features** out)
     p->d_wfrag8 = reinterpret_cast<const float*>(base + off_wf8);
     p->d_meta8 = reinterpret_cast<const int*>(base + off_meta8);
     const auto upload_bank = [&](const std::vector<float>& w, int row_len, DevBuf& d_w, DevBuf& d_b) -> af_status {
-        std::vector<int> band(2 * cfg->n_mels, 0);
-        for (uint32_t m = 0; m < cfg->n_mels; ++m) {
-            int lo = row_len, hi = 0;
-            for (int k = 0; k < row_len; ++k)
-                if (w[(size_t)m * row_len + k] != 0.0f) { lo = std::min(lo, k); hi = k + 1; }
-            band[2 * m] = lo < hi ? lo : 0;
-            band[2 * m + 1] = lo < hi ? hi : 0;
-        }
-        AF_TRY(d_w.reserve(w.size() * sizeof(float)));
-        AF_TRY(d_b.reserve(band.size() * sizeof(int)));
-        if (hipMemcpy(d_w.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_b.p, band.data(), band.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
-            return fail(AF_ERR_HIP, "uploading the filterbank failed");
-        return AF_OK;
+        return upload_bank_of(w, (int)cfg->n_mels, row_len, d_w, d_b);
     };
     // (the matrix-core DFT kernel's tables are built when a handle asks for it: af_features_set_option(h, "kernel", 3))
     if (p->dense_mel) st = upload_bank(p->W, kBins, p->d_W, p->d_band);
@@ -802,6 +881,35 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         AF_TRY(af_to_mono_device(static_cast<const float*>(pcm_dev) + (size_t)f_begin * ch, (size_t)(f_end - f_begin) * ch,
                                  (uint16_t)ch, p->d_mono.as<float>() + f_begin, stream));
         pcm_dev = p->d_mono.p;
+    }
+    if (p->dft) {
+        AF_REQUIRE(p->units_ok, "features: the batch has no unit table");
+        dft::Params q{};
+        q.pcm = pcm_dev;
+        q.out = mel_dev;
+        q.tfrag = p->d_dft.as<float>();
+        q.wfrag = reinterpret_cast<const float*>(p->d_dft.as<char>() + p->dft_off_w);
+        q.wmask = reinterpret_cast<const uint32_t*>(p->d_dft.as<char>() + p->dft_off_mask);
+        q.units = p->d_units.as<v2::UnitDesc>() + u_begin;
+        q.total_units = u_count;
+        q.hop = (int)p->cfg.hop;
+        q.kg = p->dft_kg;
+        q.nb = p->dft_nb;
+        q.n_bins = (int)p->cfg.n_fft / 2 + 1;
+        q.n_mels = (int)p->cfg.n_mels;
+        q.nmt = p->dft_nmt;
+        q.tile_stride = p->dft_tile_stride;
+        q.out_power = p->cfg.output == AF_OUT_POWER;
+        q.log_mel = (int)p->cfg.log_mel;
+        const size_t smem = (size_t)p->dft_tile_stride * sizeof(float) * (size_t)p->dft_waves;
+        int per_cu = (int)((160 * 1024) / smem);
+        if (per_cu > 4) per_cu = 4;
+        if (per_cu < 1) per_cu = 1;
+        const int64_t sets = (u_count + p->dft_waves - 1) / p->dft_waves;
+        int64_t grid = (int64_t)p->n_cus * per_cu;
+        if (grid > sets) grid = sets;
+        return dft::launch(q, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16,
+                           p->cfg.channel_mode == AF_CH_SEPARATE, p->dft_waves, (int)grid, as_stream(stream));
     }
     // dense_mel: the kernels write power rows, the contraction with W follows as its own launch
     const bool dense = p->dense_mel && p->cfg.output != AF_OUT_POWER;
@@ -961,7 +1069,7 @@ af_status af_features_run(af_features* p, const void* pcm, size_t pcm_len, float
     hipPointerAttribute_t pa;
     const bool pinned = hipPointerGetAttributes(&pa, pcm) == hipSuccess && pa.type == hipMemoryTypeHost;
     if (!pinned) (void)hipGetLastError();
-    const bool two_launches = p->dense_mel || (p->cfg.output == AF_OUT_POWER && p->cfg.n_fft != (uint32_t)kNfft);
+    const bool two_launches = !p->dft && (p->dense_mel || (p->cfg.output == AF_OUT_POWER && p->cfg.n_fft != (uint32_t)kNfft));
     if (pinned && p->contiguous && n >= 2 && in_bytes >= ((size_t)64 << 20) && !two_launches) {
         const int64_t target = (int64_t)(((size_t)32 << 20) / bpf);
         size_t c0 = 0;
@@ -1068,7 +1176,7 @@ static af_status build_v3(af_features* p)
     if (p->v3_tried) return AF_OK;
     p->v3_tried = true;
     const af_features_config* cfg = &p->cfg;
-    if (!(cfg->hop == (uint32_t)v2::kHop && !p->dense_mel && cfg->output == AF_OUT_MEL)) return AF_OK;
+    if (!(!p->dft && cfg->hop == (uint32_t)v2::kHop && !p->dense_mel && cfg->output == AF_OUT_MEL)) return AF_OK;
     std::vector<float> wfrag8b;
     std::vector<int> meta8b;
     // groups of whole filter quads first (one 16-byte store per group and lane: the kernel's QUADS instances), then the

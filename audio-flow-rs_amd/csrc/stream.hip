@@ -189,7 +189,9 @@ af_status af_stream_create(const af_stream_config* cfg, af_stream** out)
     AF_REQUIRE(cfg && out, "af_stream_create: null argument");
     *out = nullptr;
     const af_features_config& fc = cfg->features;
-    AF_REQUIRE(fc.hop > 0 && fc.n_fft % fc.hop == 0, "streaming needs n_fft to be a multiple of hop");
+    // (the carry is the n_fft - hop frames a step's last frame shares with the next step's first; rounds 1-4 also asked
+    // for n_fft % hop == 0, which nothing below needs: 400 / 160 streams like 1024 / 256)
+    AF_REQUIRE(fc.hop > 0 && fc.n_fft >= fc.hop, "streaming needs hop <= n_fft");
     AF_REQUIRE(cfg->step_frames % ((size_t)16 * fc.hop) == 0 && cfg->step_frames >= fc.n_fft,
                "step_frames must be a multiple of 16 * hop (%u) and at least n_fft", 16 * fc.hop);
     AF_REQUIRE(fc.channel_mode == AF_CH_DOWNMIX, "streaming emits one spectrogram per stream");

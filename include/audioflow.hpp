@@ -298,7 +298,8 @@ struct MelSpectrogram {
 // Stft::new(n_fft, hop) [B]: power spectrogram rows [frame][n_fft/2+1]
 class Stft {
 public:
-    // n_fft 1024 (default), 512 or 256: the Stft::new(n_fft, hop) shape of SURVEY.md section 8 A6
+    // n_fft 32..1024 (1024 default; 1024 / 512 / 256 on the register FFT kernels, any other length as a matrix-product DFT):
+    // the Stft::new(n_fft, hop) shape of SURVEY.md section 8 A6
     explicit Stft(uint32_t hop = 256, uint32_t channels = 1, uint32_t n_fft = 1024)
     {
         af_stft_config c;

@@ -264,7 +264,9 @@ typedef struct af_features af_features;
 typedef struct {
     uint32_t sample_rate;    /* Hz, of the PCM handed in */
     uint32_t channels;       /* 1..16, interleaved; more than 2 (f32 only): af_to_mono_device first, then the mono kernel */
-    uint32_t n_fft;          /* 1024 (default), 512 or 256: the frame length = the DFT size */
+    uint32_t n_fft;          /* the frame length = the DFT size, 32..1024.  1024 (default), 512, 256: register FFT kernels;
+                              * any other length (400 = 25 ms at 16 kHz ...): the DFT as a matrix product on the f32
+                              * matrix cores (features_dft.hip), same contract, about 10 x the arithmetic */
     uint32_t hop;            /* 64..1024, multiple of 4 */
     uint32_t n_mels;         /* 1..128 */
     float    f_min;          /* Hz */
@@ -354,7 +356,7 @@ af_status af_features_debug_stamps(af_features* p, int enable, unsigned long lon
 typedef struct af_stft af_stft;
 typedef struct {
     uint32_t channels;       /* 1 or 2 (interleaved; 2 is downmixed first) */
-    uint32_t n_fft;          /* 1024 (default), 512 or 256: the frame length = the DFT size */
+    uint32_t n_fft;          /* 32..1024: the frame length = the DFT size (1024 default; see af_features_config) */
     uint32_t hop;
     uint32_t sample_format;
     int32_t  device;
@@ -376,7 +378,7 @@ af_status af_stft_power(af_stft* s, const void* pcm, size_t pcm_len, float* powe
 typedef struct af_mel af_mel;
 typedef struct {
     uint32_t sample_rate;
-    uint32_t n_fft;          /* 1024 (default), 512 or 256: the frame length = the DFT size */
+    uint32_t n_fft;          /* 32..1024: the frame length = the DFT size (1024 default; see af_features_config) */
     uint32_t n_mels;
     float    f_min, f_max;   /* f_max 0 => sample_rate/2 */
     uint32_t mel_scale, mel_norm, log_mel;

@@ -385,6 +385,32 @@ void afo_stft_power_f64(const float* x, size_t n, size_t n_fft, size_t hop,
     double* re = (double*)malloc(n_fft * sizeof(double));
     double* im = (double*)malloc(n_fft * sizeof(double));
     afo_hann_periodic(n_fft, w);
+    if ((n_fft & (n_fft - 1)) != 0) {
+        /* a frame length that is not a power of two (400 = 25 ms at 16 kHz ...): the DFT sum itself, float64,
+         * angles from a table indexed by k i mod n_fft (the same reduction as afo_dft_power_naive_f64) */
+        double* c = (double*)malloc(n_fft * sizeof(double));
+        double* s = (double*)malloc(n_fft * sizeof(double));
+        for (size_t r = 0; r < n_fft; ++r) {
+            double ang = -2.0 * M_PI * (double)r / (double)n_fft;
+            c[r] = cos(ang); s[r] = sin(ang);
+        }
+        for (size_t f = 0; f < nf; ++f) {
+            const float* xf = x + f * hop;
+            for (size_t i = 0; i < n_fft; ++i) re[i] = w[i] * (double)xf[i];
+            for (size_t k = 0; k < nb; ++k) {
+                double sr = 0.0, si = 0.0;
+                size_t ki = 0;
+                for (size_t i = 0; i < n_fft; ++i) {
+                    sr += re[i] * c[ki];
+                    si += re[i] * s[ki];
+                    ki += k; if (ki >= n_fft) ki -= n_fft;
+                }
+                power[f * nb + k] = sr * sr + si * si;
+            }
+        }
+        free(c); free(s); free(w); free(re); free(im);
+        return;
+    }
     for (size_t f = 0; f < nf; ++f) {
         const float* xf = x + f * hop;
         for (size_t i = 0; i < n_fft; ++i) { re[i] = w[i] * (double)xf[i]; im[i] = 0.0; }

@@ -129,7 +129,7 @@ void afo_fir_f32(const float* x, size_t n, const float* h, size_t K, float* y);
 size_t afo_stft_n_frames(size_t n, size_t n_fft, size_t hop);
 void   afo_hann_periodic(size_t N, double* w);   /* 0.5 - 0.5 cos(2 pi n/N) */
 /* power[f][k] = |sum_n w[n] x[f*hop+n] e^{-2 pi i k n / n_fft}|^2,
- * k = 0..n_fft/2.  n_fft must be a power of two. */
+ * k = 0..n_fft/2.  Powers of two: radix-2 FFT in float64; any other n_fft: the DFT sum itself in float64. */
 void   afo_stft_power_f64(const float* x, size_t n, size_t n_fft, size_t hop,
                           double* power);
 /* direct O(N^2) DFT of one frame -- independent check of the FFT above */

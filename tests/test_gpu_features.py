@@ -165,7 +165,7 @@ def test_too_wide_filters_take_the_dense_path(af, po):
 
 
 def test_invalid_configs_are_rejected(af):
-    for kw in [dict(n_fft=500), dict(n_fft=2048), dict(n_fft=128), dict(channels=17), dict(channels=0), dict(hop=30), dict(hop=258), dict(n_mels=0),
+    for kw in [dict(n_fft=2048), dict(n_fft=16), dict(n_fft=1025), dict(channels=17), dict(channels=0), dict(hop=30), dict(hop=258), dict(n_mels=0),
                dict(n_mels=200), dict(sample_rate=0), dict(f_min=30000.0)]:
         with pytest.raises(af.AudioError):
             af.FeaturePipeline(**kw)

@@ -56,6 +56,22 @@ def test_stft_fft_vs_naive_dft_and_numpy(po):
         assert rel_err(P[f], np.abs(np.fft.rfft(fr.astype(np.float64) * w)) ** 2) < 1e-13
 
 
+@pytest.mark.parametrize("n_fft,hop", [(400, 160), (480, 240), (100, 64), (1000, 512), (33, 64), (600, 1024)])
+def test_stft_of_frame_lengths_that_are_not_powers_of_two(po, n_fft, hop):
+    """`afo_stft_power_f64` takes the DFT sum itself for these (the radix-2 FFT does not apply): pinned against numpy's
+    mixed-radix rfft and the one-frame naive DFT; the whole chain (`po.features`) follows."""
+    x = synth_clip(8, n_fft + 5 * hop + 7, 1, 16000)
+    P = po.stft_power(x, n_fft, hop)
+    assert P.shape == (6, n_fft // 2 + 1)
+    w = po.hann_periodic(n_fft)
+    for f in range(6):
+        fr = x[f * hop:f * hop + n_fft]
+        assert rel_err(P[f], np.abs(np.fft.rfft(fr.astype(np.float64) * w)) ** 2) < 1e-12
+        assert rel_err(P[f], po.dft_power_naive(fr, n_fft)) < 1e-12
+    W = po.mel_weights(16000.0, n_fft, 40)
+    assert rel_err(po.features(x, 1, 16000.0, n_fft=n_fft, hop=hop, n_mels=40), P @ W.T) < 1e-12
+
+
 def test_mel_weights_properties(po):
     W = po.mel_weights(48000.0)
     assert W.shape == (80, 513)
