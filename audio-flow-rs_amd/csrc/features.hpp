@@ -126,24 +126,30 @@ af_status launch(const Params& p, int channels, bool i16, bool separate, int gri
 // n_fft outside {1024, 512, 256} (400 = 25 ms at 16 kHz, the usual speech frame; websocket.rs:274 names the 16 kHz
 // format) has no power-of-two factorisation to hand to the register FFT.  The frame's DFT is taken as what it is, a
 // matrix product, on v_mfma_f32_16x16x4_f32: D[bin][frame] = sum_k T[k][bin] x[frame * hop + k], T = window x
-// (cos | -sin), 16 frames x 16 bins per tile, f32 throughout.  The accumulator layout (rows = bins 4 kq + i, column =
-// frame) is the B-operand layout of the mel product that follows (mel^T[filter][frame] += W[filter][bin] P[bin][frame]),
-// so the power values never leave their registers.  One wave = one 16-frame unit (the unit records of the hop-256
-// kernel, with the handle's hop), a signal tile of 15 hop + K samples in wave-private LDS; the waves of a workgroup
-// walk the fragment stream together (one barrier per bin tile) so that it is read from L2 once per workgroup.
+// (cos | -sin), 16 frames x 16 bins per tile, f32 throughout -- at half the length: the window is symmetric, so the real
+// part is a product with the folded samples x[n] + x[N - n] and the imaginary part one with x[n] - x[N - n].  The
+// accumulator layout (rows = bins 4 kq + i, column = frame) is the B-operand layout of the mel product that follows
+// (mel^T[filter][frame] += W[filter][bin] P[bin][frame]), so the power values never leave their registers.  One wave =
+// one 16-frame unit (the unit records of the hop-256 kernel, with the handle's hop), its folded rows in wave-private
+// LDS (no barrier anywhere); the fragment stream is double-buffered by chunks of four K groups.
 namespace dft {
 constexpr int kMaxMelTiles = 8;           // n_mels <= 128
 struct Params {
     const void* pcm;
     float* out;               // mel rows [total_frames][n_mels] or power rows [total_frames][n_fft / 2 + 1]
-    const float* tfrag;       // [bin tile][k group][re, im][64 lanes][4]: T[16 g + 4 kq + j][16 bt + (lane & 15)]
+    const float* tfrag;       // [bin tile][k group][cos, -sin][64 lanes][4]: w[n] cos / -sin (2 pi n bin / N), n = 16 g + 4 kq + j + 1, bin = 16 bt + (lane & 15)
     const float* wfrag;       // [bin tile][mel tile][64 lanes][4]: W[16 mt + (lane & 15)][16 bt + 4 kq + i]
     const uint32_t* wmask;    // [bin tile]: bit mt set = that tile of W has a non-zero weight
     const v2::UnitDesc* units;
     int64_t total_units;
-    int hop, kg, nb, n_bins, n_mels, nmt;   // kg = K groups of 16 samples, nb = bin tiles of 16
-    int tile_stride;          // floats of LDS per wave (>= 15 hop + 16 kg, a multiple of 8)
+    int hop, kg, nb, n_bins, n_mels, nmt;   // kg = K groups of 16 folded samples, nb = bin tiles of 16
+    int n_fft, nh;            // nh = n_fft / 2 folded samples per frame (n = 1 .. nh paired with n_fft - n)
+    int row_stride;           // floats per frame row: E [16 kg] | O [16 kg] | 8 pad (8 mod 16: conflict-free 16-byte reads)
+    int tile_stride;          // floats of LDS per wave: 16 frame rows
     int out_power, log_mel;
+    unsigned long long* stamps;   // diagnostics (af_features_debug_stamps), or null: summed over waves -- [0] cycles building the
+                                  // folded rows, [1] cycles in the products, [2] units, [3] kernel lifetime in cycles, [4] the same
+                                  // in 100 MHz ticks, [5] waves
 };
 // `waves` 64-lane waves per workgroup (1, 2 or 4: what the LDS holds), `grid` workgroups
 af_status launch(const Params& p, int channels, bool i16, bool separate, int waves, int grid, hipStream_t stream);

@@ -81,7 +81,7 @@ struct af_features {
     bool dft = false;
     DevBuf d_dft;                    // tfrag | wfrag | wmask
     size_t dft_off_w = 0, dft_off_mask = 0;
-    int dft_kg = 0, dft_nb = 0, dft_nmt = 0, dft_tile_stride = 0, dft_waves = 0;
+    int dft_kg = 0, dft_nb = 0, dft_nmt = 0, dft_row_stride = 0, dft_tile_stride = 0, dft_waves = 1;
 };
 
 namespace {
@@ -363,16 +363,21 @@ af_status build_dft(af_features* p)
 {
     const af_features_config& c = p->cfg;
     const int n_fft = (int)c.n_fft, n_bins = n_fft / 2 + 1, nm = (int)c.n_mels;
-    const int kg = (n_fft + 15) / 16, nb = (n_bins + 15) / 16, nmt = (nm + 15) / 16;
+    // the symmetric window halves the products: n = 1 .. nh = n_fft / 2 paired with n_fft - n (features_dft.hip)
+    const int nh = n_fft / 2;
+    // (at least four groups: the kernel's fragment ring takes whole chunks of four and lets one bin tile end per chunk)
+    const int kg = std::max((nh + 15) / 16, 4), nb = (n_bins + 15) / 16, nmt = (nm + 15) / 16;
     p->W.clear();                                       // (the 513-bin grid means nothing here)
     p->dft = true;
     p->dft_kg = kg; p->dft_nb = nb; p->dft_nmt = nmt;
-    const int tile_len = 15 * (int)c.hop + 16 * kg;
-    p->dft_tile_stride = (tile_len + 7) & ~7;
-    // waves per workgroup: what 64 KB of LDS hold (three workgroups of four waves per CU at hop 160 / n_fft 400)
+    p->dft_row_stride = 2 * 16 * kg + 8;               // E | O | pad: 8 (mod 16) dwords, the conflict-free stride of the b128 reads
+    p->dft_tile_stride = 16 * p->dft_row_stride;
+    // waves per workgroup: four (one per SIMD) where the LDS holds their rows, else two, else one.  Measured on 400 / 160
+    // (27 KB per wave): one workgroup of four 2.13 ms, three of two 3.9 ms, five of one 3.0 ms -- the waves beyond one per
+    // SIMD land unevenly (six on four SIMDs) and every wave carries the same number of units.
     const size_t per_wave = (size_t)p->dft_tile_stride * sizeof(float);
-    p->dft_waves = per_wave * 4 <= 64 * 1024 ? 4 : per_wave * 2 <= 80 * 1024 ? 2 : 1;
-    if (per_wave > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "features: hop %u with n_fft %u needs %zu bytes of LDS per wave", c.hop, c.n_fft, per_wave);
+    if (per_wave > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "features: n_fft %u needs %zu bytes of LDS per wave", c.n_fft, per_wave);
+    p->dft_waves = per_wave * 4 <= 160 * 1024 ? 4 : per_wave * 2 <= 160 * 1024 ? 2 : 1;
     // window x (cos | -sin), the angle reduced in integers first
     std::vector<double> win(n_fft), cs(n_fft), sn(n_fft);
     for (int i = 0; i < n_fft; ++i) {
@@ -380,17 +385,19 @@ af_status build_dft(af_features* p)
         cs[i] = std::cos(2.0 * kPi * (double)i / (double)n_fft);
         sn[i] = std::sin(2.0 * kPi * (double)i / (double)n_fft);
     }
-    std::vector<float> tfrag((size_t)nb * kg * 2 * 64 * 4, 0.0f);
+    // (zero groups behind the last one up to a multiple of 4: the kernel walks the stream in chunks of four groups)
+    std::vector<float> tfrag((size_t)((nb * kg + 3) / 4 * 4) * 2 * 64 * 4, 0.0f);
     for (int bt = 0; bt < nb; ++bt)
         for (int g = 0; g < kg; ++g)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 4; ++j) {
                     const int k = 16 * g + 4 * (lane >> 4) + j, bin = 16 * bt + (lane & 15);
-                    if (k >= n_fft || bin >= n_bins) continue;
-                    const int r = (int)(((int64_t)k * bin) % n_fft);
+                    if (k >= nh || bin >= n_bins) continue;
+                    const int nn = k + 1;                                  // the folded pair (nn, n_fft - nn)
+                    const int r = (int)(((int64_t)nn * bin) % n_fft);
                     const size_t o = ((((size_t)bt * kg + g) * 2) * 64 + lane) * 4 + j;
-                    tfrag[o] = (float)(win[k] * cs[r]);
-                    tfrag[o + 64 * 4] = (float)(-win[k] * sn[r]);
+                    tfrag[o] = (float)(win[nn] * cs[r]);
+                    tfrag[o + 64 * 4] = (float)(-win[nn] * sn[r]);
                 }
     std::vector<float> wfrag((size_t)nb * nmt * 64 * 4, 0.0f);
     std::vector<uint32_t> wmask(nb, 0u);
@@ -898,12 +905,17 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         q.n_bins = (int)p->cfg.n_fft / 2 + 1;
         q.n_mels = (int)p->cfg.n_mels;
         q.nmt = p->dft_nmt;
+        q.n_fft = (int)p->cfg.n_fft;
+        q.nh = (int)p->cfg.n_fft / 2;
+        q.row_stride = p->dft_row_stride;
         q.tile_stride = p->dft_tile_stride;
         q.out_power = p->cfg.output == AF_OUT_POWER;
         q.log_mel = (int)p->cfg.log_mel;
+        q.stamps = p->d_stamps.as<unsigned long long>();
         const size_t smem = (size_t)p->dft_tile_stride * sizeof(float) * (size_t)p->dft_waves;
+        // (at most two waves per SIMD: the kernel holds 227 registers)
         int per_cu = (int)((160 * 1024) / smem);
-        if (per_cu > 4) per_cu = 4;
+        if (per_cu > 8 / p->dft_waves) per_cu = 8 / p->dft_waves;
         if (per_cu < 1) per_cu = 1;
         const int64_t sets = (u_count + p->dft_waves - 1) / p->dft_waves;
         int64_t grid = (int64_t)p->n_cus * per_cu;
@@ -1215,6 +1227,11 @@ af_status af_features_set_option(af_features* p, const char* key, int value)
         p->opt_kernel = value < 0 ? -1 : value;
     }
     else if (std::strcmp(key, "wg_per_cu") == 0) p->opt_wg_per_cu = value < 0 ? -1 : value;
+    else if (std::strcmp(key, "dft_waves") == 0) {                                            // (diagnostics) waves per workgroup of the matrix-product DFT kernel
+        AF_REQUIRE(p->dft && (value == 1 || value == 2 || value == 4), "dft_waves: 1, 2 or 4 on a handle whose n_fft is not 1024 / 512 / 256");
+        AF_REQUIRE((size_t)p->dft_tile_stride * sizeof(float) * (size_t)value <= 160 * 1024, "dft_waves: %d waves need more than 160 KB of LDS", value);
+        p->dft_waves = value;
+    }
     else if (std::strcmp(key, "mel4") == 0) p->opt_mel4 = value < 0 ? -1 : (value != 0);    // 0: the 16 x 16 x 4 mel plan (diagnostics)
     else return fail(AF_ERR_INVALID_ARG, "af_features_set_option: unknown option '%s'", key);
     return AF_OK;

@@ -1,15 +1,24 @@
 // features_dft.hip -- STFT power + mel for frame lengths the register FFT does not factor (n_fft outside
 // {1024, 512, 256}; features.hpp, namespace dft): the DFT as a matrix product on v_mfma_f32_16x16x4_f32.
 //
-// Per wave and 16-frame unit:  for every tile of 16 bins
-//     D_re, D_im [16 bins x 16 frames] = sum over K groups of 16 samples:  T_re/im^T (A, fragments from L2)  x  frames^T (B, LDS)
+// The periodic Hann window is symmetric (w[n] = w[N - n], w[0] = 0), so with e[n] = x[n] + x[N - n] and
+// o[n] = x[n] - x[N - n] (n = 1 .. N / 2; the middle sample of an even N alone in e)
+//     Re X[k] =  sum_n w[n] cos(2 pi k n / N) e[n]          Im X[k] = -sum_n w[n] sin(2 pi k n / N) o[n]
+// -- two products of HALF the length each.  Per wave and 16-frame unit: the folded rows E, O [16 frames][N / 2] are built
+// straight from the PCM (to_mono on the way) into wave-private LDS, then for every tile of 16 bins
+//     D_re [16 bins x 16 frames] = Te^T (A, fragments from L2) x E^T (B, LDS),   D_im likewise from To, O
 //     P = D_re^2 + D_im^2                       (lane (frame n, kq) holds bins 16 bt + 4 kq + 0..3 of frame n)
 //     power output: P goes to HBM;  mel output: mel^T[16 mt .. + 16][frame] += W fragment (A) x P (B, as it sits)
-// The K index of MFMA step j of a group is 16 g + 4 kq + j: a lane's four B operands are one 16-byte LDS read of
-// consecutive samples, its four A operands one 16-byte fragment load (the host lays the fragments out in that order).
-// Bounded by the f32 matrix pipe: 2 x (n_fft / 2 + 1) x n_fft multiply-adds per frame (docs/OPS.md "STFT").
+// The K index of MFMA step j of a group is 16 g + 4 kq + j: a lane's four B operands are one 16-byte LDS read, its
+// four A operands one 16-byte fragment load (the host lays the fragments out in that order).
+// Bounded by the f32 matrix pipe: (n_fft / 2 + 1) x n_fft multiply-adds per frame (docs/OPS.md "STFT").
 #include "af_common.hpp"
 #include "features_dev.hpp"
+
+// (ablation builds, scripts/ablate: 1 no fragment loads inside the product loop, 2 no LDS reads of the folded rows there)
+#ifndef AF_DFT_ABL
+#define AF_DFT_ABL 0
+#endif
 
 namespace af {
 namespace feat {
@@ -35,20 +44,27 @@ __device__ __forceinline__ UnitDesc load_unit(const UnitDesc* units, int64_t u)
 }
 
 template <int CH, bool I16, bool SEP>
-__global__ __launch_bounds__(256) void af_features_dft_kernel(const Params p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void af_features_dft_kernel(const Params p)
 {
     using St = Stage<CH, I16>;
-    constexpr int MS = St::MS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int nw = (int)blockDim.x >> 6;
     const int n = lane & 15, kq = lane >> 4;
-    float* tile = smem + (size_t)w * p.tile_stride;
-    const int tile_len = 15 * p.hop + 16 * p.kg;                       // samples a unit's 16 frames reach
-    const float* xrow = tile + n * p.hop + 4 * kq;
+    // folded rows, one per frame: E [16 kg] | O [16 kg] | 8 floats of padding.  The row stride is 8 (mod 16) dwords: the
+    // 16-lane groups of a ds_read_b128 ({n 0-3, 12-15 of kq} + {n 4-11 of kq + 1}, features.hpp) then cover all 16
+    // 16-byte slots -- at a stride of 0 (mod 16) every read was four-way conflicted and the LDS, not the matrix pipe, set the pace
+    float* rows = smem + (size_t)w * p.tile_stride;
+    const int rs = p.row_stride, nh = p.nh, N = p.n_fft;
+    const int kpad = 16 * p.kg;                                        // entries of E (and of O) the products read (zero behind nh)
+    const float* erow = rows + n * rs + 4 * kq;
+    const float* orow_l = erow + kpad;
     const bool vec_mel = (p.n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(p.out) % 16 == 0);
     const int64_t n_sets = (p.total_units + nw - 1) / nw;
+
+    unsigned long long c_stage = 0, c_prod = 0, c_units = 0;
+    const unsigned long long k_t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0, k_r0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
 
     for (int64_t set = blockIdx.x; set < n_sets; set += gridDim.x) {
         const int64_t u = set * nw + w;
@@ -56,70 +72,158 @@ __global__ __launch_bounds__(256) void af_features_dft_kernel(const Params p)
         UnitDesc ud{};
         if (valid) ud = load_unit(p.units, u);
         const int sel = SEP ? ud.sel : -1;
-        __syncthreads();                                               // (nobody still reads the previous tiles)
+        const unsigned long long s_t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
         if (valid) {
-            // signal tile: to_mono (capture.rs:30-42) / i16 scaling on the way in, zeros behind the end of the clip
-            const bool al = ((reinterpret_cast<uintptr_t>(p.pcm) + (uintptr_t)(ud.pcm0 * St::kBytesPerFrame)) % 16) == 0;
-            for (int v = lane; v * MS < tile_len; v += 64) {
-                float m[MS];
-                St::load(p.pcm, ud.pcm0, (int64_t)v * MS, (int64_t)ud.n_avail, al, m, sel);
+            // folded rows: entry k of frame f pairs sample n = k + 1 with sample N - n of that frame; to_mono (capture.rs:30-42)
+            // / i16 scaling on the way in, zeros behind the end of the clip and behind the last pair
+            // (a valid unit holds at least one whole frame: avail >= n_fft; indices are clamped and the value selected, so
+            // the 32 loads of one entry of all 16 frames are in flight together)
+            const int64_t avail = ud.n_avail;
+            const auto mono = [&](int64_t i) -> float {
+                const int64_t ic = i < avail ? i : avail - 1;
+                float v;
+                if constexpr (CH == 1) {
+                    v = St::sample(p.pcm, ud.pcm0 + ic);
+                } else {
+                    const float l = St::sample(p.pcm, 2 * (ud.pcm0 + ic)), r = St::sample(p.pcm, 2 * (ud.pcm0 + ic) + 1);
+                    v = sel < 0 ? (l + r) * 0.5f : sel ? r : l;
+                }
+                return i < avail ? v : 0.0f;
+            };
+            for (int k = lane; k < kpad; k += 64) {
+                const int nn = k + 1;
+                const bool pair = k < nh, self = (N - nn == nn);
+                const int na = pair ? nn : 1, nb2 = pair ? N - nn : 1;      // (entries behind the last pair: any valid sample, zeroed below)
+                float a[16], b[16];
 #pragma unroll
-                for (int e = 0; e < MS; ++e) tile[v * MS + e] = m[e];
+                for (int f = 0; f < 16; ++f) {
+                    a[f] = mono((int64_t)f * p.hop + na);
+                    b[f] = mono((int64_t)f * p.hop + nb2);
+                }
+#pragma unroll
+                for (int f = 0; f < 16; ++f) {
+                    const float e = !pair ? 0.0f : self ? a[f] : a[f] + b[f];
+                    const float o = (!pair || self) ? 0.0f : a[f] - b[f];
+                    rows[f * rs + k] = e;
+                    rows[f * rs + kpad + k] = o;
+                }
             }
         }
         wave_sync();
+        if (!valid) continue;                                          // (the rows are wave-private: no barrier anywhere)
+        unsigned long long s_t1 = 0;
+        if (p.stamps) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            s_t1 = __builtin_amdgcn_s_memtime();
+        }
         f32x4 macc[kMaxMelTiles];
 #pragma unroll
         for (int mt = 0; mt < kMaxMelTiles; ++mt) macc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int bt = 0; bt < p.nb; ++bt) {
-            __syncthreads();                                           // the waves stream the same fragments: keep them together
-            if (!valid) continue;
-            f32x4 are = {0.f, 0.f, 0.f, 0.f}, aim = {0.f, 0.f, 0.f, 0.f};
-            const float4* fr = reinterpret_cast<const float4*>(p.tfrag) + (size_t)bt * p.kg * 2 * 64 + lane;
-            float4 tr = fr[0], ti = fr[64];
-            for (int g = 0; g < p.kg; ++g) {
-                const float4 b = *reinterpret_cast<const float4*>(xrow + 16 * g);
-                const float4 cr = tr, ci = ti;
-                if (g + 1 < p.kg) {                                    // the next group's fragments while this one multiplies
-                    tr = fr[(size_t)(2 * g + 2) * 64];
-                    ti = fr[(size_t)(2 * g + 3) * 64];
-                }
-                are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.x, b.x, are, 0, 0, 0);
-                aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.x, b.x, aim, 0, 0, 0);
-                are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.y, b.y, are, 0, 0, 0);
-                aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.y, b.y, aim, 0, 0, 0);
-                are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.z, b.z, are, 0, 0, 0);
-                aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.z, b.z, aim, 0, 0, 0);
-                are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.w, b.w, are, 0, 0, 0);
-                aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.w, b.w, aim, 0, 0, 0);
+        // One flat walk over (bin tile, K group) in chunks of kChunk groups; the fragment stream is contiguous in that order.
+        // Fragments are double-buffered by CHUNK: all loads of chunk c + 1 go out, unconditionally (clamped index), at the
+        // top of chunk c.  The compiler's wait at the top of the next chunk is then vmcnt(0) on loads that are a whole chunk
+        // (32 matrix instructions) old.  Finer rings lose to its bookkeeping: behind a conditional load, or across the back
+        // edge of the loop, it cannot count how many loads follow the one it needs and waits for all of them -- a ring of
+        // depth one, 590 cycles per group instead of 256 with one wave per SIMD.  The mel fragments of a bin tile that ends in
+        // a chunk are requested at that chunk's top BEFORE the fragment loads (so the wait for them counts those 2 kChunk
+        // behind them and nothing else); what ends a tile inside the chunk only saves the power values, the mel products
+        // follow once, behind the chunk (kg >= kChunk: at most one tile ends per chunk).
+        constexpr int kChunk = 4;
+        const int total = (p.nb * p.kg + kChunk - 1) / kChunk * kChunk;        // (the table ends with zero groups up to a whole chunk)
+        const float4* fr = reinterpret_cast<const float4*>(p.tfrag) + lane;
+        const float4* wfb = reinterpret_cast<const float4*>(p.wfrag) + lane;
+        float4 bufA[2 * kChunk], bufB[2 * kChunk];
+        const auto request = [&](float4 (&buf)[2 * kChunk], int q_first) {
+#pragma unroll
+            for (int d = 0; d < kChunk; ++d) {
+                const int qn = q_first + d < total ? q_first + d : total - 1;
+                buf[2 * d] = fr[(size_t)(2 * qn) * 64];
+                buf[2 * d + 1] = fr[(size_t)(2 * qn + 1) * 64];
             }
-            float pw[4];
+        };
+        request(bufA, 0);
+        float4 wfm[kMaxMelTiles];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pw[i] = __builtin_fmaf(are[i], are[i], aim[i] * aim[i]);
-            if (p.out_power) {
-                if (n < ud.n_rows) {
-                    float* o = p.out + (ud.out0 + n) * p.n_bins + 16 * bt + 4 * kq;
+        for (int mt = 0; mt < kMaxMelTiles; ++mt) wfm[mt] = float4{0.f, 0.f, 0.f, 0.f};
+        uint32_t mask = p.out_power ? 0u : p.wmask[0];                 // of the bin tile in progress (scalar, a tile ahead)
+        f32x4 are = {0.f, 0.f, 0.f, 0.f}, aim = {0.f, 0.f, 0.f, 0.f};
+        int g = 0, bt = 0;
+        // B operands one group ahead: a wave alone on its SIMD otherwise waits for its two LDS reads in every group
+        float4 be_n = *reinterpret_cast<const float4*>(erow);
+        float4 bo_n = *reinterpret_cast<const float4*>(orow_l);
+        float pw[4] = {0.f, 0.f, 0.f, 0.f};
+        const auto chunk = [&](const float4 (&cur)[2 * kChunk], float4 (&nxt)[2 * kChunk], int q0) {
+            const bool ends = g + kChunk >= p.kg;                      // a bin tile ends inside this chunk
+            if (ends && !p.out_power) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (16 * bt + 4 * kq + i < p.n_bins) o[i] = pw[i];
+                for (int mt = 0; mt < kMaxMelTiles; ++mt)
+                    if (mt < p.nmt && ((mask >> mt) & 1u)) wfm[mt] = wfb[((size_t)bt * p.nmt + mt) * 64];
+            }
+            if constexpr (!(AF_DFT_ABL & 1)) request(nxt, q0 + kChunk);
+            bool done = false;
+#pragma unroll
+            for (int d = 0; d < kChunk; ++d) {
+                const float4 cr = (AF_DFT_ABL & 1) ? bufA[2 * d] : cur[2 * d], ci = (AF_DFT_ABL & 1) ? bufA[2 * d + 1] : cur[2 * d + 1];
+                const float4 be = be_n, bo = bo_n;
+                if constexpr (!(AF_DFT_ABL & 2)) {
+                    const int gn = (g + 1 == p.kg) ? 0 : g + 1;        // (behind the last group of a bin tile: group 0 of the next)
+                    be_n = *reinterpret_cast<const float4*>(erow + 16 * gn);
+                    bo_n = *reinterpret_cast<const float4*>(orow_l + 16 * gn);
+                    __builtin_amdgcn_sched_barrier(0);                 // (the reads stay here, a whole group ahead of their use)
                 }
-            } else {
-                const uint32_t mask = p.wmask[bt];                     // wave-uniform
-                const float4* wf = reinterpret_cast<const float4*>(p.wfrag) + (size_t)bt * p.nmt * 64 + lane;
+                // a tile's first products start from zero (no write to the accumulators outside the matrix pipe: a
+                // v_mov between two of its instructions waits out the first one's latency)
+                if (g == 0) {                                          // wave-uniform
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.x, be.x, z, 0, 0, 0);
+                    aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.x, bo.x, z, 0, 0, 0);
+                } else {
+                    are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.x, be.x, are, 0, 0, 0);
+                    aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.x, bo.x, aim, 0, 0, 0);
+                }
+                are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.y, be.y, are, 0, 0, 0);
+                aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.y, bo.y, aim, 0, 0, 0);
+                are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.z, be.z, are, 0, 0, 0);
+                aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.z, bo.z, aim, 0, 0, 0);
+                are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.w, be.w, are, 0, 0, 0);
+                aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.w, bo.w, aim, 0, 0, 0);
+                if (++g == p.kg) {                                     // the bin tile is complete (the padding groups never get here)
 #pragma unroll
-                for (int mt = 0; mt < kMaxMelTiles; ++mt) {
-                    if (mt < p.nmt && ((mask >> mt) & 1u)) {
-                        const float4 a = wf[mt * 64];
-                        macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, pw[0], macc[mt], 0, 0, 0);
-                        macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, pw[1], macc[mt], 0, 0, 0);
-                        macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, pw[2], macc[mt], 0, 0, 0);
-                        macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, pw[3], macc[mt], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) pw[i] = __builtin_fmaf(are[i], are[i], aim[i] * aim[i]);
+                    g = 0;
+                    done = true;
+                }
+            }
+            if (done) {
+                if (p.out_power) {
+                    if (n < ud.n_rows) {
+                        float* o = p.out + (ud.out0 + n) * p.n_bins + 16 * bt + 4 * kq;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (16 * bt + 4 * kq + i < p.n_bins) o[i] = pw[i];
                     }
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < kMaxMelTiles; ++mt) {
+                        if (mt < p.nmt && ((mask >> mt) & 1u)) {
+                            const float4 a = wfm[mt];
+                            macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, pw[0], macc[mt], 0, 0, 0);
+                            macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, pw[1], macc[mt], 0, 0, 0);
+                            macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, pw[2], macc[mt], 0, 0, 0);
+                            macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, pw[3], macc[mt], 0, 0, 0);
+                        }
+                    }
+                    mask = bt + 1 < p.nb ? p.wmask[bt + 1] : 0u;
                 }
+                ++bt;
             }
+        };
+        for (int q0 = 0; q0 < total; q0 += 2 * kChunk) {
+            chunk(bufA, bufB, q0);
+            if (q0 + kChunk < total) chunk(bufB, bufA, q0 + kChunk);
         }
-        if (valid && !p.out_power && n < ud.n_rows) {
+        if (!p.out_power && n < ud.n_rows) {
             // mel^T tiles: rows = filters 16 mt + 4 kq + i, column = frame n: 16 bytes of one output row per lane
             float* orow = p.out + (ud.out0 + n) * p.n_mels + 4 * kq;
 #pragma unroll
@@ -141,6 +245,21 @@ __global__ __launch_bounds__(256) void af_features_dft_kernel(const Params p)
                 }
             }
         }
+        if (p.stamps) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long s_t2 = __builtin_amdgcn_s_memtime();
+            c_stage += s_t1 - s_t0;
+            c_prod += s_t2 - s_t1;
+            c_units += 1;
+        }
+    }
+    if (p.stamps && lane == 0) {
+        atomicAdd(p.stamps, c_stage);
+        atomicAdd(p.stamps + 1, c_prod);
+        atomicAdd(p.stamps + 2, c_units);
+        atomicAdd(p.stamps + 3, __builtin_amdgcn_s_memtime() - k_t0);
+        atomicAdd(p.stamps + 4, __builtin_amdgcn_s_memrealtime() - k_r0);
+        atomicAdd(p.stamps + 5, 1ull);
     }
 }
 
