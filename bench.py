@@ -471,6 +471,45 @@ def wire_secondary(torch, af, dev, pcm, n_clips: int, n_frames_pcm: int, stream)
                      "max_lsb_diff_vs_float64_oracle_chain": int(d.max()), "ok": bool(np.array_equal(got, want) and d.max() <= 1)}}
 
 
+def speech_secondary(torch, af, dev, stream, device_index: int) -> dict:
+    """The 16 kHz speech front end (websocket.rs:274 names the format; 25 ms / 10 ms frames = n_fft 400, hop 160, 80 mel) on
+    256 x 30 s mono clips: `af_features_dft_kernel`, the DFT as a matrix product (features_dft.hip).  Bound by the f32 matrix
+    pipe, so the figure beside the time is the MFMA issue rate, not an HBM fraction; two clips against the float64 oracle."""
+    import numpy as np
+    from oracle import pyoracle as po
+    n_clips, n, sr, n_fft, hop = 256, 480000, 16000, 400, 160
+    g = torch.Generator(device="cpu"); g.manual_seed(1234)
+    pcm = ((torch.rand(n_clips, n, generator=g) * 2 - 1) * 0.3).to(dev)
+    pipe = af.FeaturePipeline(sample_rate=sr, channels=1, n_fft=n_fft, hop=hop, n_mels=N_MELS, device=device_index)
+    total = pipe.set_batch_uniform(n_clips, n)
+    mel = torch.empty(total, N_MELS, device=dev, dtype=torch.float32)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:
+        pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        pipe.run_device(pcm.data_ptr(), mel.data_ptr(), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nf = pipe.n_frames(n)
+    kg, nb = max((n_fft // 2 + 15) // 16, 4), (n_fft // 2 + 1 + 15) // 16
+    flop = 2.0 * 2 * (16 * kg) * (16 * nb) * ((total + 15) // 16 * 16)
+    err = 0.0
+    for c in (0, n_clips - 1):
+        ref = po.features(pcm[c].cpu().numpy(), 1, float(sr), n_fft=n_fft, hop=hop, n_mels=N_MELS)
+        got = mel[c * nf:(c + 1) * nf].cpu().numpy().astype(np.float64)
+        err = max(err, float((np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-300)).max()))
+    return {"speech_nfft400": {"workload": f"{n_clips} x 30 s mono {sr} Hz f32 -> STFT {n_fft}/{hop} -> {N_MELS} mel, 1 GPU",
+                               "kernel": "af_features_dft_kernel", "ms": ms, "frames": total, "frames_per_s": total / (ms * 1e-3),
+                               "rtf": n_clips * 30 / (ms * 1e-3), "bound": "mfma",
+                               "tflops_f32_mfma_issued": flop / (ms * 1e-3) / 1e12, "frac_of_f32_matrix_peak": flop / (ms * 1e-3) / 1e12 / 157.3,
+                               "max_rel_err": err, "ok": bool(err < 1e-5)}}
+
+
 def northstar_secondary(torch, af, dev, n_clips: int, n_frames_pcm: int, stream, device_index: int) -> dict:
     """north_star's own batch ("1024-clip 48 kHz batch at 1 GPU"): the headline kernel on 1024 x 30 s
     stereo clips (11.8 GB of PCM resident in HBM), HIP events on the launch stream, three sampled clips
@@ -665,6 +704,7 @@ def run_rank(args) -> None:
             m["secondary"].update(northstar_secondary(torch, af, dev, args.northstar_clips, n_frames_pcm,
                                                       stream, local_rank))
             m["secondary"].update(resample_secondary(torch, af, dev))
+            m["secondary"].update(speech_secondary(torch, af, dev, stream, local_rank))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         k = max(1, min(args.cpu_clips, n_clips))
         m["cpu_baseline"] = cpu_baseline(pcm[:k].cpu().numpy(), k, n_frames_pcm)

@@ -70,6 +70,15 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ch
 python3 scripts/summarize_prof.py kernel_stats "$O/chain44_kt" "$O/chain44_kernel_stats.txt" "af_|af::|resfir|banded" > /dev/null
 python3 scripts/gpu_check_resfir10.py --time-only > "$O/chain44.txt" 2>&1
 echo "chain 44.1 done"
+# ---- the speech framing (n_fft 400 / hop 160: af_features_dft_kernel, the DFT as a matrix product)
+N="python3 scripts/gpu_bench_nfft.py --reps 20"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/nfft_kt" -- $N > "$O/nfft_kt.log" 2>&1
+python3 scripts/summarize_prof.py kernel_stats "$O/nfft_kt" "$O/nfft_kernel_stats.txt" "af_|af::" > /dev/null
+pmc nfft_sq af_features_dft "$SQ1" python3 scripts/gpu_bench_nfft.py --reps 3
+pmc nfft_sq2 af_features_dft "$SQ2" python3 scripts/gpu_bench_nfft.py --reps 3
+python3 scripts/gpu_bench_nfft.py --reps 30 --stamps --json "$O/nfft400.json" > /dev/null
+python3 scripts/gpu_bench_nfft.py --reps 30 --n_fft 480 --hop 160 --json "$O/nfft480.json" > /dev/null
+echo "nfft done"
 # ---- secondary kernels
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ops_kt" -- python3 scripts/gpu_bench_ops.py > "$O/ops.json" 2> "$O/ops_kt.log"
 python3 scripts/summarize_prof.py kernel_stats "$O/ops_kt" "$O/ops_kernel_stats.txt" "af_|af::|banded|fir|resample" > /dev/null
