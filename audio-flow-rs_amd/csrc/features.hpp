@@ -129,9 +129,10 @@ af_status launch(const Params& p, int channels, bool i16, bool separate, int gri
 // (cos | -sin), 16 frames x 16 bins per tile, f32 throughout -- at half the length: the window is symmetric, so the real
 // part is a product with the folded samples x[n] + x[N - n] and the imaginary part one with x[n] - x[N - n].  The
 // accumulator layout (rows = bins 4 kq + i, column = frame) is the B-operand layout of the mel product that follows
-// (mel^T[filter][frame] += W[filter][bin] P[bin][frame]), so the power values never leave their registers.  One wave =
-// one 16-frame unit (the unit records of the hop-256 kernel, with the handle's hop), its folded rows in wave-private
-// LDS (no barrier anywhere); the fragment stream is double-buffered by chunks of four K groups.
+// (mel^T[filter][frame] += W[filter][bin] P[bin][frame]), so the power values never leave their registers.  One
+// two-wave workgroup = one 16-frame unit (the unit records of the hop-256 kernel, with the handle's hop): each wave
+// builds half of the folded rows in LDS and multiplies every other bin tile, four workgroups per CU = two waves per
+// SIMD; the fragment stream is double-buffered by chunks of four K groups; the waves' partial mel sums meet in LDS.
 namespace dft {
 constexpr int kMaxMelTiles = 8;           // n_mels <= 128
 struct Params {
@@ -151,7 +152,7 @@ struct Params {
                                   // folded rows, [1] cycles in the products, [2] units, [3] kernel lifetime in cycles, [4] the same
                                   // in 100 MHz ticks, [5] waves
 };
-// `waves` 64-lane waves per workgroup (1, 2 or 4: what the LDS holds), `grid` workgroups
+// `waves` per workgroup: 2 (they share one 16-frame unit, each taking every other bin tile) or 1 (diagnostics); `grid` workgroups
 af_status launch(const Params& p, int channels, bool i16, bool separate, int waves, int grid, hipStream_t stream);
 }  // namespace dft
 

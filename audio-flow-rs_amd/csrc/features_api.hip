@@ -372,12 +372,12 @@ af_status build_dft(af_features* p)
     p->dft_kg = kg; p->dft_nb = nb; p->dft_nmt = nmt;
     p->dft_row_stride = 2 * 16 * kg + 8;               // E | O | pad: 8 (mod 16) dwords, the conflict-free stride of the b128 reads
     p->dft_tile_stride = 16 * p->dft_row_stride;
-    // waves per workgroup: four (one per SIMD) where the LDS holds their rows, else two, else one.  Measured on 400 / 160
-    // (27 KB per wave): one workgroup of four 2.13 ms, three of two 3.9 ms, five of one 3.0 ms -- the waves beyond one per
-    // SIMD land unevenly (six on four SIMDs) and every wave carries the same number of units.
-    const size_t per_wave = (size_t)p->dft_tile_stride * sizeof(float);
-    if (per_wave > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "features: n_fft %u needs %zu bytes of LDS per wave", c.n_fft, per_wave);
-    p->dft_waves = per_wave * 4 <= 160 * 1024 ? 4 : per_wave * 2 <= 160 * 1024 ? 2 : 1;
+    // two waves per workgroup share a unit's rows (27 KB for 400 / 160): four workgroups per CU = two waves per SIMD, each
+    // hiding the other's waits.  (One wave per unit, rows private: 2.13 ms on 256 x 30 s of 400 / 160 with one wave per SIMD --
+    // the LDS holds no more -- against 1.4x ms in this shape.)
+    const size_t per_wg = (size_t)p->dft_tile_stride * sizeof(float);
+    if (per_wg > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "features: n_fft %u needs %zu bytes of LDS per workgroup", c.n_fft, per_wg);
+    p->dft_waves = 2;
     // window x (cos | -sin), the angle reduced in integers first
     std::vector<double> win(n_fft), cs(n_fft), sn(n_fft);
     for (int i = 0; i < n_fft; ++i) {
@@ -912,14 +912,13 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         q.out_power = p->cfg.output == AF_OUT_POWER;
         q.log_mel = (int)p->cfg.log_mel;
         q.stamps = p->d_stamps.as<unsigned long long>();
-        const size_t smem = (size_t)p->dft_tile_stride * sizeof(float) * (size_t)p->dft_waves;
-        // (at most two waves per SIMD: the kernel holds 227 registers)
+        const size_t smem = (size_t)p->dft_tile_stride * sizeof(float);
+        // (at most two waves per SIMD: the kernel holds more than 128 registers)
         int per_cu = (int)((160 * 1024) / smem);
         if (per_cu > 8 / p->dft_waves) per_cu = 8 / p->dft_waves;
         if (per_cu < 1) per_cu = 1;
-        const int64_t sets = (u_count + p->dft_waves - 1) / p->dft_waves;
         int64_t grid = (int64_t)p->n_cus * per_cu;
-        if (grid > sets) grid = sets;
+        if (grid > u_count) grid = u_count;
         return dft::launch(q, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16,
                            p->cfg.channel_mode == AF_CH_SEPARATE, p->dft_waves, (int)grid, as_stream(stream));
     }
@@ -1228,8 +1227,7 @@ af_status af_features_set_option(af_features* p, const char* key, int value)
     }
     else if (std::strcmp(key, "wg_per_cu") == 0) p->opt_wg_per_cu = value < 0 ? -1 : value;
     else if (std::strcmp(key, "dft_waves") == 0) {                                            // (diagnostics) waves per workgroup of the matrix-product DFT kernel
-        AF_REQUIRE(p->dft && (value == 1 || value == 2 || value == 4), "dft_waves: 1, 2 or 4 on a handle whose n_fft is not 1024 / 512 / 256");
-        AF_REQUIRE((size_t)p->dft_tile_stride * sizeof(float) * (size_t)value <= 160 * 1024, "dft_waves: %d waves need more than 160 KB of LDS", value);
+        AF_REQUIRE(p->dft && (value == 1 || value == 2), "dft_waves: 1 or 2 on a handle whose n_fft is not 1024 / 512 / 256");
         p->dft_waves = value;
     }
     else if (std::strcmp(key, "mel4") == 0) p->opt_mel4 = value < 0 ? -1 : (value != 0);    // 0: the 16 x 16 x 4 mel plan (diagnostics)

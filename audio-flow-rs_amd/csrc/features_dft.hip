@@ -19,6 +19,11 @@
 #ifndef AF_DFT_ABL
 #define AF_DFT_ABL 0
 #endif
+// (experiment) where the next group's LDS reads and the bookkeeping go: 0 a full scheduling barrier behind the reads,
+// 1 the compiler's choice, 2 a sched_group_barrier pattern
+#ifndef AF_DFT_SCHED
+#define AF_DFT_SCHED 0
+#endif
 
 namespace af {
 namespace feat {
@@ -44,36 +49,34 @@ __device__ __forceinline__ UnitDesc load_unit(const UnitDesc* units, int64_t u)
 }
 
 template <int CH, bool I16, bool SEP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void af_features_dft_kernel(const Params p)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void af_features_dft_kernel(const Params p)
 {
     using St = Stage<CH, I16>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int nw = (int)blockDim.x >> 6;
+    const int nw = (int)blockDim.x >> 6;                                // 2: the waves of a workgroup share one unit (1: diagnostics)
     const int n = lane & 15, kq = lane >> 4;
     // folded rows, one per frame: E [16 kg] | O [16 kg] | 8 floats of padding.  The row stride is 8 (mod 16) dwords: the
     // 16-lane groups of a ds_read_b128 ({n 0-3, 12-15 of kq} + {n 4-11 of kq + 1}, features.hpp) then cover all 16
-    // 16-byte slots -- at a stride of 0 (mod 16) every read was four-way conflicted and the LDS, not the matrix pipe, set the pace
-    float* rows = smem + (size_t)w * p.tile_stride;
+    // 16-byte slots -- at a stride of 0 (mod 16) every read was four-way conflicted
+    float* rows = smem;
     const int rs = p.row_stride, nh = p.nh, N = p.n_fft;
     const int kpad = 16 * p.kg;                                        // entries of E (and of O) the products read (zero behind nh)
     const float* erow = rows + n * rs + 4 * kq;
     const float* orow_l = erow + kpad;
     const bool vec_mel = (p.n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(p.out) % 16 == 0);
-    const int64_t n_sets = (p.total_units + nw - 1) / nw;
+    const int64_t n_sets = p.total_units;
 
     unsigned long long c_stage = 0, c_prod = 0, c_units = 0;
     const unsigned long long k_t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0, k_r0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
 
     for (int64_t set = blockIdx.x; set < n_sets; set += gridDim.x) {
-        const int64_t u = set * nw + w;
-        const bool valid = u < p.total_units;                          // wave-uniform; idle waves keep the barriers company
-        UnitDesc ud{};
-        if (valid) ud = load_unit(p.units, u);
+        const UnitDesc ud = load_unit(p.units, set);
         const int sel = SEP ? ud.sel : -1;
         const unsigned long long s_t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
-        if (valid) {
+        __syncthreads();                                               // the partner has left the previous unit's rows
+        {
             // folded rows: entry k of frame f pairs sample n = k + 1 with sample N - n of that frame; to_mono (capture.rs:30-42)
             // / i16 scaling on the way in, zeros behind the end of the clip and behind the last pair
             // (a valid unit holds at least one whole frame: avail >= n_fft; indices are clamped and the value selected, so
@@ -90,27 +93,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 }
                 return i < avail ? v : 0.0f;
             };
-            for (int k = lane; k < kpad; k += 64) {
-                const int nn = k + 1;
-                const bool pair = k < nh, self = (N - nn == nn);
-                const int na = pair ? nn : 1, nb2 = pair ? N - nn : 1;      // (entries behind the last pair: any valid sample, zeroed below)
-                float a[16], b[16];
+            // (each wave builds the rows of half the frames: 16 loads in flight per entry with two waves)
+            const int f_lo = nw == 2 ? 8 * w : 0;
+            // (two entries per lane and pass = 32 loads in flight: the rows wait for HBM, not for arithmetic)
+            for (int k0 = lane; k0 < kpad; k0 += 128) {
+                for (int fh = 0; fh < (nw == 2 ? 1 : 2); ++fh) {
+                    float a[2][8], b[2][8];
 #pragma unroll
-                for (int f = 0; f < 16; ++f) {
-                    a[f] = mono((int64_t)f * p.hop + na);
-                    b[f] = mono((int64_t)f * p.hop + nb2);
-                }
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = k0 + 64 * h;
+                        const int nn = k + 1;
+                        const bool pair = k < nh;
+                        const int na = pair ? nn : 1, nb2 = pair ? N - nn : 1;   // (entries behind the last pair: any valid sample, zeroed below)
 #pragma unroll
-                for (int f = 0; f < 16; ++f) {
-                    const float e = !pair ? 0.0f : self ? a[f] : a[f] + b[f];
-                    const float o = (!pair || self) ? 0.0f : a[f] - b[f];
-                    rows[f * rs + k] = e;
-                    rows[f * rs + kpad + k] = o;
+                        for (int f = 0; f < 8; ++f) {
+                            a[h][f] = mono((int64_t)(f_lo + 8 * fh + f) * p.hop + na);
+                            b[h][f] = mono((int64_t)(f_lo + 8 * fh + f) * p.hop + nb2);
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = k0 + 64 * h;
+                        const int nn = k + 1;
+                        const bool pair = k < nh, self = (N - nn == nn);
+                        if (k < kpad) {
+#pragma unroll
+                            for (int f = 0; f < 8; ++f) {
+                                const float e = !pair ? 0.0f : self ? a[h][f] : a[h][f] + b[h][f];
+                                const float o = (!pair || self) ? 0.0f : a[h][f] - b[h][f];
+                                rows[(f_lo + 8 * fh + f) * rs + k] = e;
+                                rows[(f_lo + 8 * fh + f) * rs + kpad + k] = o;
+                            }
+                        }
+                    }
                 }
             }
         }
-        wave_sync();
-        if (!valid) continue;                                          // (the rows are wave-private: no barrier anywhere)
+        __syncthreads();                                               // all 16 rows are there
         unsigned long long s_t1 = 0;
         if (p.stamps) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -130,25 +149,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         // behind them and nothing else); what ends a tile inside the chunk only saves the power values, the mel products
         // follow once, behind the chunk (kg >= kChunk: at most one tile ends per chunk).
         constexpr int kChunk = 4;
-        const int total = (p.nb * p.kg + kChunk - 1) / kChunk * kChunk;        // (the table ends with zero groups up to a whole chunk)
+        // this wave's bin tiles: first, first + nw, ... (the odd tile of 13 alternates between the two waves from unit to unit)
+        const int first = nw == 2 ? (int)((w + set) & 1) : 0;
+        const int nt_w = (p.nb - first + nw - 1) / nw;
+        const int total = (nt_w * p.kg + kChunk - 1) / kChunk * kChunk;         // (whole chunks: the groups behind the last tile multiply into accumulators nobody reads)
         const float4* fr = reinterpret_cast<const float4*>(p.tfrag) + lane;
         const float4* wfb = reinterpret_cast<const float4*>(p.wfrag) + lane;
         float4 bufA[2 * kChunk], bufB[2 * kChunk];
-        const auto request = [&](float4 (&buf)[2 * kChunk], int q_first) {
+        const int q_max = p.nb * p.kg - 1;
+        int rt = 0, rg = 0;                                            // request cursor: (index among this wave's tiles, K group)
+        const auto request = [&](float4 (&buf)[2 * kChunk]) {
 #pragma unroll
             for (int d = 0; d < kChunk; ++d) {
-                const int qn = q_first + d < total ? q_first + d : total - 1;
+                const int t_c = rt < nt_w ? rt : (nt_w > 0 ? nt_w - 1 : 0);   // (behind the end: the last tile's groups again, unconditional loads)
+                int qn = (first + nw * t_c) * p.kg + rg;
+                if (qn > q_max) qn = q_max;
                 buf[2 * d] = fr[(size_t)(2 * qn) * 64];
                 buf[2 * d + 1] = fr[(size_t)(2 * qn + 1) * 64];
+                if (++rg == p.kg) { rg = 0; ++rt; }
             }
         };
-        request(bufA, 0);
+        request(bufA);
         float4 wfm[kMaxMelTiles];
 #pragma unroll
         for (int mt = 0; mt < kMaxMelTiles; ++mt) wfm[mt] = float4{0.f, 0.f, 0.f, 0.f};
-        uint32_t mask = p.out_power ? 0u : p.wmask[0];                 // of the bin tile in progress (scalar, a tile ahead)
+        uint32_t mask = (p.out_power || nt_w == 0) ? 0u : p.wmask[first];   // of the bin tile in progress (scalar, a tile ahead)
         f32x4 are = {0.f, 0.f, 0.f, 0.f}, aim = {0.f, 0.f, 0.f, 0.f};
-        int g = 0, bt = 0;
+        int g = 0, bt = first;
         // B operands one group ahead: a wave alone on its SIMD otherwise waits for its two LDS reads in every group
         float4 be_n = *reinterpret_cast<const float4*>(erow);
         float4 bo_n = *reinterpret_cast<const float4*>(orow_l);
@@ -160,7 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 for (int mt = 0; mt < kMaxMelTiles; ++mt)
                     if (mt < p.nmt && ((mask >> mt) & 1u)) wfm[mt] = wfb[((size_t)bt * p.nmt + mt) * 64];
             }
-            if constexpr (!(AF_DFT_ABL & 1)) request(nxt, q0 + kChunk);
+            if constexpr (!(AF_DFT_ABL & 1)) request(nxt);
             bool done = false;
 #pragma unroll
             for (int d = 0; d < kChunk; ++d) {
@@ -170,7 +197,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                     const int gn = (g + 1 == p.kg) ? 0 : g + 1;        // (behind the last group of a bin tile: group 0 of the next)
                     be_n = *reinterpret_cast<const float4*>(erow + 16 * gn);
                     bo_n = *reinterpret_cast<const float4*>(orow_l + 16 * gn);
+#if AF_DFT_SCHED == 0
                     __builtin_amdgcn_sched_barrier(0);                 // (the reads stay here, a whole group ahead of their use)
+#endif
                 }
                 // a tile's first products start from zero (no write to the accumulators outside the matrix pipe: a
                 // v_mov between two of its instructions waits out the first one's latency)
@@ -188,6 +217,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.z, bo.z, aim, 0, 0, 0);
                 are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.w, be.w, are, 0, 0, 0);
                 aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.w, bo.w, aim, 0, 0, 0);
+#if AF_DFT_SCHED == 2
+                // one matrix instruction, the two LDS reads, one more, then the scalar / vector bookkeeping in the shadow of the rest
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
                 if (++g == p.kg) {                                     // the bin tile is complete (the padding groups never get here)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) pw[i] = __builtin_fmaf(are[i], are[i], aim[i] * aim[i]);
@@ -214,16 +255,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                             macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, pw[3], macc[mt], 0, 0, 0);
                         }
                     }
-                    mask = bt + 1 < p.nb ? p.wmask[bt + 1] : 0u;
+                    mask = bt + nw < p.nb ? p.wmask[bt + nw] : 0u;
                 }
-                ++bt;
+                bt += nw;
             }
         };
         for (int q0 = 0; q0 < total; q0 += 2 * kChunk) {
             chunk(bufA, bufB, q0);
             if (q0 + kChunk < total) chunk(bufB, bufA, q0 + kChunk);
         }
-        if (!p.out_power && n < ud.n_rows) {
+        if (!p.out_power && nw == 2) {
+            // the two waves' partial mel sums: wave 1 hands its tiles over through the rows' LDS, wave 0 adds and stores
+            __syncthreads();                                           // both are done with the rows
+            float* red = smem + lane;
+            if (w == 1) {
+#pragma unroll
+                for (int mt = 0; mt < kMaxMelTiles; ++mt)
+                    if (mt < p.nmt) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) red[(mt * 4 + i) * 64] = macc[mt][i];
+                    }
+            }
+            __syncthreads();
+            if (w == 0) {
+#pragma unroll
+                for (int mt = 0; mt < kMaxMelTiles; ++mt)
+                    if (mt < p.nmt) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) macc[mt][i] += red[(mt * 4 + i) * 64];
+                    }
+            }
+        }
+        if (!p.out_power && n < ud.n_rows && w == 0) {
             // mel^T tiles: rows = filters 16 mt + 4 kq + i, column = frame n: 16 bytes of one output row per lane
             float* orow = p.out + (ud.out0 + n) * p.n_mels + 4 * kq;
 #pragma unroll
@@ -267,7 +330,7 @@ template <int CH, bool I16, bool SEP>
 static af_status launch_k(const Params& p, int waves, int grid, hipStream_t stream)
 {
     auto kern = af_features_dft_kernel<CH, I16, SEP>;
-    const size_t smem = sizeof(float) * (size_t)p.tile_stride * (size_t)waves;
+    const size_t smem = sizeof(float) * (size_t)p.tile_stride;          // one unit's rows per workgroup, whatever its waves
     if (smem > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "features (DFT kernel): %zu bytes of LDS for one workgroup", smem);
     static LdsAttrFlags attr_set;
     AF_HIP(allow_big_lds(kern, 160 * 1024, attr_set));
@@ -279,7 +342,7 @@ static af_status launch_k(const Params& p, int waves, int grid, hipStream_t stre
 af_status launch(const Params& p, int channels, bool i16, bool separate, int waves, int grid, hipStream_t stream)
 {
     if (grid <= 0) return AF_OK;
-    if (!(waves == 1 || waves == 2 || waves == 4)) return fail(AF_ERR_INVALID_ARG, "features (DFT kernel): %d waves per workgroup", waves);
+    if (!(waves == 1 || waves == 2)) return fail(AF_ERR_INVALID_ARG, "features (DFT kernel): %d waves per workgroup", waves);
     if (p.nmt > kMaxMelTiles) return fail(AF_ERR_UNSUPPORTED, "features (DFT kernel): %d mel tiles (limit %d)", p.nmt, kMaxMelTiles);
     if (channels == 2 && !i16) return separate ? launch_k<2, false, true>(p, waves, grid, stream) : launch_k<2, false, false>(p, waves, grid, stream);
     if (channels == 1 && !i16) return launch_k<1, false, false>(p, waves, grid, stream);
