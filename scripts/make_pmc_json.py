@@ -45,6 +45,8 @@ copies = {"kernel_stats.txt": RT + "_kernel_stats.txt", "pmc_fetch.txt": RT + "_
           "pmc_wire_write.txt": RT + "_wire_pmc_write.txt", "pmc_wire_sq.txt": RT + "_wire_pmc_sq.txt", "pmc_wire_sq2.txt": RT + "_wire_pmc_sq2.txt",
           "wire_bench.json": RT + "_wire_bench.json", "wire_bench_messages320.json": RT + "_wire_bench_messages320.json",
           "wire_bench_i16.json": RT + "_wire_bench_i16.json", "chain44_kernel_stats.txt": RT + "_chain44_kernel_stats.txt",
+          "nfft_kernel_stats.txt": RT + "_nfft_kernel_stats.txt", "pmc_nfft_sq.txt": RT + "_nfft_pmc_sq.txt", "pmc_nfft_sq2.txt": RT + "_nfft_pmc_sq2.txt",
+          "nfft400.json": RT + "_nfft400.json", "nfft480.json": RT + "_nfft480.json",
           "chain44.txt": RT + "_chain44.txt",
           "v3_kernel_stats.txt": RT + "_v3_kernel_stats.txt", "pmc_v3_fetch.txt": RT + "_v3_pmc_fetch.txt",
           "pmc_v3_write.txt": RT + "_v3_pmc_write.txt", "pmc_v3_sq.txt": RT + "_v3_pmc_sq.txt", "pmc_v3_sq2.txt": RT + "_v3_pmc_sq2.txt"}
@@ -140,7 +142,7 @@ res = {
     "formulas": "lds = SQ_LDS_IDX_ACTIVE / 256 CUs; valu = SQ_INSTS_VALU x 2 cycles / 1024 SIMDs; mfma = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; all over GRBM_GUI_ACTIVE / 8 XCDs of the profiled launch",
     "source": ["profiles/" + RT + "_pmc_sq.txt", "profiles/" + RT + "_pmc_sq2.txt"],
     "note": "recorded by separate rocprofv3 --pmc passes (scripts/profile_r%02d.sh), not measured by the bench run that quotes it" % ROUND,
-    "in_kernel_clock_GHz": 2.14, "in_kernel_clock_note": "s_memtime / s_memrealtime inside the product kernel (AF_V2_CLK builds, profiles/r05_v2_ablations.txt): 2.11-2.16 GHz against 2.38 GHz for builds with a large piece left out -- the launch is power-limited",
+    "in_kernel_clock_GHz": 1.97, "in_kernel_clock_note": "s_memtime / s_memrealtime inside the product kernel (AF_V2_CLK builds, profiles/r05_v2_ablations.txt section 5): 1.97-1.98 GHz with the mel phase on 4 x 4 x 1 blocks (2.10-2.16 GHz with the 16 x 16 x 4 tiles of rounds 2-4) against 2.38 GHz for builds with a large piece left out -- the launch is power-limited",
 }
 # the matrix-core DFT kernel (opt-in) on the same workload, same formulas
 old_res = json.load(open(os.path.join(dst, "pmc_resources.json"))) if os.path.exists(os.path.join(dst, "pmc_resources.json")) else {}
