@@ -168,6 +168,7 @@ SIGNATURES = {
     "af_features_mel_weights": (_st, [_vp, _vp, _sz]),
     "af_features_kernel_name": (C.c_char_p, []),
     "af_features_plan_describe": (C.c_int, [_vp, _vp]),
+    "af_features_kernel_describe": (C.c_int, [_vp, _vp]),
     "af_features_debug_stamps": (_st, [_vp, C.c_int, _vp]),
     # full chain
     "af_stft_default_config": (None, [C.POINTER(StftConfig)]),

@@ -1235,6 +1235,21 @@ af_status af_features_set_option(af_features* p, const char* key, int value)
     return AF_OK;
 }
 
+int af_features_kernel_describe(const af_features* p, int32_t* info)
+{
+    if (!p || !info) return 0;
+    for (int i = 0; i < 12; ++i) info[i] = 0;
+    info[0] = p->dft ? 4 : (p->cfg.hop == (uint32_t)v2::kHop && (p->plan8.n_waves == v2::kW || p->dense_mel)) ? 2 : 1;
+    info[1] = p->plan4.ok ? 1 : 0;
+    info[2] = p->plan4.quads[0]; info[3] = p->plan4.quads[1];
+    info[4] = p->plan4.n_pieces[0]; info[5] = p->plan4.n_pieces[1];
+    if (p->dft) {
+        info[6] = p->dft_kg; info[7] = p->dft_nb; info[8] = p->dft_nmt; info[9] = p->dft_waves;
+        info[10] = (int32_t)((size_t)p->dft_tile_stride * sizeof(float));
+    }
+    return 1;
+}
+
 int af_features_plan_describe(const af_features* p, int32_t* info)
 {
     if (!p || !info) return 0;

@@ -346,6 +346,12 @@ const char* af_features_kernel_name(void);
  * slots of wave 0..7} of the hop-256 kernel, then that kernel's per-slot group ends [8 waves][8 slots]
  * (0: the group continues; else 0x10000 | filters << 8 | first filter) */
 int       af_features_plan_describe(const af_features* p, int32_t* info);
+/* diagnostics, host only: which kernel family serves the handle and the shape of its round-5 plans, info[12] =
+ * {family (1 general fused kernel, 2 hop-256 register-FFT kernel, 4 matrix-product DFT kernel for n_fft other than
+ *  1024 / 512 / 256), mel phase on 4 x 4 x 1 blocks available (0 / 1), its 4-step quads of group 0 and 1, its
+ *  block pieces of group 0 and 1, then for family 4: K groups of 16 folded samples, bin tiles, mel tiles, waves per
+ *  workgroup, LDS bytes per workgroup, 0}; returns 1 */
+int       af_features_kernel_describe(const af_features* p, int32_t* info);
 /* diagnostics: enable/disable in-kernel phase stamps; out[32] (optional) receives the
  * [wave][phase] shader-cycle sums recorded since they were enabled */
 af_status af_features_debug_stamps(af_features* p, int enable, unsigned long long* out);

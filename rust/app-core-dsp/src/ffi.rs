@@ -121,6 +121,8 @@ extern "C" {
     pub fn af_features_run(p: *mut af_features, pcm: *const c_void, pcm_len: usize, mel: *mut f32, mel_cap: usize) -> af_status;
     pub fn af_features_run_device(p: *mut af_features, pcm_dev: *const c_void, mel_dev: *mut f32, stream: *mut c_void) -> af_status;
     pub fn af_features_mel_weights(p: *const af_features, w: *mut f32, cap: usize) -> af_status;
+    /// diagnostics: kernel family (1 general, 2 hop-256 register FFT, 4 matrix-product DFT) and the shape of its plans, info[12]
+    pub fn af_features_kernel_describe(p: *const af_features, info: *mut i32) -> c_int;
     pub fn af_pipeline_run(batch: *const af_batch_desc, pcm: *const c_void, pcm_len: usize, out: *mut f32, out_cap: usize, total_rows_out: *mut usize) -> af_status;
     // Stft / MelFilterbank (docs/OPS.md)
     pub fn af_stft_default_config(cfg: *mut af_stft_config);

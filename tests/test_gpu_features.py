@@ -386,3 +386,29 @@ def test_hop256_mel_plans_agree(af, po, kw):
                 assert frame_rel_err(o[row:row + ref.shape[0]], ref) < TOL
         row += ref.shape[0]
     assert row == out[0].shape[0]
+
+
+def test_kernel_describe_names_the_family_and_the_round5_plans(af):
+    """`af_features_kernel_describe`: which kernel family serves a handle and the shape of the 4 x 4 x 1 mel plan / the
+    matrix-product DFT's tables -- the documented cases (DESIGN.md sections 6 and 6g)."""
+    import ctypes as C
+    lib = af.library()
+
+    def describe(**kw):
+        p = af.FeaturePipeline(**kw)
+        info = (C.c_int32 * 12)()
+        assert lib.af_features_kernel_describe(p._h, info) == 1
+        return list(info)
+
+    d = describe()                                               # BASELINE config 2's handle
+    assert d[0] == 2 and d[1] == 1 and d[2] == 8 and d[3] == 8 and 16 >= d[4] >= 10 and 16 >= d[5] >= 10
+    d = describe(sample_rate=16000, n_mels=64)
+    assert d[0] == 2 and d[1] == 1 and d[2] <= 8 and d[3] <= 8
+    assert describe(n_mels=40)[:2] == [2, 0]                     # too few, too wide bands for 16 blocks at 32 steps: 16 x 16 x 4 tiles
+    assert describe(sample_rate=44100, n_mels=128)[:2] == [2, 0]
+    assert describe(n_mels=23, sample_rate=8000)[1] == 0         # not a multiple of 4
+    assert describe(hop=160)[0] == 1                             # the general fused kernel
+    d = describe(sample_rate=16000, channels=1, n_fft=400, hop=160)
+    assert d[0] == 4 and d[1] == 0 and d[6:10] == [13, 13, 5, 2] and d[10] == 16 * (2 * 16 * 13 + 8) * 4
+    d = describe(sample_rate=16000, channels=1, n_fft=100, hop=64)
+    assert d[0] == 4 and d[6] == 4                               # at least four K groups (the kernel walks chunks of four)
