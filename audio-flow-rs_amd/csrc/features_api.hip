@@ -84,6 +84,13 @@ struct af_features {
     int dft_kg = 0, dft_nb = 0, dft_nmt = 0, dft_row_stride = 0, dft_tile_stride = 0, dft_waves = 1;
 };
 
+// folded-row padding of the matrix-product DFT kernel in dwords: 8 is the conflict-free stride of its 16-byte LDS reads, 4
+// leaves one two-way conflict per read (measured: no difference in time) and brings 400 / 160 from 22 to 21 LDS granules of
+// 1 280 bytes per workgroup, i.e. from five to six workgroups per CU (1.74 against 1.89 ms)
+#ifndef AF_DFT_PAD
+#define AF_DFT_PAD 4
+#endif
+
 namespace {
 
 constexpr double kPi = 3.14159265358979323846;
@@ -370,11 +377,11 @@ af_status build_dft(af_features* p)
     p->W.clear();                                       // (the 513-bin grid means nothing here)
     p->dft = true;
     p->dft_kg = kg; p->dft_nb = nb; p->dft_nmt = nmt;
-    p->dft_row_stride = 2 * 16 * kg + 8;               // E | O | pad: 8 (mod 16) dwords, the conflict-free stride of the b128 reads
+    p->dft_row_stride = 2 * 16 * kg + (AF_DFT_PAD);    // E | O | pad
     p->dft_tile_stride = 16 * p->dft_row_stride;
     // two waves per workgroup share a unit's rows (27 KB for 400 / 160): four workgroups per CU = two waves per SIMD, each
     // hiding the other's waits.  (One wave per unit, rows private: 2.13 ms on 256 x 30 s of 400 / 160 with one wave per SIMD --
-    // the LDS holds no more -- against 1.93 ms in this shape.)
+    // the LDS holds no more -- against 1.74 ms in this shape at six workgroups per CU.)
     const size_t per_wg = (size_t)p->dft_tile_stride * sizeof(float);
     if (per_wg > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "features: n_fft %u needs %zu bytes of LDS per workgroup", c.n_fft, per_wg);
     p->dft_waves = 2;
@@ -914,8 +921,15 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         q.stamps = p->d_stamps.as<unsigned long long>();
         const size_t smem = (size_t)p->dft_tile_stride * sizeof(float);
         // (at most two waves per SIMD: the kernel holds more than 128 registers)
-        int per_cu = (int)((160 * 1024) / smem);
-        if (per_cu > 8 / p->dft_waves) per_cu = 8 / p->dft_waves;
+        // (LDS is handed out in granules of 1 280 bytes: 128 per CU)
+        const size_t alloc = (smem + 1279) / 1280 * 1280;
+        int per_cu = (int)((160 * 1024) / alloc);
+        const int max_waves = p->dft_nmt <= 5 ? 12 : 8;              // (the 5-tile instance holds 160 registers: three waves per SIMD)
+        if (per_cu > max_waves / p->dft_waves) per_cu = max_waves / p->dft_waves;
+        // (whole waves per SIMD: five two-wave workgroups put ten waves on four SIMDs and every wave carries the same number
+        // of units -- 1.97 ms against 1.89 with four on 400 / 160)
+        if (p->dft_waves == 2 && per_cu > 2 && (per_cu & 1)) per_cu -= 1;
+        if (p->opt_wg_per_cu > 0 && (size_t)p->opt_wg_per_cu * smem <= 160 * 1024) per_cu = p->opt_wg_per_cu;   // (diagnostics)
         if (per_cu < 1) per_cu = 1;
         int64_t grid = (int64_t)p->n_cus * per_cu;
         if (grid > u_count) grid = u_count;

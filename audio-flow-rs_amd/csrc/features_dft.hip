@@ -48,8 +48,8 @@ __device__ __forceinline__ UnitDesc load_unit(const UnitDesc* units, int64_t u)
     return d;
 }
 
-template <int CH, bool I16, bool SEP>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void af_features_dft_kernel(const Params p)
+template <int CH, bool I16, bool SEP, int NMT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 3 : 2))) void af_features_dft_kernel(const Params p)
 {
     using St = Stage<CH, I16>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -57,9 +57,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int nw = (int)blockDim.x >> 6;                                // 2: the waves of a workgroup share one unit (1: diagnostics)
     const int n = lane & 15, kq = lane >> 4;
-    // folded rows, one per frame: E [16 kg] | O [16 kg] | 8 floats of padding.  The row stride is 8 (mod 16) dwords: the
-    // 16-lane groups of a ds_read_b128 ({n 0-3, 12-15 of kq} + {n 4-11 of kq + 1}, features.hpp) then cover all 16
-    // 16-byte slots -- at a stride of 0 (mod 16) every read was four-way conflicted
+    // folded rows, one per frame: E [16 kg] | O [16 kg] | padding.  At a row stride of 0 (mod 16) dwords every ds_read_b128
+    // is four-way conflicted; 8 (mod 16) is conflict-free (its 16-lane groups, {n 0-3, 12-15 of kq} + {n 4-11 of kq + 1},
+    // features.hpp, then cover all 16 sixteen-byte slots); 4 (mod 16), the host's choice, leaves one two-way slot per read
+    // and fits one more workgroup on the CU (features_api.hip, AF_DFT_PAD)
     float* rows = smem;
     const int rs = p.row_stride, nh = p.nh, N = p.n_fft;
     const int kpad = 16 * p.kg;                                        // entries of E (and of O) the products read (zero behind nh)
@@ -135,9 +136,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             s_t1 = __builtin_amdgcn_s_memtime();
         }
-        f32x4 macc[kMaxMelTiles];
+        f32x4 macc[NMT];
 #pragma unroll
-        for (int mt = 0; mt < kMaxMelTiles; ++mt) macc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < NMT; ++mt) macc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // One flat walk over (bin tile, K group) in chunks of kChunk groups; the fragment stream is contiguous in that order.
         // Fragments are double-buffered by CHUNK: all loads of chunk c + 1 go out, unconditionally (clamped index), at the
@@ -170,9 +171,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
             }
         };
         request(bufA);
-        float4 wfm[kMaxMelTiles];
+        float4 wfm[NMT];
 #pragma unroll
-        for (int mt = 0; mt < kMaxMelTiles; ++mt) wfm[mt] = float4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < NMT; ++mt) wfm[mt] = float4{0.f, 0.f, 0.f, 0.f};
         uint32_t mask = (p.out_power || nt_w == 0) ? 0u : p.wmask[first];   // of the bin tile in progress (scalar, a tile ahead)
         f32x4 are = {0.f, 0.f, 0.f, 0.f}, aim = {0.f, 0.f, 0.f, 0.f};
         int g = 0, bt = first;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
             const bool ends = g + kChunk >= p.kg;                      // a bin tile ends inside this chunk
             if (ends && !p.out_power) {
 #pragma unroll
-                for (int mt = 0; mt < kMaxMelTiles; ++mt)
+                for (int mt = 0; mt < NMT; ++mt)
                     if (mt < p.nmt && ((mask >> mt) & 1u)) wfm[mt] = wfb[((size_t)bt * p.nmt + mt) * 64];
             }
             if constexpr (!(AF_DFT_ABL & 1)) request(nxt);
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
                     }
                 } else {
 #pragma unroll
-                    for (int mt = 0; mt < kMaxMelTiles; ++mt) {
+                    for (int mt = 0; mt < NMT; ++mt) {
                         if (mt < p.nmt && ((mask >> mt) & 1u)) {
                             const float4 a = wfm[mt];
                             macc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, pw[0], macc[mt], 0, 0, 0);
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
             float* red = smem + lane;
             if (w == 1) {
 #pragma unroll
-                for (int mt = 0; mt < kMaxMelTiles; ++mt)
+                for (int mt = 0; mt < NMT; ++mt)
                     if (mt < p.nmt) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) red[(mt * 4 + i) * 64] = macc[mt][i];
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
             __syncthreads();
             if (w == 0) {
 #pragma unroll
-                for (int mt = 0; mt < kMaxMelTiles; ++mt)
+                for (int mt = 0; mt < NMT; ++mt)
                     if (mt < p.nmt) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) macc[mt][i] += red[(mt * 4 + i) * 64];
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
             // mel^T tiles: rows = filters 16 mt + 4 kq + i, column = frame n: 16 bytes of one output row per lane
             float* orow = p.out + (ud.out0 + n) * p.n_mels + 4 * kq;
 #pragma unroll
-            for (int mt = 0; mt < kMaxMelTiles; ++mt) {
+            for (int mt = 0; mt < NMT; ++mt) {
                 if (mt < p.nmt) {
                     f32x4 r = macc[mt];
                     if (p.log_mel) {
@@ -326,10 +327,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
 }
 
-template <int CH, bool I16, bool SEP>
-static af_status launch_k(const Params& p, int waves, int grid, hipStream_t stream)
+template <int CH, bool I16, bool SEP, int NMT>
+static af_status launch_kn(const Params& p, int waves, int grid, hipStream_t stream)
 {
-    auto kern = af_features_dft_kernel<CH, I16, SEP>;
+    auto kern = af_features_dft_kernel<CH, I16, SEP, NMT>;
     const size_t smem = sizeof(float) * (size_t)p.tile_stride;          // one unit's rows per workgroup, whatever its waves
     if (smem > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "features (DFT kernel): %zu bytes of LDS for one workgroup", smem);
     static LdsAttrFlags attr_set;
@@ -337,6 +338,14 @@ static af_status launch_k(const Params& p, int waves, int grid, hipStream_t stre
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), smem, stream, p);
     AF_HIP(hipGetLastError());
     return AF_OK;
+}
+
+// (two instances by mel tiles: 80 mels = 5 tiles of 16 leave 24 registers to the rest of the kernel)
+template <int CH, bool I16, bool SEP>
+static af_status launch_k(const Params& p, int waves, int grid, hipStream_t stream)
+{
+    if (p.nmt <= 5) return launch_kn<CH, I16, SEP, 5>(p, waves, grid, stream);
+    return launch_kn<CH, I16, SEP, kMaxMelTiles>(p, waves, grid, stream);
 }
 
 af_status launch(const Params& p, int channels, bool i16, bool separate, int waves, int grid, hipStream_t stream)

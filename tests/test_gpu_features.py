@@ -409,6 +409,6 @@ def test_kernel_describe_names_the_family_and_the_round5_plans(af):
     assert describe(n_mels=23, sample_rate=8000)[1] == 0         # not a multiple of 4
     assert describe(hop=160)[0] == 1                             # the general fused kernel
     d = describe(sample_rate=16000, channels=1, n_fft=400, hop=160)
-    assert d[0] == 4 and d[1] == 0 and d[6:10] == [13, 13, 5, 2] and d[10] == 16 * (2 * 16 * 13 + 8) * 4
+    assert d[0] == 4 and d[1] == 0 and d[6:10] == [13, 13, 5, 2] and d[10] == 16 * (2 * 16 * 13 + 4) * 4
     d = describe(sample_rate=16000, channels=1, n_fft=100, hop=64)
     assert d[0] == 4 and d[6] == 4                               # at least four K groups (the kernel walks chunks of four)
