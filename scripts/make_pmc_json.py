@@ -45,7 +45,7 @@ copies = {"kernel_stats.txt": RT + "_kernel_stats.txt", "pmc_fetch.txt": RT + "_
           "pmc_wire_write.txt": RT + "_wire_pmc_write.txt", "pmc_wire_sq.txt": RT + "_wire_pmc_sq.txt", "pmc_wire_sq2.txt": RT + "_wire_pmc_sq2.txt",
           "wire_bench.json": RT + "_wire_bench.json", "wire_bench_messages320.json": RT + "_wire_bench_messages320.json",
           "wire_bench_i16.json": RT + "_wire_bench_i16.json", "chain44_kernel_stats.txt": RT + "_chain44_kernel_stats.txt",
-          "nfft_kernel_stats.txt": RT + "_nfft_kernel_stats.txt", "pmc_nfft_sq.txt": RT + "_nfft_pmc_sq.txt", "pmc_nfft_sq2.txt": RT + "_nfft_pmc_sq2.txt",
+          "nfft_kernel_stats.txt": RT + "_nfft_kernel_stats.txt", "pmc_nfft_fetch.txt": RT + "_nfft_pmc_fetch.txt", "pmc_nfft_write.txt": RT + "_nfft_pmc_write.txt", "pmc_nfft_sq.txt": RT + "_nfft_pmc_sq.txt", "pmc_nfft_sq2.txt": RT + "_nfft_pmc_sq2.txt",
           "nfft400.json": RT + "_nfft400.json", "nfft480.json": RT + "_nfft480.json",
           "chain44.txt": RT + "_chain44.txt",
           "v3_kernel_stats.txt": RT + "_v3_kernel_stats.txt", "pmc_v3_fetch.txt": RT + "_v3_pmc_fetch.txt",
@@ -121,6 +121,18 @@ if wf and ww:
                                 "hbm_read_bytes_per_launch": int(r_), "hbm_write_bytes_per_launch": int(w_), "hbm_bytes_per_launch": int(r_ + w_),
                                 "algorithmic_bytes_per_launch": algw, "traffic_over_algorithmic": round((r_ + w_) / algw, 4),
                                 "source": ["profiles/" + RT + "_wire_pmc_fetch.txt", "profiles/" + RT + "_wire_pmc_write.txt"]}
+# the speech framing on the matrix-product DFT kernel (compute-bound: the figure shows that the 2.5 x overlap of the frames and the
+# fragment stream stay in the caches)
+nf, nw_ = table("pmc_nfft_fetch.txt"), table("pmc_nfft_write.txt")
+if nf and nw_:
+    k, v = first(nf, "af_features_dft")
+    r_ = v["FETCH_SIZE"] * 1024 / cal_f
+    w_ = first(nw_, "af_features_dft")[1]["WRITE_SIZE"] * 1024 / cal_w
+    algn = 256 * 480000 * 4 + 256 * 2998 * 80 * 4
+    traffic["speech_nfft400_256x30s"] = {"workload": "256 x 30 s mono 16 kHz f32 -> STFT 400 / 160 -> 80 mel, one launch", "kernel": k,
+                                         "hbm_read_bytes_per_launch": int(r_), "hbm_write_bytes_per_launch": int(w_), "hbm_bytes_per_launch": int(r_ + w_),
+                                         "algorithmic_bytes_per_launch": algn, "traffic_over_algorithmic": round((r_ + w_) / algn, 4),
+                                         "source": ["profiles/" + RT + "_nfft_pmc_fetch.txt", "profiles/" + RT + "_nfft_pmc_write.txt"]}
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
 # ---- the other resources of the headline kernel (HBM fraction AND VALU / MFMA / LDS fractions)

@@ -74,6 +74,8 @@ echo "chain 44.1 done"
 N="python3 scripts/gpu_bench_nfft.py --reps 20"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/nfft_kt" -- $N > "$O/nfft_kt.log" 2>&1
 python3 scripts/summarize_prof.py kernel_stats "$O/nfft_kt" "$O/nfft_kernel_stats.txt" "af_|af::" > /dev/null
+pmc nfft_fetch af_features_dft "FETCH_SIZE" python3 scripts/gpu_bench_nfft.py --reps 3
+pmc nfft_write af_features_dft "WRITE_SIZE" python3 scripts/gpu_bench_nfft.py --reps 3
 pmc nfft_sq af_features_dft "$SQ1" python3 scripts/gpu_bench_nfft.py --reps 3
 pmc nfft_sq2 af_features_dft "$SQ2" python3 scripts/gpu_bench_nfft.py --reps 3
 python3 scripts/gpu_bench_nfft.py --reps 30 --stamps --json "$O/nfft400.json" > /dev/null

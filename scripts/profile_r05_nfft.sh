@@ -1,3 +1,6 @@
+#!/bin/bash
+# The matrix-product DFT kernel's part of scripts/profile_r05.sh alone (run on the GPU box through gpurun): kernel trace, FETCH / WRITE /
+# SQ counter passes (never combined with a trace), the bench lines with the in-kernel stamps.  Output: gpurun_out/r05p/nfft_*.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O="$GRAFT_REPO_ROOT/gpurun_out/r05p"; mkdir -p "$O"
@@ -11,6 +14,8 @@ pmc() { local d="$1" rx="$2" c="$3"; shift 3
 rm -rf "$O/nfft_kt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/nfft_kt" -- python3 scripts/gpu_bench_nfft.py --reps 20 > "$O/nfft_kt.log" 2>&1
 python3 scripts/summarize_prof.py kernel_stats "$O/nfft_kt" "$O/nfft_kernel_stats.txt" "af_|af::" > /dev/null
+pmc nfft_fetch af_features_dft "FETCH_SIZE" python3 scripts/gpu_bench_nfft.py --reps 3
+pmc nfft_write af_features_dft "WRITE_SIZE" python3 scripts/gpu_bench_nfft.py --reps 3
 pmc nfft_sq af_features_dft "$SQ1" python3 scripts/gpu_bench_nfft.py --reps 3
 pmc nfft_sq2 af_features_dft "$SQ2" python3 scripts/gpu_bench_nfft.py --reps 3
 python3 scripts/gpu_bench_nfft.py --reps 30 --stamps --json "$O/nfft400.json"
