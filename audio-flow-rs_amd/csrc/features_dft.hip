@@ -21,6 +21,11 @@
 #endif
 // (experiment) where the next group's LDS reads and the bookkeeping go: 0 a full scheduling barrier behind the reads,
 // 1 the compiler's choice, 2 a sched_group_barrier pattern
+// (experiment) 0: a tile's first matrix instructions take a zero C operand (a branch per group); 1: the accumulators are zeroed
+// where a tile ends
+#ifndef AF_DFT_ZERO
+#define AF_DFT_ZERO 0
+#endif
 #ifndef AF_DFT_SCHED
 #define AF_DFT_SCHED 0
 #endif
@@ -157,17 +162,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 
         const float4* fr = reinterpret_cast<const float4*>(p.tfrag) + lane;
         const float4* wfb = reinterpret_cast<const float4*>(p.wfrag) + lane;
         float4 bufA[2 * kChunk], bufB[2 * kChunk];
-        const int q_max = p.nb * p.kg - 1;
-        int rt = 0, rg = 0;                                            // request cursor: (index among this wave's tiles, K group)
+        // request cursor: a running group index into the table (no multiplications per load), stepping over the partner's
+        // tiles at a tile end and standing still on this wave's last group (the loads stay unconditional)
+        int rq = first * p.kg < p.nb * p.kg ? first * p.kg : p.nb * p.kg - 1, rg = 0;
+        int r_left = nt_w * p.kg;                                      // groups of this wave not yet requested
+        const int r_skip = (nw - 1) * p.kg;
         const auto request = [&](float4 (&buf)[2 * kChunk]) {
 #pragma unroll
             for (int d = 0; d < kChunk; ++d) {
-                const int t_c = rt < nt_w ? rt : (nt_w > 0 ? nt_w - 1 : 0);   // (behind the end: the last tile's groups again, unconditional loads)
-                int qn = (first + nw * t_c) * p.kg + rg;
-                if (qn > q_max) qn = q_max;
-                buf[2 * d] = fr[(size_t)(2 * qn) * 64];
-                buf[2 * d + 1] = fr[(size_t)(2 * qn + 1) * 64];
-                if (++rg == p.kg) { rg = 0; ++rt; }
+                const float4* g0 = fr + (size_t)rq * 128;              // [group][cos, -sin][64 lanes]
+                buf[2 * d] = g0[0];
+                buf[2 * d + 1] = g0[64];
+                if (r_left > 1) {
+                    --r_left;
+                    ++rq;
+                    if (++rg == p.kg) { rg = 0; rq += r_skip; }
+                }
             }
         };
         request(bufA);
@@ -204,11 +214,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 
                 }
                 // a tile's first products start from zero (no write to the accumulators outside the matrix pipe: a
                 // v_mov between two of its instructions waits out the first one's latency)
+#if AF_DFT_ZERO == 0
                 if (g == 0) {                                          // wave-uniform
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.x, be.x, z, 0, 0, 0);
                     aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.x, bo.x, z, 0, 0, 0);
-                } else {
+                } else
+#endif
+                {
                     are = __builtin_amdgcn_mfma_f32_16x16x4f32(cr.x, be.x, are, 0, 0, 0);
                     aim = __builtin_amdgcn_mfma_f32_16x16x4f32(ci.x, bo.x, aim, 0, 0, 0);
                 }
@@ -233,6 +246,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 
                 if (++g == p.kg) {                                     // the bin tile is complete (the padding groups never get here)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) pw[i] = __builtin_fmaf(are[i], are[i], aim[i] * aim[i]);
+#if AF_DFT_ZERO == 1
+                    are = f32x4{0.f, 0.f, 0.f, 0.f};
+                    aim = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
                     g = 0;
                     done = true;
                 }
