@@ -24,10 +24,10 @@
 // (experiment) 0: a tile's first matrix instructions take a zero C operand (a branch per group); 1: the accumulators are zeroed
 // where a tile ends
 #ifndef AF_DFT_ZERO
-#define AF_DFT_ZERO 0
+#define AF_DFT_ZERO 1
 #endif
 #ifndef AF_DFT_SCHED
-#define AF_DFT_SCHED 0
+#define AF_DFT_SCHED 1
 #endif
 
 namespace af {
