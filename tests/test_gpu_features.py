@@ -412,3 +412,27 @@ def test_kernel_describe_names_the_family_and_the_round5_plans(af):
     assert d[0] == 4 and d[1] == 0 and d[6:10] == [13, 13, 5, 2] and d[10] == 16 * (2 * 16 * 13 + 4) * 4
     d = describe(sample_rate=16000, channels=1, n_fft=100, hop=64)
     assert d[0] == 4 and d[6] == 4                               # at least four K groups (the kernel walks chunks of four)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_mels=40), dict(sample_rate=16000, channels=1, n_fft=400, hop=160), dict(hop=160)],
+                         ids=["hop256-mel4", "hop256-tiles", "dft-400", "general"])
+def test_output_rows_at_a_pointer_that_is_only_4_byte_aligned(af, kw):
+    """`af_features_run_device` with a row buffer that starts 4 bytes off a 16-byte boundary: the kernels fall back from their
+    16-byte stores to single floats; same rows, nothing written in front of or behind them."""
+    import torch
+    dev = torch.device("cuda:0")
+    ch, sr = kw.get("channels", 2), kw.get("sample_rate", 48000)
+    n = 40000
+    x = torch.from_numpy(synth_clip(91, n, ch, sr)).to(dev)
+    pipe = af.FeaturePipeline(**kw)
+    total = pipe.set_batch_uniform(1, n)
+    nm = kw.get("n_mels", 80)
+    s = torch.cuda.current_stream().cuda_stream
+    ref = torch.empty(total, nm, device=dev)
+    pipe.run_device(x.data_ptr(), ref.data_ptr(), s)
+    buf = torch.full((total * nm + 8,), -7.0, device=dev)
+    pipe.run_device(x.data_ptr(), buf.data_ptr() + 4, s)
+    torch.cuda.synchronize()
+    got = buf[1:1 + total * nm].reshape(total, nm)
+    assert bits_equal(got.cpu().numpy(), ref.cpu().numpy())
+    assert float(buf[0]) == -7.0 and bool((buf[1 + total * nm:] == -7.0).all())
