@@ -117,6 +117,7 @@ struct Plan4 {
     bool ok = false;
     int quads[2] = {0, 0};                // steps / 4 per group
     int n_pieces[2] = {0, 0};
+    int read_conflict_score[2] = {0, 0};  // 16-byte LDS slots two lanes of a read group share, after the arrangement search (0: conflict-free)
 };
 
 af_status launch(const Params& p, int channels, bool i16, bool separate, int grid, hipStream_t stream);

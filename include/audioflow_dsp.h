@@ -350,7 +350,8 @@ int       af_features_plan_describe(const af_features* p, int32_t* info);
  * {family (1 general fused kernel, 2 hop-256 register-FFT kernel, 4 matrix-product DFT kernel for n_fft other than
  *  1024 / 512 / 256), mel phase on 4 x 4 x 1 blocks available (0 / 1), its 4-step quads of group 0 and 1, its
  *  block pieces of group 0 and 1, then for family 4: K groups of 16 folded samples, bin tiles, mel tiles, waves per
- *  workgroup, LDS bytes per workgroup, 0}; returns 1 */
+ *  workgroup, LDS bytes per workgroup; last: the 4 x 4 x 1 plan's LDS read-conflict score (slots shared inside a read group)};
+ * returns 1 */
 int       af_features_kernel_describe(const af_features* p, int32_t* info);
 /* diagnostics: enable/disable in-kernel phase stamps; out[32] (optional) receives the
  * [wave][phase] shader-cycle sums recorded since they were enabled */
