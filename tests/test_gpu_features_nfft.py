@@ -146,3 +146,30 @@ def test_whisper_shaped_batch_at_size(af, po):
         assert frame_rel_err(m[i], po.features(base[i], 1, 16000.0, n_fft=400, hop=160)) < TOL
     for c in range(3, clips):
         assert bits_equal(m[c], m[c % 3])
+
+
+def test_one_and_two_waves_per_unit_agree(af, po):
+    """`af_features_set_option(h, "dft_waves", 1)`: one wave multiplies every bin tile of a unit instead of two waves taking
+    every other one (their partial mel sums meet in LDS): same rows within float32 summation order, both inside the tolerance;
+    power rows (no sums across waves) bit for bit."""
+    lib = af.library()
+    kw = dict(sample_rate=16000, channels=1, n_fft=400, hop=160)
+    x = synth_clip(33, 16000 * 2 + 55, 1, 16000)
+    ref = po.features(x, 1, 16000.0, n_fft=400, hop=160)
+    rows = []
+    for waves in (2, 1):
+        p = af.FeaturePipeline(**kw)
+        assert lib.af_features_set_option(p._h, b"dft_waves", waves) == 0
+        p.set_batch_uniform(1, x.size)
+        rows.append(p.run(x))
+        assert frame_rel_err(rows[-1], ref) < TOL
+    assert frame_rel_err(rows[0], np.asarray(rows[1], np.float64)) < 2e-6
+    pw = []
+    for waves in (2, 1):
+        p = af.FeaturePipeline(output=af._ffi.AF_OUT_POWER, **kw)
+        assert lib.af_features_set_option(p._h, b"dft_waves", waves) == 0
+        p.set_batch_uniform(1, x.size)
+        pw.append(p.run(x))
+    assert bits_equal(pw[0], pw[1])
+    # the option belongs to handles this kernel serves
+    assert lib.af_features_set_option(af.FeaturePipeline()._h, b"dft_waves", 1) == af._ffi.AF_ERR_INVALID_ARG
