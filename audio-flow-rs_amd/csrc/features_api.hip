@@ -637,7 +637,7 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     // (the matrix-product DFT kernel walks the same records with the handle's own hop and takes any alignment)
     const int64_t unit_hop = p->dft ? (int64_t)p->cfg.hop : (int64_t)v2::kHop;
     if (p->dft && p->total_units >= (1ll << 31)) return fail(AF_ERR_UNSUPPORTED, "features: more than 2^31 units in one batch");
-    if (((v2_ok || v3_possible) && aligned4 || p->dft) && p->total_units > 0 && (p->dft || p->total_units < (1ll << 26))) {
+    if ((((v2_ok || v3_possible) && aligned4) || p->dft) && p->total_units > 0 && (p->dft || p->total_units < (1ll << 26))) {
         std::vector<v2::UnitDesc> units((size_t)p->total_units + 4);   // + zero records: the kernels read a unit ahead
         const bool sep = p->cfg.channel_mode == AF_CH_SEPARATE;
         size_t k = 0;
