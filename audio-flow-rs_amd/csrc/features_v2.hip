@@ -76,6 +76,10 @@
 #ifndef AF_V2_M4
 #define AF_V2_M4 0
 #endif
+// (experiment) start the workgroups staggered (s_sleep units of 64 cycles per step of blockIdx % 16); 0: together
+#ifndef AF_V2_STAGGER
+#define AF_V2_STAGGER 0
+#endif
 // issue priority of the kernel's waves outside their raised sections (experiment: 1 when it shares CUs with another kernel)
 #ifndef AF_V2_BASE_PRIO
 #define AF_V2_BASE_PRIO 0
@@ -582,6 +586,11 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         for (int q = 0; q < kLaneTw; ++q) asm volatile("" : "+v"(ltw[q]));
     }
 
+#if AF_V2_STAGGER
+    // (experiment) the workgroups start AF_V2_STAGGER x 64 x (blockIdx % 16) cycles apart: every workgroup walks the same phases
+    // in the same time, so the whole chip does its FFT arithmetic, then its mel phase, ... together
+    for (unsigned i = 0; i < (blockIdx.x & 15u); ++i) __builtin_amdgcn_s_sleep(AF_V2_STAGGER);
+#endif
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memtime() : 0;
     bool fresh = true;
