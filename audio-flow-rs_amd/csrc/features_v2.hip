@@ -76,6 +76,11 @@
 #ifndef AF_V2_M4
 #define AF_V2_M4 0
 #endif
+// (experiment, 4 x 4 x 1 mel instances) 1: the mel rows of a unit go through an LDS image [16][n_mels] and leave as one contiguous
+// run of 16-byte stores per thread (one more barrier per unit) instead of 320 separate 16-byte pieces
+#ifndef AF_V2_M4_STAGE
+#define AF_V2_M4_STAGE 0
+#endif
 // (experiment) start the workgroups staggered (s_sleep units of 64 cycles per step of blockIdx % 16); 0: together
 #ifndef AF_V2_STAGGER
 #define AF_V2_STAGGER 0
@@ -812,9 +817,23 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) r[i] = __log10f(fmaxf(r[i], 1e-10f));
             }
+#if AF_V2_M4_STAGE
+            {
+                float* stage = reinterpret_cast<float*>(lmeta + kW * kMaxSlotsW);
+                if ((l4o >> 17) & 1)
+                    *reinterpret_cast<float4*>(stage + fr * n_mels + 4 * ((l4o >> 10) & 127)) = float4{r[0], r[1], r[2], r[3]};
+                __syncthreads();
+                const int t0 = (w << 6) + lane_now();
+                if (t0 * 4 < ud.n_rows * n_mels)
+                    reinterpret_cast<float4*>(p.out + ud.out0 * n_mels)[t0] = reinterpret_cast<const float4*>(stage)[t0];
+            }
+            if (false) {
+                float* o = nullptr;
+#else
             if (((l4o >> 17) & 1) && fr < ud.n_rows) {                  // the band's first piece holds its sums
                 // uniform base + 32-bit lane offset
                 float* o = p.out + ud.out0 * n_mels + (unsigned)(fr * n_mels + 4 * ((l4o >> 10) & 127));
+#endif
                 if constexpr (AF_V2_M4 & 2) {
                     abl_use(r[0]); abl_use(r[1]); abl_use(r[2]); abl_use(r[3]);
                 } else
@@ -961,7 +980,7 @@ static af_status launch_m4(const Params& p, int grid, hipStream_t stream)
 {
     const int most = p.m4_quads[0] > p.m4_quads[1] ? p.m4_quads[0] : p.m4_quads[1];
     auto go = [&](auto kern) -> af_status {
-        constexpr size_t smem = sizeof(float) * kLdsFloats;
+        constexpr size_t smem = sizeof(float) * (kLdsFloats + (AF_V2_M4_STAGE ? 16 * 128 : 0));
         static LdsAttrFlags attr_set;
         AF_HIP(allow_big_lds(kern, (int)smem, attr_set));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kT), smem, stream, p);
