@@ -101,8 +101,59 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 
             };
             // (each wave builds the rows of half the frames: 16 loads in flight per entry with two waves)
             const int f_lo = nw == 2 ? 8 * w : 0;
+            bool done_wide = false;
+            if constexpr (!I16 && !(AF_DFT_ABL & 4)) {
+                // f32: a lane takes four consecutive entries of a frame -- 16-byte loads of samples n .. n + 3 and of their
+                // partners N - n - 3 .. N - n (two each for stereo; global loads only need dword alignment) -- and every load
+                // of the wave's half of the rows is in flight at once: the rows take one trip to HBM instead of four.  Frames
+                // that reach behind the end of the clip (wave-uniform test) take the element-wise path below.
+                const int J = kpad >> 2;                                // 16-byte pieces per row half
+                const int n_f = nw == 2 ? 8 : 16;
+                const int64_t last = (int64_t)(f_lo + n_f - 1) * p.hop + N;      // one behind the last sample these frames touch
+                if (last <= avail) {
+                    done_wide = true;
+                    const float* x0 = static_cast<const float*>(p.pcm) + ud.pcm0 * CH;
+                    for (int j = lane; j < J; j += 64) {               // (52 pieces per row half at 400: one pass, 16 loads per lane)
+                        for (int f0 = 0; f0 < n_f; f0 += 8) {
+                            float4 a4[8], b4[8];
+#pragma unroll
+                            for (int f = 0; f < 8; ++f) {
+                                const float* xf = x0 + (int64_t)(f_lo + f0 + f) * p.hop * CH;
+                                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                                if constexpr (CH == 1) {
+                                    const f4u av = *reinterpret_cast<const f4u*>(xf + 4 * j + 1);
+                                    const f4u bv = *reinterpret_cast<const f4u*>(xf + N - 4 * j - 4);
+                                    a4[f] = float4{av[0], av[1], av[2], av[3]};
+                                    b4[f] = float4{bv[3], bv[2], bv[1], bv[0]};   // partner of sample n + i is N - n - i
+                                } else {
+                                    const f4u a0 = *reinterpret_cast<const f4u*>(xf + 2 * (4 * j + 1)), a1 = *reinterpret_cast<const f4u*>(xf + 2 * (4 * j + 3));
+                                    const f4u b0 = *reinterpret_cast<const f4u*>(xf + 2 * (N - 4 * j - 4)), b1 = *reinterpret_cast<const f4u*>(xf + 2 * (N - 4 * j - 2));
+                                    const auto mix = [&](float l, float r) { return sel < 0 ? (l + r) * 0.5f : sel ? r : l; };   // to_mono (capture.rs:30-42) / one channel
+                                    a4[f] = float4{mix(a0[0], a0[1]), mix(a0[2], a0[3]), mix(a1[0], a1[1]), mix(a1[2], a1[3])};
+                                    b4[f] = float4{mix(b1[2], b1[3]), mix(b1[0], b1[1]), mix(b0[2], b0[3]), mix(b0[0], b0[1])};
+                                }
+                            }
+#pragma unroll
+                            for (int f = 0; f < 8; ++f) {
+                                const float av[4] = {a4[f].x, a4[f].y, a4[f].z, a4[f].w}, bv[4] = {b4[f].x, b4[f].y, b4[f].z, b4[f].w};
+                                float e[4], o[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int k = 4 * j + i, nn = k + 1;
+                                    const bool pair = k < nh, self = (N - nn == nn);
+                                    e[i] = !pair ? 0.0f : self ? av[i] : av[i] + bv[i];
+                                    o[i] = (!pair || self) ? 0.0f : av[i] - bv[i];
+                                }
+                                float* er = rows + (f_lo + f0 + f) * rs + 4 * j;
+                                *reinterpret_cast<float4*>(er) = float4{e[0], e[1], e[2], e[3]};
+                                *reinterpret_cast<float4*>(er + kpad) = float4{o[0], o[1], o[2], o[3]};
+                            }
+                        }
+                    }
+                }
+            }
             // (two entries per lane and pass = 32 loads in flight: the rows wait for HBM, not for arithmetic)
-            for (int k0 = lane; k0 < kpad; k0 += 128) {
+            for (int k0 = lane; k0 < kpad && !done_wide; k0 += 128) {
                 for (int fh = 0; fh < (nw == 2 ? 1 : 2); ++fh) {
                     float a[2][8], b[2][8];
 #pragma unroll
