@@ -143,6 +143,7 @@ struct Params {
     const float* wfrag;       // [bin tile][mel tile][64 lanes][4]: W[16 mt + (lane & 15)][16 bt + 4 kq + i]
     const uint32_t* wmask;    // [bin tile]: bit mt set = that tile of W has a non-zero weight
     const v2::UnitDesc* units;
+    unsigned* queue;          // device counter, zeroed before the launch: units behind the first gridDim.x are dealt by it (null: static stride)
     int64_t total_units;
     int hop, kg, nb, n_bins, n_mels, nmt;   // kg = K groups of 16 folded samples, nb = bin tiles of 16
     int n_fft, nh;            // nh = n_fft / 2 folded samples per frame (n = 1 .. nh paired with n_fft - n)

@@ -80,7 +80,8 @@ struct af_features {
     // n_fft outside {1024, 512, 256}: the DFT as a matrix product (features_dft.hip); none of the FFT kernels' tables exist
     bool dft = false;
     DevBuf d_dft;                    // tfrag | wfrag | wmask
-    size_t dft_off_w = 0, dft_off_mask = 0;
+    size_t dft_off_w = 0, dft_off_mask = 0, dft_off_queue = 0;
+    int opt_dft_queue = -1;          // af_features_set_option("dft_queue"): 0 the static deal of units (diagnostics)
     int dft_kg = 0, dft_nb = 0, dft_nmt = 0, dft_row_stride = 0, dft_tile_stride = 0, dft_waves = 1;
 };
 
@@ -525,7 +526,10 @@ af_status build_dft(af_features* p)
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     p->dft_off_w = up16(tfrag.size() * sizeof(float));
     p->dft_off_mask = up16(p->dft_off_w + wfrag.size() * sizeof(float));
-    AF_TRY(p->d_dft.reserve(p->dft_off_mask + wmask.size() * sizeof(uint32_t)));
+    // (the counter in a 256-byte block of its own: on the cache line of the mask words, which every wave reads once per bin
+    // tile, the atomics made the launch five times slower)
+    p->dft_off_queue = (p->dft_off_mask + wmask.size() * sizeof(uint32_t) + 511) & ~(size_t)255;
+    AF_TRY(p->d_dft.reserve(p->dft_off_queue + 256));
     char* b = p->d_dft.as<char>();
     if (hipMemcpy(b, tfrag.data(), tfrag.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(b + p->dft_off_w, wfrag.data(), wfrag.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1010,6 +1014,8 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         q.wmask = reinterpret_cast<const uint32_t*>(p->d_dft.as<char>() + p->dft_off_mask);
         q.units = p->d_units.as<v2::UnitDesc>() + u_begin;
         q.total_units = u_count;
+        q.queue = p->opt_dft_queue == 0 ? nullptr : reinterpret_cast<unsigned*>(p->d_dft.as<char>() + p->dft_off_queue);
+        if (q.queue) AF_HIP(hipMemsetAsync(q.queue, 0, sizeof(unsigned), as_stream(stream)));
         q.hop = (int)p->cfg.hop;
         q.kg = p->dft_kg;
         q.nb = p->dft_nb;
@@ -1348,6 +1354,7 @@ af_status af_features_set_option(af_features* p, const char* key, int value)
         AF_REQUIRE(p->dft && (value == 1 || value == 2), "dft_waves: 1 or 2 on a handle whose n_fft is not 1024 / 512 / 256");
         p->dft_waves = value;
     }
+    else if (std::strcmp(key, "dft_queue") == 0) p->opt_dft_queue = value < 0 ? -1 : (value != 0);
     else if (std::strcmp(key, "mel4") == 0) p->opt_mel4 = value < 0 ? -1 : (value != 0);    // 0: the 16 x 16 x 4 mel plan (diagnostics)
     else return fail(AF_ERR_INVALID_ARG, "af_features_set_option: unknown option '%s'", key);
     return AF_OK;

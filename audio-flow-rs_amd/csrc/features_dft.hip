@@ -77,11 +77,23 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 
     unsigned long long c_stage = 0, c_prod = 0, c_units = 0;
     const unsigned long long k_t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0, k_r0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
 
-    for (int64_t set = blockIdx.x; set < n_sets; set += gridDim.x) {
+    // Units: the first one by workgroup index, the rest from a device-wide counter (p.queue; null: a static stride) -- the
+    // workgroups of a launch do not all run at the same pace (three waves share a SIMD with whoever is there), and with 31.2
+    // units per workgroup a static deal leaves 3 % of the launch to its stragglers.  Thread 0 takes the next ticket while the
+    // current unit's rows are requested and leaves it in a padding word of the last row (two words, alternating: nothing
+    // else reads or writes them) once those loads are back.  It must be consumed there: an atomic whose result stays pending
+    // into the product loops makes the compiler wait with vmcnt(0) at every loop head (a first version: 6.8 ms instead of 1.45).
+    volatile unsigned* mailbox = reinterpret_cast<volatile unsigned*>(smem + 16 * rs - 2);
+    int64_t set = blockIdx.x;
+    unsigned ticket = 0;
+    for (unsigned iter = 0;; ++iter) {
+        __syncthreads();                                               // the partner has left the previous unit's rows (and its ticket is visible)
+        if (iter) set = p.queue ? (int64_t)gridDim.x + (int64_t)__builtin_amdgcn_readfirstlane(mailbox[(iter - 1) & 1]) : set + gridDim.x;
+        if (set >= n_sets) break;
+        if (p.queue && threadIdx.x == 0) ticket = atomicAdd(p.queue, 1u);
         const UnitDesc ud = load_unit(p.units, set);
         const int sel = SEP ? ud.sel : -1;
         const unsigned long long s_t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
-        __syncthreads();                                               // the partner has left the previous unit's rows
         {
             // folded rows: entry k of frame f pairs sample n = k + 1 with sample N - n of that frame; to_mono (capture.rs:30-42)
             // / i16 scaling on the way in, zeros behind the end of the clip and behind the last pair
@@ -113,7 +125,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 
                 if (last <= avail) {
                     done_wide = true;
                     const float* x0 = static_cast<const float*>(p.pcm) + ud.pcm0 * CH;
+                    const int j_valid = (nh + 3) >> 2;                  // pieces that hold a pair; the rest of a row half is zero
                     for (int j = lane; j < J; j += 64) {               // (52 pieces per row half at 400: one pass, 16 loads per lane)
+                        // (a piece behind the last pair loads nothing: with the row padded to four K groups its samples would lie
+                        // behind the frame -- and its partners in front of it: n_fft 36 faulted here in the first version)
+                        const int jl = j < j_valid ? j : 0;
                         for (int f0 = 0; f0 < n_f; f0 += 8) {
                             float4 a4[8], b4[8];
 #pragma unroll
@@ -121,13 +137,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 
                                 const float* xf = x0 + (int64_t)(f_lo + f0 + f) * p.hop * CH;
                                 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
                                 if constexpr (CH == 1) {
-                                    const f4u av = *reinterpret_cast<const f4u*>(xf + 4 * j + 1);
-                                    const f4u bv = *reinterpret_cast<const f4u*>(xf + N - 4 * j - 4);
+                                    const f4u av = *reinterpret_cast<const f4u*>(xf + 4 * jl + 1);
+                                    const f4u bv = *reinterpret_cast<const f4u*>(xf + N - 4 * jl - 4);
                                     a4[f] = float4{av[0], av[1], av[2], av[3]};
                                     b4[f] = float4{bv[3], bv[2], bv[1], bv[0]};   // partner of sample n + i is N - n - i
                                 } else {
-                                    const f4u a0 = *reinterpret_cast<const f4u*>(xf + 2 * (4 * j + 1)), a1 = *reinterpret_cast<const f4u*>(xf + 2 * (4 * j + 3));
-                                    const f4u b0 = *reinterpret_cast<const f4u*>(xf + 2 * (N - 4 * j - 4)), b1 = *reinterpret_cast<const f4u*>(xf + 2 * (N - 4 * j - 2));
+                                    const f4u a0 = *reinterpret_cast<const f4u*>(xf + 2 * (4 * jl + 1)), a1 = *reinterpret_cast<const f4u*>(xf + 2 * (4 * jl + 3));
+                                    const f4u b0 = *reinterpret_cast<const f4u*>(xf + 2 * (N - 4 * jl - 4)), b1 = *reinterpret_cast<const f4u*>(xf + 2 * (N - 4 * jl - 2));
                                     const auto mix = [&](float l, float r) { return sel < 0 ? (l + r) * 0.5f : sel ? r : l; };   // to_mono (capture.rs:30-42) / one channel
                                     a4[f] = float4{mix(a0[0], a0[1]), mix(a0[2], a0[3]), mix(a1[0], a1[1]), mix(a1[2], a1[3])};
                                     b4[f] = float4{mix(b1[2], b1[3]), mix(b1[0], b1[1]), mix(b0[2], b0[3]), mix(b0[0], b0[1])};
@@ -186,6 +202,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 
                 }
             }
         }
+        if (p.queue && threadIdx.x == 0) mailbox[iter & 1] = ticket;
         __syncthreads();                                               // all 16 rows are there
         unsigned long long s_t1 = 0;
         if (p.stamps) {

@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--clips", type=int, default=256); ap.add_argument("--seconds", type=float, default=30.0)
 ap.add_argument("--sr", type=int, default=16000); ap.add_argument("--n_fft", type=int, default=400)
 ap.add_argument("--hop", type=int, default=160); ap.add_argument("--channels", type=int, default=1)
-ap.add_argument("--reps", type=int, default=10); ap.add_argument("--waves", type=int, default=0); ap.add_argument("--wg_per_cu", type=int, default=0)
+ap.add_argument("--reps", type=int, default=10); ap.add_argument("--waves", type=int, default=0); ap.add_argument("--wg_per_cu", type=int, default=0); ap.add_argument("--queue", type=int, default=-1)
 ap.add_argument("--json", default=""); ap.add_argument("--stamps", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -20,6 +20,7 @@ n = int(a.seconds * a.sr)
 x = (torch.rand(a.clips, n, a.channels, device=dev) * 2 - 1) * 0.3
 p = af.FeaturePipeline(sample_rate=a.sr, channels=a.channels, n_fft=a.n_fft, hop=a.hop)
 if a.wg_per_cu: assert af.library().af_features_set_option(p._h, b"wg_per_cu", a.wg_per_cu) == 0
+if a.queue >= 0: assert af.library().af_features_set_option(p._h, b"dft_queue", a.queue) == 0
 if a.waves: assert af.library().af_features_set_option(p._h, b"dft_waves", a.waves) == 0
 tot = p.set_batch_uniform(a.clips, n)
 mel = torch.empty(tot, 80, device=dev)

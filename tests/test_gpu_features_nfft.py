@@ -25,6 +25,9 @@ CASES = [
     dict(sample_rate=16000, channels=1, n_fft=100, hop=64),
     dict(sample_rate=16000, channels=1, n_fft=33, hop=64),                        # odd frame length, K padded to 48
     dict(sample_rate=16000, channels=3, n_fft=400, hop=160),                      # to_mono first (capture.rs:30-42)
+    dict(sample_rate=22050, channels=3, n_fft=36, hop=128),                       # rows padded to four K groups (64 entries for 18 pairs):
+    dict(sample_rate=22050, channels=1, n_fft=36, hop=128),                       # the first version's 16-byte row loads left the frame here
+    dict(sample_rate=22050, channels=2, n_fft=40, hop=64),
 ]
 
 
