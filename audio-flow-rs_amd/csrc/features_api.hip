@@ -486,7 +486,7 @@ af_status build_dft(af_features* p)
     p->dft_tile_stride = 16 * p->dft_row_stride;
     // two waves per workgroup share a unit's rows (27 KB for 400 / 160): four workgroups per CU = two waves per SIMD, each
     // hiding the other's waits.  (One wave per unit, rows private: 2.13 ms on 256 x 30 s of 400 / 160 with one wave per SIMD --
-    // the LDS holds no more -- against 1.45 ms in this shape at six workgroups per CU.)
+    // the LDS holds no more -- against 1.39 ms in this shape at six workgroups per CU.)
     const size_t per_wg = (size_t)p->dft_tile_stride * sizeof(float);
     if (per_wg > 160 * 1024) return fail(AF_ERR_UNSUPPORTED, "features: n_fft %u needs %zu bytes of LDS per workgroup", c.n_fft, per_wg);
     p->dft_waves = 2;
