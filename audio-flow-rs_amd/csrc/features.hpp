@@ -105,6 +105,10 @@ struct Params {
     const float* wfrag4;      // [2 groups][kM4Quads][64][4]
     const int* lane4;         // [2 groups][64]: k_start | quad << 10 | owner << 17 | add1 << 18 | add2 << 19 | (lane & 3) << 20
     int m4_quads[2];          // 16-byte operand quads (= 4 steps) of each group
+    // work distribution: with `queue` (a device counter, zeroed before the launch) every workgroup's range gives its last
+    // `pool_units` units (a multiple of the kernel's chunk, the same for all ranges) to a pool dealt by that counter
+    unsigned* queue;
+    int pool_units;
 };
 
 // The mel phase on 16 blocks of 4 x 4 x 1 (round 5).  The banded filterbank touches two filters per bin; a 16-filter
@@ -113,6 +117,15 @@ struct Params {
 // w >> 2; its 16 block slots hold the group's tiles, long bands cut into up to four pieces that sit side by side in
 // one row of four blocks (summed at the end by two DPP row shifts).  All pieces of a group run `steps` bins.
 constexpr int kM4Quads = 8;               // at most 32 steps per wave
+// units per chunk of the common pool, and the share of every workgroup's range that goes there: 1 / 2^kPoolShift
+#ifndef AF_V2_POOL_CHUNK
+#define AF_V2_POOL_CHUNK 11
+#endif
+#ifndef AF_V2_POOL_SHIFT
+#define AF_V2_POOL_SHIFT 3
+#endif
+constexpr int kPoolChunk = AF_V2_POOL_CHUNK;
+constexpr int kPoolShift = AF_V2_POOL_SHIFT;
 struct Plan4 {
     bool ok = false;
     int quads[2] = {0, 0};                // steps / 4 per group

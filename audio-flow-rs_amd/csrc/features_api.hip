@@ -81,6 +81,8 @@ struct af_features {
     bool dft = false;
     DevBuf d_dft;                    // tfrag | wfrag | wmask
     size_t dft_off_w = 0, dft_off_mask = 0, dft_off_queue = 0;
+    DevBuf d_queue;                  // hop-256 kernel: the counter of its unit pool (a 256-byte block of its own)
+    int opt_pool = -1;               // af_features_set_option("pool"): 0 every workgroup its own contiguous range only
     int opt_dft_queue = -1;          // af_features_set_option("dft_queue"): 0 the static deal of units (diagnostics)
     int dft_kg = 0, dft_nb = 0, dft_nmt = 0, dft_row_stride = 0, dft_tile_stride = 0, dft_waves = 1;
 };
@@ -1160,6 +1162,16 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         int64_t grid2 = (int64_t)p->n_cus * 2;
         if (wg_knob == 1) grid2 = (int64_t)p->n_cus;
         if (grid2 > u_count) grid2 = u_count;
+        // the pool of the work distribution: 1 / 2^kPoolShift of every range, whole chunks (ranges of at least 64 units)
+        if (p->opt_pool != 0 && u_count / grid2 >= 64) {
+            const int pool = (int)((u_count / grid2) >> v2::kPoolShift) / v2::kPoolChunk * v2::kPoolChunk;
+            if (pool > 0) {
+                AF_TRY(p->d_queue.reserve(256));
+                AF_HIP(hipMemsetAsync(p->d_queue.p, 0, sizeof(unsigned), as_stream(stream)));
+                q.queue = p->d_queue.as<unsigned>();
+                q.pool_units = pool;
+            }
+        }
         AF_TRY(v2::launch(q, kernel_channels(p->cfg), p->cfg.sample_format == AF_PCM_I16, prm.separate != 0,
                           (int)grid2, as_stream(stream)));
         return finish();
@@ -1354,6 +1366,7 @@ af_status af_features_set_option(af_features* p, const char* key, int value)
         AF_REQUIRE(p->dft && (value == 1 || value == 2), "dft_waves: 1 or 2 on a handle whose n_fft is not 1024 / 512 / 256");
         p->dft_waves = value;
     }
+    else if (std::strcmp(key, "pool") == 0) p->opt_pool = value < 0 ? -1 : (value != 0);
     else if (std::strcmp(key, "dft_queue") == 0) p->opt_dft_queue = value < 0 ? -1 : (value != 0);
     else if (std::strcmp(key, "mel4") == 0) p->opt_mel4 = value < 0 ? -1 : (value != 0);    // 0: the 16 x 16 x 4 mel plan (diagnostics)
     else return fail(AF_ERR_INVALID_ARG, "af_features_set_option: unknown option '%s'", key);

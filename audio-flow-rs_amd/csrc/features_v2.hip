@@ -551,10 +551,16 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     // LDS byte address of this wave's buffer = the low half of its flat address
     const WaveBuf wv{wb, (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<uintptr_t>(wb)), lane};
 
+    // Work: workgroup b owns the contiguous units [r0, r1) (consecutive units of a clip share 15/16 of their signal tile).  The
+    // workgroups do not run at one pace -- the average lifetime differs by 8 % between the XCDs and by 10 % inside one
+    // (profiles/r05_v2_ablations.txt section 8) -- so with p.queue set every range gives its last `pool` units to a common
+    // pool of chunks of (unsigned)kPoolChunk units, dealt by a device-wide counter to whoever has finished its own part.
     const int64_t G = gridDim.x, bid = blockIdx.x;
     unsigned u = (unsigned)(p.total_units * bid / G);
-    const unsigned u_end = (unsigned)(p.total_units * (bid + 1) / G);
+    unsigned u_end = (unsigned)(p.total_units * (bid + 1) / G);
     if (u >= u_end) return;
+    const unsigned pool = p.queue ? (unsigned)p.pool_units : 0u;       // the same for every range (<= the shortest range - 1)
+    u_end -= pool;
 #if AF_V2_CLK
     const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -602,6 +608,8 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     bool pf_ready = false;                           // pf[] already holds / awaits the new hops of the next unit
     uint4 pf[PFU];
     UnitDesc ud_next = load_desc(p.units, u);
+    volatile unsigned* ticket_box = reinterpret_cast<volatile unsigned*>(lmeta + kW * kMaxSlotsW);
+    for (;;) {                                       // segments: the workgroup's own part, then chunks of the pool
     while (u < u_end) {
         const UnitDesc ud = ud_next;
         AF_STAMP2(0);
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
             }
 #if AF_V2_M4_STAGE
             {
-                float* stage = reinterpret_cast<float*>(lmeta + kW * kMaxSlotsW);
+                float* stage = reinterpret_cast<float*>(lmeta + kW * kMaxSlotsW) + 4;
                 if ((l4o >> 17) & 1)
                     *reinterpret_cast<float4*>(stage + fr * n_mels + 4 * ((l4o >> 10) & 127)) = float4{r[0], r[1], r[2], r[3]};
                 __syncthreads();
@@ -940,6 +948,21 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         ++u;
         fresh = !has_next;
     }
+        if (!pool) break;
+        // the next chunk of the pool: ticket t is chunk t / G of range t % G (the chunks of one range are dealt far apart in time)
+        __syncthreads();
+        if (tid == 0) *ticket_box = atomicAdd(p.queue, 1u);
+        __syncthreads();
+        const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)*ticket_box);
+        const unsigned per_range = pool / (unsigned)kPoolChunk;
+        if (t >= per_range * (unsigned)G) break;
+        const unsigned rb = t % (unsigned)G, rk = t / (unsigned)G;
+        u = (unsigned)(p.total_units * (rb + 1) / G) - pool + rk * (unsigned)kPoolChunk;
+        u_end = u + (unsigned)kPoolChunk;
+        fresh = true;
+        pf_ready = false;
+        ud_next = load_desc(p.units, u);
+    }
     if constexpr (STAMPS) {
         if (lane == 0 && w < 4)
             for (int i = 0; i < 8; ++i) atomicAdd(p.stamps + w * 8 + i, acc_t[i]);
@@ -949,6 +972,13 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         atomicAdd(p.stamps, __builtin_amdgcn_s_memtime() - clk_t0);
         atomicAdd(p.stamps + 1, __builtin_amdgcn_s_memrealtime() - clk_r0);
         atomicAdd(p.stamps + 2, 1ull);
+        // the spread of the workgroups' lifetimes (100 MHz ticks): sum and maximum by blockIdx % 8, the latest end (ticks since the
+        // first workgroup's start is not knowable here: s_memrealtime is a free-running counter, so ends are compared directly)
+        const unsigned long long life = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        atomicAdd(p.stamps + 8 + (blockIdx.x & 7), life);
+        atomicMax(p.stamps + 16 + (blockIdx.x & 7), life);
+        atomicMax(p.stamps + 24, __builtin_amdgcn_s_memrealtime());
+        atomicMax(p.stamps + 25, ~clk_r0);                             // (~earliest start: the buffer starts zeroed)
     }
 #endif
 }
@@ -957,7 +987,7 @@ template <int CH, bool I16, bool SEP, int NSLOT, bool STAMPS, bool POWER>
 static af_status launch_kp(const Params& p, int grid, hipStream_t stream)
 {
     auto kern = af_features_v2_kernel<CH, I16, SEP, NSLOT, STAMPS, POWER>;
-    constexpr size_t smem = sizeof(float) * kLdsFloats;
+    constexpr size_t smem = sizeof(float) * (kLdsFloats + 4);        // (+ the ticket word of the pool)
     static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
     static LdsAttrFlags attr_set;
     AF_HIP(allow_big_lds(kern, (int)smem, attr_set));
@@ -980,7 +1010,7 @@ static af_status launch_m4(const Params& p, int grid, hipStream_t stream)
 {
     const int most = p.m4_quads[0] > p.m4_quads[1] ? p.m4_quads[0] : p.m4_quads[1];
     auto go = [&](auto kern) -> af_status {
-        constexpr size_t smem = sizeof(float) * (kLdsFloats + (AF_V2_M4_STAGE ? 16 * 128 : 0));
+        constexpr size_t smem = sizeof(float) * (kLdsFloats + 4 + (AF_V2_M4_STAGE ? 16 * 128 : 0));
         static LdsAttrFlags attr_set;
         AF_HIP(allow_big_lds(kern, (int)smem, attr_set));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kT), smem, stream, p);

@@ -314,6 +314,8 @@ af_status af_features_set_batch_spans(af_features* p, const int64_t* starts,
 /* per-handle diagnostics (unlike af_debug_set they touch no other handle); value -1: follow af_debug_set
  *   "kernel"     1: the general fused kernel also where the hop-256 kernel applies
  *   "wg_per_cu"  workgroups per CU of the fused kernels
+ *   "pool"       0: the hop-256 kernel with every workgroup on its own contiguous range of units only (default: the last
+ *                eighth of every range is dealt through a device-wide counter; same rows, bit for bit)
  *   "mel4"       0: the hop-256 kernel's mel phase on 16 x 16 x 4 matrix tiles also where the plan on 16 blocks of
  *                4 x 4 x 1 fits (n_mels a multiple of 4, <= 16 pieces per half of the bands); same rows within the
  *                float32 summation order */

@@ -47,5 +47,10 @@ for path in a.libs:
         st = np.zeros(32, np.uint64)
         assert lib.af_features_debug_stamps(h, 0, st.ctypes.data) == 0
         if st[1]: clk = f"   in-kernel clock {float(st[0]) / float(st[1]) * 0.1:6.3f} GHz, {float(st[0]) / float(st[2]) / 1e6:6.3f} M cycles per workgroup"
+        if st[24]:
+            n8 = float(st[2]) / 8.0
+            avg = [float(st[8 + i]) / n8 * 0.01 for i in range(8)]; mx = [float(st[16 + i]) * 0.01 for i in range(8)]
+            span = (float(st[24]) - float(~st[25] & np.uint64(0xFFFFFFFFFFFFFFFF))) * 0.01
+            clk += "\n      workgroup lifetimes by blockIdx % 8 (us): avg " + " ".join(f"{x:6.1f}" for x in avg) + "\n" + " " * 45 + "max " + " ".join(f"{x:6.1f}" for x in mx) + f"\n      first start to last end over the 10 launches (us): {span:.1f}"
     print(f"{os.path.basename(path):28s} {e0.elapsed_time(e1) / a.reps:8.4f} ms{clk}", flush=True)
     lib.af_features_destroy(h)

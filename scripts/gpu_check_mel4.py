@@ -45,8 +45,8 @@ if "--time" in sys.argv:
     x = (torch.rand(256, 1440000, 2, device=dev) * 2 - 1) * 0.3
     s = torch.cuda.current_stream().cuda_stream
     pipes, res = {}, {0: [], 1: []}
-    for m4 in (0, 1):
-        p = af.FeaturePipeline(); lib.af_features_set_option(p._h, b"mel4", m4)
+    for m4 in (0, 1):                                    # (--pool: the same handle twice, work pool off / on)
+        p = af.FeaturePipeline(); lib.af_features_set_option(p._h, b"pool" if "--pool" in sys.argv else b"mel4", m4)
         tot = p.set_batch_uniform(256, 1440000); pipes[m4] = p
     mel = torch.empty(tot, 80, device=dev)
     t0 = time.time()
@@ -61,5 +61,5 @@ if "--time" in sys.argv:
             e1.record(); torch.cuda.synchronize()
             res[m4].append(e0.elapsed_time(e1) / 50)
     for m4 in (0, 1):
-        r = sorted(res[m4]); print(f"config 2, mel4={m4}: min {r[0]:.4f}  median {r[len(r) // 2]:.4f}  max {r[-1]:.4f} ms  (8 x 50 launches, alternating)")
+        r = sorted(res[m4]); print(f"config 2, {'pool' if '--pool' in sys.argv else 'mel4'}={m4}: min {r[0]:.4f}  median {r[len(r) // 2]:.4f}  max {r[-1]:.4f} ms  (8 x 50 launches, alternating)")
 print("FAILED" if bad else "ok"); sys.exit(1 if bad else 0)

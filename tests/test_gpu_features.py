@@ -436,3 +436,31 @@ def test_output_rows_at_a_pointer_that_is_only_4_byte_aligned(af, kw):
     got = buf[1:1 + total * nm].reshape(total, nm)
     assert bits_equal(got.cpu().numpy(), ref.cpu().numpy())
     assert float(buf[0]) == -7.0 and bool((buf[1 + total * nm:] == -7.0).all())
+
+
+def test_work_pool_gives_the_same_rows(af):
+    """The hop-256 kernel deals the last eighth of every workgroup's unit range through a device-wide counter (batches of at
+    least 64 units per workgroup; `af_features_set_option(h, "pool", 0)` keeps the static ranges).  Which workgroup computes a
+    unit, and whether it loads its signal tile whole or shifts the previous one, does not change a bit of its rows; two
+    launches of the pooled handle agree with each other as well (the deal differs from launch to launch)."""
+    import torch
+    dev = torch.device("cuda:0")
+    lib = af.library()
+    clips, n = 100, 1440000
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    x = ((torch.rand(4, n, 2, generator=g) * 2 - 1) * 0.3).to(dev).repeat(25, 1, 1).contiguous()
+    s = torch.cuda.current_stream().cuda_stream
+    out = []
+    for pool in (0, -1, -1):
+        p = af.FeaturePipeline()
+        assert lib.af_features_set_option(p._h, b"pool", pool) == 0
+        total = p.set_batch_uniform(clips, n)
+        mel = torch.empty(total, 80, device=dev)
+        p.run_device(x.data_ptr(), mel.data_ptr(), s)
+        torch.cuda.synchronize()
+        out.append(mel)
+    assert torch.equal(out[0].view(torch.int32), out[1].view(torch.int32))
+    assert torch.equal(out[1].view(torch.int32), out[2].view(torch.int32))
+    nf = total // clips
+    m = out[1].reshape(clips, nf, 80)
+    assert torch.equal(m[:4].view(torch.int32), m[96:100].view(torch.int32))     # the batch repeats four clips
