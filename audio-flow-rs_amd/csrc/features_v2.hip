@@ -635,6 +635,11 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         __builtin_amdgcn_sched_barrier(0);
 
         const bool has_next = (u + 1 < u_end) && (ud.flags & 1);
+        // the ticket of the next pool chunk is taken a whole unit before it is needed (the counter is one address for 512
+        // workgroups that come for it at about the same time) and put into LDS behind this unit's vmcnt(0) below
+        const bool take_ticket = pool && (u + 1 == u_end) && tid == 0;
+        unsigned tk = 0;
+        if (take_ticket) tk = atomicAdd(p.queue, 1u);
         // requests the 16 new hops of the unit BEHIND unit `d` (whose tile starts at d.pcm0) into pf[LO..HI)
         const auto issue_prefetch = [&](const UnitDesc& d, bool wanted, auto lo_c, auto hi_c) {
             constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
@@ -732,6 +737,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         // instead of its own: it counts the fragment loads against the mel stores issued between the slots (vector
         // memory operations retire in order), so a slot behind a flush waited for that flush's HBM stores.
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+        if (take_ticket) *ticket_box = tk;
 
         if (has_next && !(AF_ABL & 1024)) {
             // The next tile is this one shifted by 16 hops: the last kTail samples move to the front,
@@ -950,9 +956,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     }
         if (!pool) break;
         // the next chunk of the pool: ticket t is chunk t / G of range t % G (the chunks of one range are dealt far apart in time)
-        __syncthreads();
-        if (tid == 0) *ticket_box = atomicAdd(p.queue, 1u);
-        __syncthreads();
+        __syncthreads();                             // (the ticket was stored a mel phase ago; everybody is done with this segment)
         const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)*ticket_box);
         const unsigned per_range = pool / (unsigned)kPoolChunk;
         if (t >= per_range * (unsigned)G) break;
