@@ -81,6 +81,9 @@
 #ifndef AF_V2_M4_STAGE
 #define AF_V2_M4_STAGE 0
 #endif
+#ifndef AF_V2_POOL_GUIDED
+#define AF_V2_POOL_GUIDED 0
+#endif
 // (experiment) start the workgroups staggered (s_sleep units of 64 cycles per step of blockIdx % 16); 0: together
 #ifndef AF_V2_STAGGER
 #define AF_V2_STAGGER 0
@@ -958,11 +961,22 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         // the next chunk of the pool: ticket t is chunk t / G of range t % G (the chunks of one range are dealt far apart in time)
         __syncthreads();                             // (the ticket was stored a mel phase ago; everybody is done with this segment)
         const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)*ticket_box);
+#if AF_V2_POOL_GUIDED
+        // (experiment) chunks that shrink: every range's pool is cut into 1/2, 1/4, 1/8 and the rest, the large ones dealt first
+        if (t >= 4u * (unsigned)G) break;
+        const unsigned rb = t % (unsigned)G, rk = t / (unsigned)G;
+        const unsigned c0 = pool >> 1, c1 = pool >> 2, c2 = pool >> 3;
+        const unsigned off = rk == 0 ? 0u : rk == 1 ? c0 : rk == 2 ? c0 + c1 : c0 + c1 + c2;
+        const unsigned len = rk == 0 ? c0 : rk == 1 ? c1 : rk == 2 ? c2 : pool - (c0 + c1 + c2);
+        u = (unsigned)(p.total_units * (rb + 1) / G) - pool + off;
+        u_end = u + len;
+#else
         const unsigned per_range = pool / (unsigned)kPoolChunk;
         if (t >= per_range * (unsigned)G) break;
         const unsigned rb = t % (unsigned)G, rk = t / (unsigned)G;
         u = (unsigned)(p.total_units * (rb + 1) / G) - pool + rk * (unsigned)kPoolChunk;
         u_end = u + (unsigned)kPoolChunk;
+#endif
         fresh = true;
         pf_ready = false;
         ud_next = load_desc(p.units, u);
