@@ -12,6 +12,7 @@
 // The K index of MFMA step j of a group is 16 g + 4 kq + j: a lane's four B operands are one 16-byte LDS read, its
 // four A operands one 16-byte fragment load (the host lays the fragments out in that order).
 // Bounded by the f32 matrix pipe: (n_fft / 2 + 1) x n_fft multiply-adds per frame (docs/OPS.md "STFT").
+#include <type_traits>
 #include "af_common.hpp"
 #include "features_dev.hpp"
 
@@ -114,17 +115,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 
             // (each wave builds the rows of half the frames: 16 loads in flight per entry with two waves)
             const int f_lo = nw == 2 ? 8 * w : 0;
             bool done_wide = false;
-            if constexpr (!I16 && !(AF_DFT_ABL & 4)) {
-                // f32: a lane takes four consecutive entries of a frame -- 16-byte loads of samples n .. n + 3 and of their
-                // partners N - n - 3 .. N - n (two each for stereo; global loads only need dword alignment) -- and every load
-                // of the wave's half of the rows is in flight at once: the rows take one trip to HBM instead of four.  Frames
-                // that reach behind the end of the clip (wave-uniform test) take the element-wise path below.
+            if constexpr (!(AF_DFT_ABL & 4)) {
+                // A lane takes four consecutive entries of a frame -- samples n .. n + 3 and their partners N - n - 3 .. N - n as
+                // vectors (f32: 16-byte loads, two each for stereo, global loads only need dword alignment; i16: four or eight
+                // shorts declared 2-byte aligned, whatever the compiler makes of them) -- and every load of the wave's half of
+                // the rows is in flight at once: the rows take one trip to HBM instead of four.  Frames that reach behind
+                // the end of the clip (wave-uniform test) take the element-wise path below.
                 const int J = kpad >> 2;                                // 16-byte pieces per row half
                 const int n_f = nw == 2 ? 8 : 16;
                 const int64_t last = (int64_t)(f_lo + n_f - 1) * p.hop + N;      // one behind the last sample these frames touch
                 if (last <= avail) {
                     done_wide = true;
-                    const float* x0 = static_cast<const float*>(p.pcm) + ud.pcm0 * CH;
+                    typedef typename std::conditional<I16, int16_t, float>::type Elem;
+                    const Elem* x0 = static_cast<const Elem*>(p.pcm) + ud.pcm0 * CH;
                     const int j_valid = (nh + 3) >> 2;                  // pieces that hold a pair; the rest of a row half is zero
                     for (int j = lane; j < J; j += 64) {               // (52 pieces per row half at 400: one pass, 16 loads per lane)
                         // (a piece behind the last pair loads nothing: with the row padded to four K groups its samples would lie
@@ -134,9 +137,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NMT <= 5 ? 
                             float4 a4[8], b4[8];
 #pragma unroll
                             for (int f = 0; f < 8; ++f) {
-                                const float* xf = x0 + (int64_t)(f_lo + f0 + f) * p.hop * CH;
+                                const Elem* xf = x0 + (int64_t)(f_lo + f0 + f) * p.hop * CH;
                                 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                                if constexpr (CH == 1) {
+                                typedef short s4u __attribute__((ext_vector_type(4), aligned(2)));
+                                if constexpr (I16) {
+                                    constexpr float sc = 1.0f / 32768.0f;      // docs/OPS.md "PCM formats"
+                                    const short* xs = reinterpret_cast<const short*>(xf);
+                                    if constexpr (CH == 1) {
+                                        const s4u av = *reinterpret_cast<const s4u*>(xs + 4 * jl + 1);
+                                        const s4u bv = *reinterpret_cast<const s4u*>(xs + N - 4 * jl - 4);
+                                        a4[f] = float4{(float)av[0] * sc, (float)av[1] * sc, (float)av[2] * sc, (float)av[3] * sc};
+                                        b4[f] = float4{(float)bv[3] * sc, (float)bv[2] * sc, (float)bv[1] * sc, (float)bv[0] * sc};
+                                    } else {
+                                        const s4u a0 = *reinterpret_cast<const s4u*>(xs + 2 * (4 * jl + 1)), a1 = *reinterpret_cast<const s4u*>(xs + 2 * (4 * jl + 3));
+                                        const s4u b0 = *reinterpret_cast<const s4u*>(xs + 2 * (N - 4 * jl - 4)), b1 = *reinterpret_cast<const s4u*>(xs + 2 * (N - 4 * jl - 2));
+                                        const auto mix = [&](short l, short r) { const float fl = (float)l * sc, fr = (float)r * sc; return sel < 0 ? (fl + fr) * 0.5f : sel ? fr : fl; };
+                                        a4[f] = float4{mix(a0[0], a0[1]), mix(a0[2], a0[3]), mix(a1[0], a1[1]), mix(a1[2], a1[3])};
+                                        b4[f] = float4{mix(b1[2], b1[3]), mix(b1[0], b1[1]), mix(b0[2], b0[3]), mix(b0[0], b0[1])};
+                                    }
+                                } else if constexpr (CH == 1) {
                                     const f4u av = *reinterpret_cast<const f4u*>(xf + 4 * jl + 1);
                                     const f4u bv = *reinterpret_cast<const f4u*>(xf + N - 4 * jl - 4);
                                     a4[f] = float4{av[0], av[1], av[2], av[3]};
