@@ -643,7 +643,7 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
     // (the matrix-product DFT kernel walks the same records with the handle's own hop and takes any alignment)
     const int64_t unit_hop = p->dft ? (int64_t)p->cfg.hop : (int64_t)v2::kHop;
     if (p->dft && p->total_units >= (1ll << 31)) return fail(AF_ERR_UNSUPPORTED, "features: more than 2^31 units in one batch");
-    if ((((v2_ok || v3_possible) && aligned4) || p->dft) && p->total_units > 0 && (p->dft || p->total_units < (1ll << 26))) {
+    if ((v2_ok || v3_possible || p->dft) && p->total_units > 0 && (p->dft || p->total_units < (1ll << 26))) {
         std::vector<v2::UnitDesc> units((size_t)p->total_units + 4);   // + zero records: the kernels read a unit ahead
         const bool sep = p->cfg.channel_mode == AF_CH_SEPARATE;
         size_t k = 0;
@@ -1105,8 +1105,12 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
     // never built, run their default kernel.
     const bool own = p->opt_kernel >= 0;
     int ksel = own ? p->opt_kernel : debug_knob(kKnobFeaturesKernel);
-    const bool hop256_ok = p->units_ok && p->offsets_aligned4 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 == 0;
-    const bool v3_applies = hop256_ok && p->v3_ok && !prm.out_power && !prm.log_mel;
+    // (round 5: the hop-256 kernel's plain global loads take 2-byte-aligned addresses as well -- the chip runs global memory in
+    // unaligned access mode, the DFT kernel's i16 row loads rely on it -- so mono i16 clips at odd frame offsets stay on it;
+    // the matrix-core DFT kernel reads through range-checked buffer loads and keeps its dword rule)
+    const bool aligned4_now = p->offsets_aligned4 && reinterpret_cast<uintptr_t>(pcm_dev) % 4 == 0;
+    const bool hop256_ok = p->units_ok && reinterpret_cast<uintptr_t>(pcm_dev) % (kernel_bytes_per_frame(p->cfg) == 2 ? 2 : 4) == 0;
+    const bool v3_applies = hop256_ok && aligned4_now && p->v3_ok && !prm.out_power && !prm.log_mel;
     if (ksel == 3 && !v3_applies) {
         if (!own) {
             ksel = 0;

@@ -315,7 +315,7 @@ def test_one_shot_pipeline_run(af, po):
 @pytest.mark.parametrize("ch,fmt", [(2, 0), (1, 0), (2, 1), (1, 1)])
 def test_hop256_kernel_on_clips_off_16_byte_boundaries(af, po, ch, fmt):
     """Clip bases that are only dword-aligned (odd frame offsets) stay on the hop-256 kernel (its 16-byte global loads
-    need 4-byte alignment only); i16 mono clips on odd frames are the one case left to the general kernel.  Rows equal
+    need no alignment beyond the sample's own: since round 5 that includes i16 mono clips on odd frames).  Rows equal
     the general kernel's within rounding and the oracle's within tolerance; a clip's rows do not depend on where it
     starts."""
     import ctypes as C
@@ -341,8 +341,7 @@ def test_hop256_kernel_on_clips_off_16_byte_boundaries(af, po, ch, fmt):
         # the same clip alone, at offset 0 (16-byte aligned): identical rows on the hop-256 kernel
         alone = af.FeaturePipeline(channels=ch, sample_format=fmt)
         alone.set_batch_uniform(1, n)
-        if not (ch == 1 and fmt == 1):
-            assert bits_equal(alone.run(x), got[row:row + nf])
+        assert bits_equal(alone.run(x), got[row:row + nf])
         row += nf
 
 
