@@ -398,6 +398,29 @@ af_status af_chain_set_option(af_chain* c, const char* key, int value)
         if (value > 0) AF_TRY(pipeline_resources(c, value));
         return AF_OK;
     }
+    if (std::strcmp(key, "n_fft") == 0) {
+        // the frame length of the STFT / mel stage (the config struct has no field for it: 1024 there); e.g. 400 with hop 160 for
+        // 25 ms / 10 ms speech frames behind a 48 -> 16 kHz chain.  The stage's handle is rebuilt and the batch forgotten:
+        // af_chain_set_batch* must follow.
+        af_features_config fc;
+        af_features_default_config(&fc);
+        fc.sample_rate = c->cfg.output_rate;
+        fc.channels = 1;
+        fc.n_fft = (uint32_t)value;
+        fc.hop = c->cfg.hop;
+        fc.n_mels = c->cfg.n_mels;
+        fc.f_min = c->cfg.f_min;
+        fc.f_max = c->cfg.f_max;
+        fc.device = -1;
+        af_features* nf = nullptr;
+        AF_TRY(af_features_create(&fc, &nf));
+        af_features_destroy(c->feat);
+        c->feat = nf;
+        c->n_clips = 0;
+        c->total_in = 0;
+        c->total_frames = 0;
+        return AF_OK;
+    }
     // the STFT / mel stage is a feature handle of its own: its kernel choice follows af_debug_set("features.kernel") unless
     // the chain pins it here (tests/test_gpu_concurrency.py flips the process-wide switch under a running chain)
     if (std::strcmp(key, "kernel") == 0 || std::strcmp(key, "wg_per_cu") == 0 || std::strcmp(key, "mel4") == 0) return af_features_set_option(c->feat, key, value);

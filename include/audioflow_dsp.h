@@ -441,6 +441,9 @@ af_status af_chain_run_device(af_chain* c, const void* pcm_dev, float* mel_dev, 
 af_status af_chain_run(af_chain* c, const void* pcm, size_t pcm_len, float* mel, size_t mel_cap);
 /* per-handle diagnostics (unlike af_debug_set they touch no other handle):
  *   "unfused"  1: resampler and FIR as separate launches; 0: fused where covered; -1: follow af_debug_set
+ *   "n_fft"    the frame length of the STFT / mel stage, 32..1024 (the config has no field for it: 1024); e.g. 400 with hop
+ *              160 for 25 ms / 10 ms speech frames behind a 48 -> 16 kHz chain.  Forgets the batch: af_chain_set_batch*
+ *              must follow.  (af_chain_stream_* keeps 1024.)
  *   "kernel", "wg_per_cu", "mel4": handed to the chain's STFT / mel stage (af_features_set_option); without them that stage
  *              follows af_debug_set("features.kernel") like any feature handle
  *   "pipeline" k > 0: equal-length batches run the two launches of the fused form side by side on two internal

@@ -835,3 +835,29 @@ def test_features_per_handle_option(af):
     gen = a.run(x)
     assert bits_equal(b.run(x), base)                        # b still on the hop-256 kernel
     assert frame_rel_err(gen, base) < 2e-6 and lib.af_features_set_option(a._h, b"bogus", 1) != 0
+
+
+@pytest.mark.parametrize("ch,fmt", [(2, 0), (1, 1)])
+def test_chain_with_speech_frames(af, po, ch, fmt):
+    """48 kHz capture -> to_mono -> 16 kHz -> FIR -> 25 ms / 10 ms frames (n_fft 400, hop 160: `af_chain_set_option(c, "n_fft", 400)`,
+    the STFT / mel stage then runs the matrix-product DFT kernel) -> 80 mel, against the chained oracle; ragged clips."""
+    taps = lowpass_taps()
+    lens = [48000, 30001, 7000]
+    clips = [synth_clip(190 + i, n, ch, 48000) for i, n in enumerate(lens)]
+    if fmt:
+        clips = [np.round(c * 32767.0).astype(np.int16) for c in clips]
+    chain = af.ChainPipeline(input_rate=48000, channels=ch, output_rate=16000, fir_taps=taps, hop=160, sample_format=fmt)
+    chain.set_option("n_fft", 400)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = chain.set_batch(off)
+    got = chain.run(np.concatenate(clips))
+    assert got.shape == (total, 80)
+    row = 0
+    for c in clips:
+        x = c.astype(np.float32) / np.float32(32768.0) if fmt else c
+        mono = po.to_mono(x, ch)
+        y = po.fir(po.resample(mono, 48000, 16000).astype(np.float32), taps).astype(np.float32)
+        ref = po.features(y, 1, 16000.0, n_fft=400, hop=160)
+        assert frame_rel_err(got[row:row + ref.shape[0]], ref) < 1e-5
+        row += ref.shape[0]
+    assert row == total
