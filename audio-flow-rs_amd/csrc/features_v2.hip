@@ -997,6 +997,13 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         atomicMax(p.stamps + 16 + (blockIdx.x & 7), life);
         atomicMax(p.stamps + 24, __builtin_amdgcn_s_memrealtime());
         atomicMax(p.stamps + 25, ~clk_r0);                             // (~earliest start: the buffer starts zeroed)
+        // dispatch ramp and tail of ONE launch (meaningful when the stamps hold a single launch): sum and latest of the starts,
+        // sum and ~earliest of the ends
+        const unsigned long long clk_r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(p.stamps + 26, clk_r0);
+        atomicMax(p.stamps + 27, clk_r0);
+        atomicAdd(p.stamps + 28, clk_r1);
+        atomicMax(p.stamps + 29, ~clk_r1);
     }
 #endif
 }

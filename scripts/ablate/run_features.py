@@ -42,7 +42,8 @@ for path in a.libs:
     if a.clk:
         import numpy as np
         assert lib.af_features_debug_stamps(h, 1, None) == 0
-        for _ in range(10): assert lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), s) == 0
+        n_clk = int(os.environ.get("AF_CLK_LAUNCHES", "10"))
+        for _ in range(n_clk): assert lib.af_features_run_device(h, pcm.data_ptr(), mel.data_ptr(), s) == 0
         torch.cuda.synchronize()
         st = np.zeros(32, np.uint64)
         assert lib.af_features_debug_stamps(h, 0, st.ctypes.data) == 0
@@ -51,6 +52,12 @@ for path in a.libs:
             n8 = float(st[2]) / 8.0
             avg = [float(st[8 + i]) / n8 * 0.01 for i in range(8)]; mx = [float(st[16 + i]) * 0.01 for i in range(8)]
             span = (float(st[24]) - float(~st[25] & np.uint64(0xFFFFFFFFFFFFFFFF))) * 0.01
+            if n_clk == 1 and st[26]:
+                M = np.uint64(0xFFFFFFFFFFFFFFFF); n = float(st[2])
+                s_min, s_max, s_avg = float(~st[25] & M), float(st[27]), float(st[26]) / n
+                e_min, e_max, e_avg = float(~st[29] & M), float(st[24]), float(st[28]) / n
+                clk += (f"\n      one launch, {int(n)} workgroups (us from the first start): starts avg {(s_avg - s_min) * 0.01:.1f} last {(s_max - s_min) * 0.01:.1f};"
+                        f" ends first {(e_min - s_min) * 0.01:.1f} avg {(e_avg - s_min) * 0.01:.1f} last {(e_max - s_min) * 0.01:.1f}")
             clk += "\n      workgroup lifetimes by blockIdx % 8 (us): avg " + " ".join(f"{x:6.1f}" for x in avg) + "\n" + " " * 45 + "max " + " ".join(f"{x:6.1f}" for x in mx) + f"\n      first start to last end over the 10 launches (us): {span:.1f}"
     print(f"{os.path.basename(path):28s} {e0.elapsed_time(e1) / a.reps:8.4f} ms{clk}", flush=True)
     lib.af_features_destroy(h)
