@@ -663,7 +663,7 @@ af_status upload_tables(af_features* p, const std::vector<int64_t>& start_in,
             }
         }
         AF_TRY(p->d_units.reserve(units.size() * sizeof(v2::UnitDesc)));
-        if (!p->dft) AF_TRY(p->d_queue.reserve(256));               // the counter of the hop-256 kernel's work pool, a block of its own
+        if (!p->dft) AF_TRY(p->d_queue.reserve((64 + 4096) * sizeof(unsigned)));               // the counter of the hop-256 kernel's work pool, a block of its own
         AF_HIP(hipMemcpy(p->d_units.p, units.data(), units.size() * sizeof(v2::UnitDesc), hipMemcpyHostToDevice));
         p->units_ok = true;
     }
@@ -1170,8 +1170,9 @@ static af_status run_device_impl(af_features* p, const void* pcm_dev, float* mel
         // the pool of the work distribution: 1 / 2^kPoolShift of every range, whole chunks (ranges of at least 64 units)
         if (p->opt_pool != 0 && u_count / grid2 >= 64) {
             const int pool = (int)((u_count / grid2) >> v2::kPoolShift) / v2::kPoolChunk * v2::kPoolChunk;
-            if (pool > 0 && p->d_queue.p) {                     // (allocated with the batch tables: nothing is allocated on the launch path)
-                AF_HIP(hipMemsetAsync(p->d_queue.p, 0, sizeof(unsigned), as_stream(stream)));
+            if (pool > 0 && p->d_queue.p && grid2 <= 4096) {    // (allocated with the batch tables: nothing is allocated on the launch path)
+                // [0]: the global ticket counter; [64 ...]: one deque word per range (pool mode 2)
+                AF_HIP(hipMemsetAsync(p->d_queue.p, 0, (64 + (size_t)grid2) * sizeof(unsigned), as_stream(stream)));
                 q.queue = p->d_queue.as<unsigned>();
                 q.pool_units = pool;
             }

@@ -81,6 +81,13 @@
 #ifndef AF_V2_M4_STAGE
 #define AF_V2_M4_STAGE 0
 #endif
+// work distribution with p.queue: 1 = the pool's chunks dealt by one counter (every chunk starts with a whole-tile load);
+// 2 = every range's tail is a deque of chunks: its owner takes them from the front WITHOUT a break (claimed two units ahead, the
+// tile keeps shifting), the workgroups that have run out steal from the back of the others' (one packed word per range: low half
+// front claims, high half back claims; a claim is valid while front + back < chunks)
+#ifndef AF_V2_POOL_MODE
+#define AF_V2_POOL_MODE 1
+#endif
 #ifndef AF_V2_POOL_GUIDED
 #define AF_V2_POOL_GUIDED 0
 #endif
@@ -612,6 +619,7 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
     uint4 pf[PFU];
     UnitDesc ud_next = load_desc(p.units, u);
     volatile unsigned* ticket_box = reinterpret_cast<volatile unsigned*>(lmeta + kW * kMaxSlotsW);
+    [[maybe_unused]] bool owner = true;              // (pool mode 2) still inside the own range
     for (;;) {                                       // segments: the workgroup's own part, then chunks of the pool
     while (u < u_end) {
         const UnitDesc ud = ud_next;
@@ -637,12 +645,25 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         ud_next = load_desc(p.units, u + 1);
         __builtin_amdgcn_sched_barrier(0);
 
-        const bool has_next = (u + 1 < u_end) && (ud.flags & 1);
         // the ticket of the next pool chunk is taken a whole unit before it is needed (the counter is one address for 512
         // workgroups that come for it at about the same time) and put into LDS behind this unit's vmcnt(0) below
+#if AF_V2_POOL_MODE == 2
+        // (after B1: the claim this workgroup's thread 0 stored two units ago is visible) extend the segment by the next chunk of
+        // the own range while the deque has one
+        if (pool && owner && u + 1 == u_end) {
+            const unsigned old_w = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket_box[0]);
+            if ((old_w & 0xFFFFu) + (old_w >> 16) < pool / (unsigned)kPoolChunk) u_end += (unsigned)kPoolChunk;
+            else owner = false;
+        }
+        const bool take_ticket = pool && owner && (u + 2 == u_end) && tid == 0;
+        unsigned tk = 0;
+        if (take_ticket) tk = atomicAdd(p.queue + 64 + (unsigned)bid, 1u);
+#else
         const bool take_ticket = pool && (u + 1 == u_end) && tid == 0;
         unsigned tk = 0;
         if (take_ticket) tk = atomicAdd(p.queue, 1u);
+#endif
+        const bool has_next = (u + 1 < u_end) && (ud.flags & 1);
         // requests the 16 new hops of the unit BEHIND unit `d` (whose tile starts at d.pcm0) into pf[LO..HI)
         const auto issue_prefetch = [&](const UnitDesc& d, bool wanted, auto lo_c, auto hi_c) {
             constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
@@ -958,6 +979,34 @@ __global__ __launch_bounds__(kT, 4) void af_features_v2_kernel(const Params p)
         fresh = !has_next;
     }
         if (!pool) break;
+#if AF_V2_POOL_MODE == 2
+        // out of own work: steal a chunk from the back of another range's deque.  Thread 0 walks the global ticket list
+        // (ticket t probes range t % G; K rounds over all ranges) until a claim is valid or the list ends.
+        owner = false;
+        __syncthreads();                             // everybody is done with this segment (and with the box)
+        if (tid == 0) {
+            const unsigned K = pool / (unsigned)kPoolChunk;
+            unsigned found = 0xFFFFFFFFu;
+            for (;;) {
+                const unsigned t = atomicAdd(p.queue, 1u);
+                if (t >= K * (unsigned)G) break;
+                const unsigned v = t % (unsigned)G;
+                const unsigned old_w = atomicAdd(p.queue + 64 + v, 0x10000u);
+                const unsigned f = old_w & 0xFFFFu, r = old_w >> 16;
+                if (f + r < K) { found = (unsigned)(p.total_units * (v + 1) / G) - pool + (K - 1u - r) * (unsigned)kPoolChunk; break; }
+            }
+            ticket_box[1] = found;
+        }
+        __syncthreads();
+        const unsigned found = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket_box[1]);
+        if (found == 0xFFFFFFFFu) break;
+        u = found;
+        u_end = u + (unsigned)kPoolChunk;
+        fresh = true;
+        pf_ready = false;
+        ud_next = load_desc(p.units, u);
+        continue;
+#endif
         // the next chunk of the pool: ticket t is chunk t / G of range t % G (the chunks of one range are dealt far apart in time)
         __syncthreads();                             // (the ticket was stored a mel phase ago; everybody is done with this segment)
         const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)*ticket_box);
