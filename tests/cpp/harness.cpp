@@ -139,6 +139,32 @@ int main()
         size_t arg5 = 0;
         for (size_t k = 1; k < 257; ++k) if (P5[k] > P5[arg5]) arg5 = k;
         CHECK(arg5 == 32 && std::fabs(P5[32] / (0.5 * 512 / 4) / (0.5 * 512 / 4) - 1.0) < 1e-3);
+        // n_fft 400 / hop 160 (the matrix-product DFT kernel): 1 kHz = bin 25 of 201, the amplitude law with N = 400, and one
+        // frame against the DFT sum taken here in double
+        Stft st400(160, 1, 400);
+        CHECK(st400.n_frames(x.size()) == 1 + (16000 - 400) / 160 && st400.n_bins() == 201);
+        auto P4 = st400.power(x);
+        CHECK(P4.size() == st400.n_frames(x.size()) * 201);
+        size_t arg4 = 0;
+        for (size_t k = 1; k < 201; ++k) if (P4[k] > P4[arg4]) arg4 = k;
+        CHECK(arg4 == 25 && std::fabs(P4[25] / (0.5 * 400 / 4) / (0.5 * 400 / 4) - 1.0) < 1e-3);
+        {
+            const size_t f = 7;
+            double num = 0.0, den = 0.0;
+            for (size_t k = 0; k < 201; ++k) {
+                double re = 0.0, im = 0.0;
+                for (size_t n = 0; n < 400; ++n) {
+                    const double w = 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / 400.0);
+                    const double a = -2.0 * M_PI * (double)((k * n) % 400) / 400.0;
+                    re += w * (double)x[f * 160 + n] * std::cos(a);
+                    im += w * (double)x[f * 160 + n] * std::sin(a);
+                }
+                const double ref = re * re + im * im, d = (double)P4[f * 201 + k] - ref;
+                num += d * d;
+                den += ref * ref;
+            }
+            CHECK(std::sqrt(num / den) < 1e-5);
+        }
         MelFilterbank fb(16000, 80);
         auto W = fb.weights();
         CHECK(W.size() == 80 * 513);
