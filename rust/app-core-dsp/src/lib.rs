@@ -666,6 +666,19 @@ mod tests {
     }
 
     #[test]
+    fn test_stft_speech_frames() {                               // build-defined (docs/OPS.md "Frame lengths"): Stft::new(400, 160)
+        let mut st = Stft::new(400, 160).unwrap();               // 25 ms / 10 ms at 16 kHz (websocket.rs:274 names the format)
+        let x: Vec<f32> = (0..16000).map(|i| 0.5 * (2.0 * std::f32::consts::PI * 1000.0 * i as f32 / 16000.0).sin()).collect();
+        assert_eq!(st.n_frames(x.len()), 1 + (16000 - 400) / 160);
+        assert_eq!(st.n_bins(), 201);
+        let p = st.power(&x).unwrap();
+        let arg = (1..201).max_by(|&a, &b| p[a].partial_cmp(&p[b]).unwrap()).unwrap();
+        assert_eq!(arg, 25);                                     // 1 kHz at 16 kHz / 400
+        let law = (0.5f32 * 400.0 / 4.0).powi(2);                // a bin-centred tone of amplitude A: |X|^2 = (A N / 4)^2
+        assert!((p[25] / law - 1.0).abs() < 1e-3);
+    }
+
+    #[test]
     fn test_no_resample_needed() {                               // resampler.rs:185-190
         let mut resampler = AudioResampler::new(16000, 16000).unwrap();
         let input = vec![0.1, 0.2, 0.3, 0.4];
