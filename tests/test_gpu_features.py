@@ -463,3 +463,26 @@ def test_work_pool_gives_the_same_rows(af):
     nf = total // clips
     m = out[1].reshape(clips, nf, 80)
     assert torch.equal(m[:4].view(torch.int32), m[96:100].view(torch.int32))     # the batch repeats four clips
+
+
+def test_mel_plan_arrangement_does_not_change_a_bit(af, monkeypatch):
+    """`build_plan4` rearranges the 4 x 4 x 1 plan's pieces (rows, order in a row, first bin of each piece's window) against LDS
+    bank conflicts; `AF_M4_NO_ARRANGE=1` at handle creation keeps the first-fit layout.  A piece's products are summed in bin order
+    either way and the pieces of a band in the same order, so the rows are the same bits; the conflict score drops."""
+    import ctypes as C
+    lib = af.library()
+    x = synth_clip(17, 60000, 2, 48000)
+
+    def run():
+        p = af.FeaturePipeline()
+        info = (C.c_int32 * 12)()
+        assert lib.af_features_kernel_describe(p._h, info) == 1
+        p.set_batch_uniform(1, 60000)
+        return p.run(x), info[11]
+
+    arranged, score = run()
+    monkeypatch.setenv("AF_M4_NO_ARRANGE", "1")
+    first_fit, score_ff = run()
+    monkeypatch.delenv("AF_M4_NO_ARRANGE")
+    assert bits_equal(arranged, first_fit)
+    assert score <= 8 and score == score_ff              # (the score is the search's result either way; the layout differs)
